@@ -1,0 +1,171 @@
+/* zoe_sw.h — C ABI of the MI355X (gfx950) implementation of Zoe's striped Smith-Waterman hot path.
+ *
+ * CDCgov/zoe is a pure-Rust crate with no FFI of its own; the boundary this header replaces is the
+ * set of generic Rust functions below (file:line in the reference checkout).  Each entry point is the
+ * *batched* form of one of them: "for every read i: build the profile from read i, run the function
+ * against the context's reference".  Role convention (src/alignment/sw/mod.rs:119-120): the read is
+ * the profile sequence ("query"), the context's sequence is `reference`.
+ *
+ *   StripedProfile::<T,N,S>::new(seq,&matrix,go,ge)          src/alignment/profile.rs:239-247
+ *   sw_simd_score::<T,N,S>(reference,&profile)               src/alignment/sw/striped.rs:65-142
+ *   sw_simd_score_ends::<T,N,S>(reference,&profile)          src/alignment/sw/striped.rs:153-162
+ *   sw_simd_align::<T,N,S>(reference,&profile)               src/alignment/sw/striped.rs:449-598
+ *   ProfileSets::sw_score_from_{i8,i16,i32}                  src/alignment/profile_set.rs:71-107
+ *   ProfileSets::sw_align_from_{i8,i16,i32}                  src/alignment/profile_set.rs:124-179
+ *   LocalProfiles::new_with_w{128,256,512}                   src/alignment/profile_set.rs:434-483
+ *   Nucleotides::into_local_profile (w256)                   src/data/types/nucleotides/mod.rs:262-266
+ *   SeqSrc::make_alignment / Alignment::invert               src/alignment/mod.rs:176-190, types/output.rs:396-425
+ *
+ * Plain pointers and sizes only; no hidden global state; one context per GPU; a context may be used
+ * from one host thread at a time.  Every function returns a zsw_error and never aborts.
+ * Results are bit-identical to the reference's CPU path: score and status for every read; for the
+ * alignment calls also ranges and CIGAR of the stated <T,N> instantiation.
+ */
+#ifndef ZOE_SW_H
+#define ZOE_SW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Codes 1..4 are ProfileError (src/alignment/errors.rs:6-15) as raised by validate_profile_args
+ * (src/alignment/profile.rs:32-44). */
+typedef enum zsw_error {
+    ZSW_OK = 0,
+    ZSW_ERR_EMPTY_SEQUENCE = 1,
+    ZSW_ERR_GAP_OPEN_OUT_OF_RANGE = 2,
+    ZSW_ERR_GAP_EXTEND_OUT_OF_RANGE = 3,
+    ZSW_ERR_BAD_GAP_WEIGHTS = 4,
+    ZSW_ERR_INVALID_ARGUMENT = -1,
+    ZSW_ERR_HIP = -2,          /* a HIP runtime call failed; see zsw_last_error_string */
+    ZSW_ERR_NO_DEVICE = -3,    /* no gfx950 device / HIP runtime unusable: the product path fails loudly */
+    ZSW_ERR_UNSUPPORTED = -4,  /* valid in the reference but outside what the kernels cover (documented) */
+    ZSW_ERR_NOT_CONFIGURED = -5
+} zsw_error;
+
+/* MaybeAligned<T> (src/alignment/types/output.rs:18-25), per read. ZSW_STATUS_EMPTY marks a read of
+ * length 0, for which StripedProfile::new returns Err(ProfileError::EmptySequence). */
+typedef enum zsw_status {
+    ZSW_STATUS_SOME = 0,
+    ZSW_STATUS_OVERFLOWED = 1,
+    ZSW_STATUS_UNMAPPED = 2,
+    ZSW_STATUS_EMPTY = 3
+} zsw_status;
+
+/* T of StripedProfile<T,N,S> (AlignableIntWidth, src/math/integer.rs:231-238). Unsigned types run
+ * the biased algorithm on matrix.to_biased_matrix() (src/data/matrices/mod.rs:471-491). */
+typedef enum zsw_int_type { ZSW_I8 = 0, ZSW_I16 = 1, ZSW_I32 = 2, ZSW_U8 = 3, ZSW_U16 = 4, ZSW_U32 = 5 } zsw_int_type;
+
+typedef enum zsw_mem { ZSW_MEM_HOST = 0, ZSW_MEM_DEVICE = 1 } zsw_mem;
+
+typedef struct zsw_context zsw_context;
+
+/* A batch of profile sequences (reads). Either fixed-length (offsets == NULL, read i occupies
+ * bases[i*fixed_len, (i+1)*fixed_len)) or ragged (offsets[n_reads+1], read i = bases[offsets[i], offsets[i+1])).
+ * `mem` says where bases/offsets AND the output arrays of the call live. */
+typedef struct zsw_batch {
+    const uint8_t* bases;
+    const uint64_t* offsets;
+    uint32_t fixed_len;
+    uint64_t n_reads;
+    zsw_mem mem;
+} zsw_batch;
+
+/* Per-read alignment record: Alignment<u32> (src/alignment/types/output.rs:264-279) with
+ * AlignmentStates (src/alignment/types/state.rs:53) flattened into a ciglet array. */
+typedef struct zsw_alignment {
+    uint32_t score;
+    uint32_t ref_start, ref_end;     /* ref_range   (0-based, end-exclusive) */
+    uint32_t query_start, query_end; /* query_range (excludes clipped bases) */
+    uint32_t ref_len, query_len;
+    uint32_t n_ciglets;              /* number of (inc, op) pairs of this read */
+    uint64_t ciglet_offset;          /* index of its first pair in the ciglet arrays */
+} zsw_alignment;
+
+/* ---- context ------------------------------------------------------------------------------- */
+zsw_error zsw_create(int device_id, zsw_context** out);
+void zsw_destroy(zsw_context* ctx);
+const char* zsw_last_error_string(const zsw_context* ctx);
+int zsw_device_count(void);
+
+/* WeightMatrix<i8,S> + ByteIndexMap<S> + gap penalties, validated exactly like validate_profile_args
+ * (codes 2..4). weights[r*S + q]: row = reference residue, column = query residue
+ * (src/data/matrices/mod.rs:242-244); index_map[256] = ByteIndexMap::to_index
+ * (src/data/constants/mappings/byte_index.rs:331-333); 1 <= S <= 32. */
+zsw_error zsw_set_scoring(zsw_context* ctx, const int8_t* weights, int S, const uint8_t* index_map, int gap_open,
+                          int gap_extend);
+
+/* The `reference: &[u8]` argument of sw_simd_*; copied into the context (replicated per GPU). */
+zsw_error zsw_set_reference(zsw_context* ctx, const uint8_t* reference, size_t len, zsw_mem mem);
+
+/* ---- score-only ---------------------------------------------------------------------------- */
+/* out_score[i], out_status[i] = StripedProfile::<int_type, lanes, S>::new(read_i).sw_score(reference).
+ * `lanes` must be a power of two in 2..64 (it does not change a score; it is checked and kept for
+ * signature parity). `stream` is a hipStream_t (NULL = default stream); the call is asynchronous
+ * when batch.mem == ZSW_MEM_DEVICE. */
+zsw_error zsw_score_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes,
+                          uint32_t* out_score, uint8_t* out_status, void* stream);
+
+/* LocalProfiles::new_with_w{preset_bits}(read_i).sw_score_from_i{from_width}(reference):
+ * from_width in {8,16,32}, preset_bits in {128,256,512}. out_tier (optional) = width that answered. */
+zsw_error zsw_score_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits,
+                               uint32_t* out_score, uint8_t* out_status, uint8_t* out_tier, void* stream);
+
+/* ---- score + ends -------------------------------------------------------------------------- */
+/* sw_simd_score_ends: 0-based exclusive ends; first row holding the maximum, then first column. */
+zsw_error zsw_score_ends_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes,
+                               uint32_t* out_score, uint32_t* out_ref_end, uint32_t* out_query_end,
+                               uint8_t* out_status, void* stream);
+
+/* ---- full alignment ------------------------------------------------------------------------ */
+/* out_aln[i] / out_status[i] = StripedProfile::<int_type,lanes,S>::new(read_i).sw_align(SeqSrc::Reference(reference))
+ * (invert != 0: SeqSrc::Query(reference), i.e. the result passed through Alignment::invert).
+ * Ciglets of all reads are packed into out_inc/out_op (capacity ciglet_cap pairs); *out_n_ciglets
+ * receives the total. If the capacity is too small the call returns ZSW_ERR_INVALID_ARGUMENT and
+ * *out_n_ciglets holds the required size. This call synchronises the stream. */
+zsw_error zsw_align_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, int invert,
+                          zsw_alignment* out_aln, uint8_t* out_status, uint32_t* out_inc, uint8_t* out_op,
+                          uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream);
+
+/* LocalProfiles::new_with_w{preset_bits}(read_i).sw_align_from_i{from_width}(..): each read's CIGAR is
+ * that of the first tier that does not overflow (each tier has its own lane count). */
+zsw_error zsw_align_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, int invert,
+                               zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
+                               uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream);
+
+/* ---- bench/test utilities (not part of the reference surface) ------------------------------ */
+/* Counter-based synthetic reads: read i depends only on (seed, i, reference), so any
+ * shard regenerates its own slice. Writes reads [first, first+n) of length `len` into out (device). */
+zsw_error zsw_synth_reads(zsw_context* ctx, uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint8_t* out_device,
+                          void* stream);
+/* Ragged variant: lengths uniform in [min_len, max_len]; offsets_device[n+1] must hold the exclusive
+ * prefix sum of zsw_synth_length(seed, first+i, ..) (see zoe_amd/synth.py). */
+zsw_error zsw_synth_reads_ragged(zsw_context* ctx, uint64_t seed, uint64_t first, uint64_t n, uint32_t min_len,
+                                 uint32_t max_len, const uint64_t* offsets_device, uint8_t* out_device, void* stream);
+uint32_t zsw_synth_length(uint64_t seed, uint64_t index, uint32_t min_len, uint32_t max_len);
+
+/* Runs a small on-device check of the instruction-level assumptions the kernels make (v_perm byte
+ * order, cross-lane shuffle direction, packed saturation). Returns ZSW_OK or ZSW_ERR_HIP with the
+ * failing check named in zsw_last_error_string. */
+zsw_error zsw_selftest(zsw_context* ctx);
+
+/* Host twins of the generator (no GPU needed): tests and the CPU baseline consume the same bytes. */
+void zsw_synth_reference_host(uint64_t seed, uint64_t len, uint8_t* out);
+void zsw_synth_reads_host(uint64_t seed, uint64_t first, uint64_t n, uint32_t len, const uint8_t* ref, uint32_t R,
+                          uint8_t* out);
+void zsw_synth_reads_ragged_host(uint64_t seed, uint64_t first, uint64_t n, uint32_t min_len, uint32_t max_len,
+                                 const uint64_t* offsets, const uint8_t* ref, uint32_t R, uint8_t* out);
+
+/* HIP-event timing of the dominant kernel of each *_batch call, recorded on the call's stream.
+ * zsw_timing_read synchronises on the recorded events, returns the summed kernel seconds and the
+ * number of launches since the last read, and resets. For bench.py's roofline line. */
+zsw_error zsw_timing_enable(zsw_context* ctx, int enable);
+zsw_error zsw_timing_read(zsw_context* ctx, double* seconds, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZOE_SW_H */

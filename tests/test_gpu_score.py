@@ -1,0 +1,219 @@
+"""GPU parity tests for the score / score+ends kernels, called through the C ABI (via zoe_amd.alignment).
+
+Checker = oracle/ (CPU restatement of the reference, pinned by tests/test_oracle_golden.py).
+Bar: bit-exact score, status (and ends) for every read.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+S_, O_, U_, E_ = 0, 1, 2, 3
+
+
+@pytest.fixture(scope="module")
+def za():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests need an MI355X")
+    import zoe_amd
+
+    zoe_amd.SwContext.get(0).selftest()
+    return zoe_amd
+
+
+@pytest.fixture(scope="module")
+def dna(za):
+    return za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+
+
+def osc(oracle, m, go, ge):
+    return oracle.Scoring(m.signed_weights(), m.mapping.index_map, go, ge)
+
+
+def test_selftest(za):
+    za.SwContext.get(0).selftest()
+
+
+def test_synth_device_matches_host(za):
+    from zoe_amd import synth
+
+    ref = synth.reference_host(2000)
+    ctx = za.SwContext.get(0)
+    rb = synth.reads_device(ctx, ref, 12345, 4096, 150)
+    host = synth.reads_host(ref, 12345, 4096, 150)
+    assert np.array_equal(rb.bases.cpu().numpy().reshape(4096, 150), host)
+    rr = synth.reads_ragged_device(ctx, ref, 77, 2000, 75, 400)
+    hb, hoff = synth.reads_ragged_host(ref, 77, 2000, 75, 400)
+    assert np.array_equal(rr.offsets.cpu().numpy(), hoff)
+    assert np.array_equal(rr.bases.cpu().numpy()[: len(hb)], hb)
+
+
+def test_config1_10k_reads_i16_and_cascade(za, oracle, dna):
+    """BASELINE.json configs[0] inputs: 10k synthetic 150 bp reads vs one 2 kb reference, default matrix."""
+    from zoe_amd import synth
+
+    ref = synth.reference_host(2000)
+    n = 10000
+    host = synth.reads_host(ref, 0, n, 150)
+    sc = osc(oracle, dna, -10, -1)
+    want_s, want_st, want_tier = oracle.batch_score_w256(8, sc, host, ref, fixed_len=150, threads=8)
+    rb = za.ReadBatch.from_fixed(__import__("torch").from_numpy(host.reshape(-1)).cuda(), 150)
+    got = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1).sw_score_from_i8(ref)
+    assert np.array_equal(got.status.cpu().numpy(), want_st)
+    assert np.array_equal(got.score.cpu().numpy().view(np.uint32), want_s)
+    assert np.array_equal(got.tier.cpu().numpy(), want_tier)
+    got16 = za.StripedProfileBatch(rb, dna, -10, -1, "i16", 16).sw_score(ref)
+    assert np.array_equal(got16.score.cpu().numpy().view(np.uint32), want_s)
+    assert np.array_equal(got16.status.cpu().numpy(), want_st)
+    # i8 direct: Overflowed exactly where the true score >= 255 (striped.rs:619)
+    got8 = za.StripedProfileBatch(rb, dna, -10, -1, "i8", 32).sw_score(ref)
+    st8 = got8.status.cpu().numpy()
+    assert np.array_equal(st8 == O_, want_s >= 255)
+    # the generic plain-array oracle on a slice (every <T,N>)
+    for i in range(0, 64):
+        assert (int(want_st[i]), int(want_s[i])) == oracle.score("i16", 16, sc, host[i], ref)
+
+
+@pytest.mark.parametrize("T,N", [("i8", 32), ("i16", 16), ("i32", 8), ("u8", 32), ("u16", 16), ("u32", 8)])
+def test_all_int_types_vs_oracle(za, oracle, dna, T, N):
+    from zoe_amd import synth
+
+    ref = synth.reference_host(500)
+    host = synth.reads_host(ref, 500, 300, 60)
+    # make some reads score low/high: truncate similarity by randomising tails
+    rng = np.random.default_rng(5)
+    for i in range(0, 300, 3):
+        k = int(rng.integers(5, 60))
+        host[i, k:] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 60 - k)
+    sc = osc(oracle, dna, -10, -1)
+    m = dna if T[0] == "i" else dna.to_biased_matrix()
+    got = za.StripedProfileBatch([bytes(r) for r in host], m, -10, -1, T, N).sw_score(ref)
+    st, s = got.status.cpu().numpy(), got.score.cpu().numpy().view(np.uint32)
+    for i in range(300):
+        o_st, o_s = oracle.score(T, N, sc, host[i], ref)
+        assert (int(st[i]), int(s[i]) if st[i] == S_ else 0) == (o_st, o_s if o_st == S_ else 0), (i, T)
+
+
+def test_known_answers_through_gpu(za, oracle, h1, h5, cy):
+    """The reference's own vectors, run through the HIP path (src/alignment/sw/test.rs)."""
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    # :103-114 profile = H5 (1,760 bp), other = H1 -> Some(37); u8x16 and i16x16
+    assert za.StripedProfileBatch([h5], dna.to_biased_matrix(), -10, -1, "u8", 16).sw_score(h1).maybe_aligned(0) == ("Some", 37)
+    assert za.StripedProfileBatch([h5], dna, -10, -1, "i16", 16).sw_score(h1).maybe_aligned(0) == ("Some", 37)
+    # :88-100
+    r = za.StripedProfileBatch([b"ACGTUNacgtun"], dna, -10, -1, "i16", 16).sw_score(b"ACGTTNACGTTN")
+    assert r.maybe_aligned(0) == ("Some", 20)
+    # :265-271, :274-280, :304-311
+    v = b"A" * 100
+    assert za.StripedProfileBatch([v], dna.to_biased_matrix(), -10, -1, "u16", 16).sw_score(v).maybe_aligned(0) == ("Some", 200)
+    assert za.StripedProfileBatch([cy], dna.to_biased_matrix(), -10, -1, "u16", 16).sw_score(cy).maybe_aligned(0) == ("Some", 3372)
+    r = za.LocalProfilesBatch.new_with_w128([cy], dna, -10, -1).sw_score_from_i8(cy)
+    assert r.maybe_aligned(0) == ("Some", 3372) and int(r.tier[0]) == 16
+    # :283-290 lazy-F regression
+    m = za.WeightMatrix.new(za.DNA_PROFILE_MAP, 10, -10, b"N").to_biased_matrix()
+    assert za.StripedProfileBatch([b"AGA"], m, -5, -5, "u16", 4).sw_score(b"AA").maybe_aligned(0) == ("Some", 15)
+    # :293-301 overflow
+    m = za.WeightMatrix.new(za.DNA_PROFILE_MAP, 127, 0, b"N").to_biased_matrix()
+    assert za.StripedProfileBatch([b"AAAA"], m, -10, -1, "u8", 8).sw_score(b"AAAA").maybe_aligned(0) == ("Overflowed", None)
+    # striped.rs:45-55
+    m = za.WeightMatrix.new_biased_dna_matrix(4, -2, b"N")
+    r = za.StripedProfileBatch([b"CGTTCGCCATAAAGGGGG"], m, -3, -1, "u8", 32).sw_score(b"ATGCATCGATCGATCGATCGATCGATCGATGC")
+    assert r.maybe_aligned(0) == ("Some", 26)
+    # sw/mod.rs:193-218 custom alphabet (S = 4, catch-all A)
+    mp = za.ByteIndexMap.new(b"ABCD", b"A")
+    m = za.WeightMatrix.new(mp, 1, -1, None)
+    assert za.StripedProfileBatch([b"AABDDAB"], m, -4, -2, "i8", 32).sw_score(b"BDAACAABDDDB").maybe_aligned(0) == ("Some", 5)
+
+
+def test_score_ends_vs_oracle(za, oracle, dna):
+    from zoe_amd import synth
+
+    ref = synth.reference_host(700)
+    host = synth.reads_host(ref, 9000, 400, 90)
+    host[5] = np.frombuffer(b"N" * 90, dtype=np.uint8)
+    sc = osc(oracle, dna, -10, -1)
+    got = za.StripedProfileBatch([bytes(r) for r in host], dna, -10, -1, "i16", 16).sw_score_ends(za.SeqSrc.Reference(ref))
+    st, s = got.status.cpu().numpy(), got.score.cpu().numpy()
+    re_, qe = got.ref_end.cpu().numpy(), got.query_end.cpu().numpy()
+    for i in range(400):
+        o_st, (o_s, o_re, o_qe) = oracle.score_ends("i16", 16, sc, host[i], ref)
+        assert int(st[i]) == o_st, i
+        if o_st == S_:
+            assert (int(s[i]), int(re_[i]), int(qe[i])) == (o_s, o_re, o_qe), i
+    # low-complexity ties: first row, then first column (striped.rs:312-321 == scalar.rs:207-211)
+    reads = [b"TTTTTTTT", b"ACACACAC", b"GGGGG", b"CCCCA", b"TTTAG"]
+    refs = b"TTTTTTTTTTTTACACACACACACACGGGGGGGGTAAAACCCC"
+    got = za.StripedProfileBatch(reads, dna, -10, -1, "i8", 8).sw_score_ends(za.SeqSrc.Reference(refs))
+    for i, rd in enumerate(reads):
+        o_st, (o_s, o_re, o_qe) = oracle.score_ends("i8", 8, osc(oracle, dna, -10, -1), rd, refs)
+        assert (int(got.status[i]), int(got.score[i]), int(got.ref_end[i]), int(got.query_end[i])) == (o_st, o_s, o_re, o_qe)
+
+
+def test_ragged_and_edge_cases(za, oracle, dna):
+    from zoe_amd import synth
+
+    ref = synth.reference_host(1000)
+    hb, hoff = synth.reads_ragged_host(ref, 3, 257, 20, 300)  # odd count: last lane pair half empty
+    reads = [hb[hoff[i] : hoff[i + 1]].tobytes() for i in range(257)]
+    reads[10] = b"N" * 40  # unmapped
+    reads[11] = b"acgu" * 10  # lower case + U
+    reads[12] = bytes(range(256))  # arbitrary bytes -> catch-all
+    sc = osc(oracle, dna, -10, -1)
+    got = za.LocalProfilesBatch.new_with_w256(reads, dna, -10, -1).sw_score_from_i8(ref)
+    st, s = got.status.cpu().numpy(), got.score.cpu().numpy()
+    for i, rd in enumerate(reads):
+        o_st, o_s, o_tier = oracle.cascade_score(8, 256, sc, rd, ref)
+        assert (int(st[i]), int(s[i]) if o_st == S_ else 0, int(got.tier[i])) == (o_st, o_s if o_st == S_ else 0, o_tier), i
+    # empty reference -> Unmapped (striped.rs:140-141 with best = MIN)
+    got = za.StripedProfileBatch(reads[:8], dna, -10, -1, "i16", 16).sw_score(b"")
+    assert (got.status.cpu().numpy() == U_).all()
+    # an empty read is ProfileError::EmptySequence (profile.rs:33-34)
+    with pytest.raises(za.ProfileError) as ei:
+        za.StripedProfileBatch([b"ACGT", b""], dna, -10, -1, "i16", 16)
+    assert ei.value.variant == "EmptySequence"
+    for go, ge, variant in ((1, 0, "GapOpenOutOfRange"), (-10, 1, "GapExtendOutOfRange"), (-1, -2, "BadGapWeights")):
+        with pytest.raises(za.ProfileError) as ei:
+            za.StripedProfileBatch([b"ACGT"], dna, go, ge, "i16", 16)
+        assert ei.value.variant == variant
+
+
+def test_generic_matrix_and_i16_saturation(za, oracle):
+    """A matrix whose N column is not zero takes the biased-table kernel; weights of 127 push scores past
+    i16 so the exact 32-bit kernel answers (cascade tier 32)."""
+    rng = np.random.default_rng(11)
+    w = rng.integers(-9, 10, size=(5, 5)).astype(np.int8)
+    m = za.WeightMatrix.new_custom(za.DNA_PROFILE_MAP, w)
+    ref = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), 400))
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(rng.integers(10, 150)))) for _ in range(200)]
+    sc = oracle.Scoring(w, za.DNA_PROFILE_MAP.index_map, -4, -2)
+    got = za.LocalProfilesBatch.new_with_w256(reads, m, -4, -2).sw_score_from_i8(ref)
+    for i, rd in enumerate(reads):
+        o_st, o_s, o_tier = oracle.cascade_score(8, 256, sc, rd, ref)
+        assert (int(got.status[i]), int(got.score[i]) if o_st == S_ else 0, int(got.tier[i])) == (o_st, o_s if o_st == S_ else 0, o_tier), i
+    big = za.WeightMatrix.new_dna_matrix(127, -127, b"N")
+    long_read = b"ACGT" * 150  # 600 x 127 = 76,200 > 65,535
+    refl = b"TT" + long_read + b"GG"
+    r = za.LocalProfilesBatch.new_with_w256([long_read, b"ACGTACGT"], big, -10, -1).sw_score_from_i8(refl)
+    assert r.maybe_aligned(0) == ("Some", 600 * 127) and int(r.tier[0]) == 32
+    assert r.maybe_aligned(1) == ("Some", 8 * 127) and int(r.tier[1]) == 16
+    r = za.StripedProfileBatch([long_read], big, -10, -1, "i16", 16).sw_score(refl)
+    assert r.maybe_aligned(0) == ("Overflowed", None)
+
+
+def test_protein_alphabet_exact_kernel(za, oracle):
+    """S = 25-style alphabets fall outside the table kernels and run on the exact 32-bit kernel."""
+    rng = np.random.default_rng(3)
+    keys = b"ARNDCQEGHILKMFPSTWYV"
+    mp = za.ByteIndexMap.new(keys, b"A")
+    w = rng.integers(-4, 8, size=(20, 20)).astype(np.int8)
+    w = ((w + w.T) // 2).astype(np.int8)
+    m = za.WeightMatrix.new_custom(mp, w)
+    ref = bytes(rng.choice(np.frombuffer(keys, dtype=np.uint8), 300))
+    reads = [bytes(rng.choice(np.frombuffer(keys, dtype=np.uint8), int(rng.integers(5, 80)))) for _ in range(60)]
+    sc = oracle.Scoring(w, mp.index_map, -11, -1)
+    got = za.StripedProfileBatch(reads, m, -11, -1, "i16", 16).sw_score(ref)
+    for i, rd in enumerate(reads):
+        o_st, o_s = oracle.score("i16", 16, sc, rd, ref)
+        assert (int(got.status[i]), int(got.score[i]) if o_st == S_ else 0) == (o_st, o_s if o_st == S_ else 0), i

@@ -1,0 +1,107 @@
+"""ctypes binding of libzoe_sw_hip.so (the C ABI declared in include/zoe_sw.h).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is usable, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzoe_sw_hip.so")
+
+ZSW_OK = 0
+ERROR_NAMES = {
+    0: "ZSW_OK",
+    1: "ProfileError::EmptySequence",
+    2: "ProfileError::GapOpenOutOfRange",
+    3: "ProfileError::GapExtendOutOfRange",
+    4: "ProfileError::BadGapWeights",
+    -1: "ZSW_ERR_INVALID_ARGUMENT",
+    -2: "ZSW_ERR_HIP",
+    -3: "ZSW_ERR_NO_DEVICE",
+    -4: "ZSW_ERR_UNSUPPORTED",
+    -5: "ZSW_ERR_NOT_CONFIGURED",
+}
+MEM_HOST, MEM_DEVICE = 0, 1
+INT_TYPES = {"i8": 0, "i16": 1, "i32": 2, "u8": 3, "u16": 4, "u32": 5}
+
+# every symbol include/zoe_sw.h declares (tests/test_capi_symbols.py checks the two lists agree)
+SYMBOLS = [
+    "zsw_create", "zsw_destroy", "zsw_last_error_string", "zsw_device_count", "zsw_set_scoring", "zsw_set_reference",
+    "zsw_score_batch", "zsw_score_batch_from", "zsw_score_ends_batch", "zsw_align_batch", "zsw_align_batch_from",
+    "zsw_synth_reads", "zsw_synth_reads_ragged", "zsw_synth_length", "zsw_synth_reference_host", "zsw_synth_reads_host",
+    "zsw_synth_reads_ragged_host", "zsw_selftest", "zsw_timing_enable", "zsw_timing_read",
+]
+
+
+class ZswBatch(C.Structure):
+    _fields_ = [
+        ("bases", C.c_void_p),
+        ("offsets", C.c_void_p),
+        ("fixed_len", C.c_uint32),
+        ("n_reads", C.c_uint64),
+        ("mem", C.c_int),
+    ]
+
+
+class ZswAlignment(C.Structure):
+    _fields_ = [
+        ("score", C.c_uint32),
+        ("ref_start", C.c_uint32),
+        ("ref_end", C.c_uint32),
+        ("query_start", C.c_uint32),
+        ("query_end", C.c_uint32),
+        ("ref_len", C.c_uint32),
+        ("query_len", C.c_uint32),
+        ("n_ciglets", C.c_uint32),
+        ("ciglet_offset", C.c_uint64),
+    ]
+
+
+class ZswError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        name = ERROR_NAMES.get(code, str(code))
+        super().__init__(f"{name}{': ' + detail if detail else ''}")
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads the HIP library; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZswError(-3, f"{LIB_PATH} not built: run `python -m zoe_amd.build` (hipcc, gfx950)")
+    lib = C.CDLL(LIB_PATH)
+    vp, u8p, u32p, u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    lib.zsw_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.zsw_destroy.argtypes = [vp]
+    lib.zsw_destroy.restype = None
+    lib.zsw_last_error_string.argtypes = [vp]
+    lib.zsw_last_error_string.restype = C.c_char_p
+    lib.zsw_set_scoring.argtypes = [vp, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    lib.zsw_set_reference.argtypes = [vp, C.c_void_p, C.c_size_t, C.c_int]
+    lib.zsw_score_batch.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, u32p, u8p, vp]
+    lib.zsw_score_batch_from.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, u32p, u8p, u8p, vp]
+    lib.zsw_score_ends_batch.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, u32p, u32p, u32p, u8p, vp]
+    lib.zsw_align_batch.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, C.c_int, vp, u8p, u32p, u8p, C.c_uint64, C.POINTER(C.c_uint64), vp]
+    lib.zsw_align_batch_from.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, C.c_int, vp, u8p, u8p, u32p, u8p, C.c_uint64, C.POINTER(C.c_uint64), vp]
+    lib.zsw_synth_reads.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp]
+    lib.zsw_synth_reads_ragged.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p, vp, vp]
+    lib.zsw_synth_length.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+    lib.zsw_synth_length.restype = C.c_uint32
+    lib.zsw_synth_reference_host.argtypes = [C.c_uint64, C.c_uint64, vp]
+    lib.zsw_synth_reference_host.restype = None
+    lib.zsw_synth_reads_host.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp, C.c_uint32, vp]
+    lib.zsw_synth_reads_host.restype = None
+    lib.zsw_synth_reads_ragged_host.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p, vp, C.c_uint32, vp]
+    lib.zsw_synth_reads_ragged_host.restype = None
+    lib.zsw_selftest.argtypes = [vp]
+    lib.zsw_timing_enable.argtypes = [vp, C.c_int]
+    lib.zsw_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    _lib = lib
+    return lib

@@ -1,0 +1,511 @@
+"""Host-side mirror of the reference's interface for the striped Smith-Waterman path, batched over reads.
+
+Names, argument meaning and error behaviour follow the reference (file:line in the reference checkout):
+
+    ByteIndexMap, DNA_PROFILE_MAP        src/data/constants/mappings/byte_index.rs:231-358, dna.rs:177-178
+    WeightMatrix                         src/data/matrices/mod.rs:230-546
+    ProfileError / validate_profile_args src/alignment/errors.rs:6-15, profile.rs:32-44
+    StripedProfile::{new,sw_score,sw_score_ends,sw_align}   src/alignment/profile.rs:239-519
+    LocalProfiles::new_with_w{128,256,512} + ProfileSets    src/alignment/profile_set.rs:71-179,434-483
+    MaybeAligned                         src/alignment/types/output.rs:18-25
+    SeqSrc                               src/alignment/mod.rs:161-190
+
+The reference builds one profile from one sequence and aligns it against many; here a *batch* of reads
+plays the profile role (sw/mod.rs:119-120: the profile is built from the query) and every call runs all
+of them against one reference on the GPU through the C ABI (include/zoe_sw.h).  PyTorch is used only
+to own device memory and streams.  There is no CPU path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib
+
+SOME, OVERFLOWED, UNMAPPED, EMPTY = 0, 1, 2, 3
+
+
+class ProfileError(ValueError):
+    """src/alignment/errors.rs:6-15"""
+
+    NAMES = {1: "EmptySequence", 2: "GapOpenOutOfRange", 3: "GapExtendOutOfRange", 4: "BadGapWeights"}
+
+    def __init__(self, code: int):
+        self.code = code
+        self.variant = self.NAMES[code]
+        super().__init__(self.variant)
+
+
+def validate_profile_args(seq_len: int, gap_open: int, gap_extend: int) -> None:
+    """src/alignment/profile.rs:32-44"""
+    if seq_len == 0:
+        raise ProfileError(1)
+    if not -127 <= gap_open <= 0:
+        raise ProfileError(2)
+    if not -127 <= gap_extend <= 0:
+        raise ProfileError(3)
+    if gap_extend < gap_open:
+        raise ProfileError(4)
+
+
+class ByteIndexMap:
+    """256-entry byte -> residue-index table (byte_index.rs:231-358)."""
+
+    def __init__(self, index_map: np.ndarray, byte_keys: bytes):
+        self.index_map = np.ascontiguousarray(index_map, dtype=np.uint8)
+        self.byte_keys = bytes(byte_keys)
+
+    @staticmethod
+    def new(byte_keys: bytes, catch_all: bytes) -> "ByteIndexMap":
+        keys = bytes(byte_keys)
+        if len(set(keys)) != len(keys):
+            raise ValueError("duplicate byte_keys")
+        if catch_all[0] not in keys:
+            raise ValueError("The catch_all must be present in the byte_keys.")
+        m = np.full(256, keys.index(catch_all[0]), dtype=np.uint8)
+        for i, k in enumerate(keys):
+            m[k] = i
+        return ByteIndexMap(m, keys)
+
+    @staticmethod
+    def new_ignoring_case(byte_keys: bytes, catch_all: bytes) -> "ByteIndexMap":
+        keys = bytes(byte_keys).upper()
+        if len(set(keys)) != len(keys):
+            raise ValueError("duplicate byte_keys")
+        ca = bytes(catch_all).upper()[0]
+        if ca not in keys:
+            raise ValueError("The catch_all must be present in the byte_keys.")
+        m = np.full(256, keys.index(ca), dtype=np.uint8)
+        for i, k in enumerate(keys):
+            m[k] = i
+            m[bytes([k]).lower()[0]] = i
+        return ByteIndexMap(m, keys)
+
+    def add_synonym_ignore_case(self, new_key: bytes, previous_key: bytes) -> "ByteIndexMap":
+        m = self.index_map.copy()
+        idx = m[previous_key[0]]
+        m[bytes(new_key).upper()[0]] = idx
+        m[bytes(new_key).lower()[0]] = idx
+        return ByteIndexMap(m, self.byte_keys)
+
+    def __len__(self) -> int:
+        return len(self.byte_keys)
+
+    def to_index(self, b: int) -> int:
+        return int(self.index_map[b])
+
+
+# dna.rs:177-178
+DNA_PROFILE_MAP = ByteIndexMap.new_ignoring_case(b"ACGTN", b"N").add_synonym_ignore_case(b"U", b"T")
+
+
+class WeightMatrix:
+    """weights[ref_residue][query_residue] (matrices/mod.rs:230-235). `bias` is non-zero only for the
+    unsigned form produced by to_biased_matrix()."""
+
+    def __init__(self, weights: np.ndarray, mapping: ByteIndexMap, bias: int = 0, signed: bool = True):
+        self.weights = np.ascontiguousarray(weights)
+        self.mapping = mapping
+        self.bias = int(bias)
+        self.signed = signed
+
+    @staticmethod
+    def new(mapping: ByteIndexMap, matching: int, mismatch: int, ignoring: Optional[bytes]) -> "WeightMatrix":
+        S = len(mapping)
+        w = np.zeros((S, S), dtype=np.int8)
+        skip = None
+        if ignoring is not None:
+            if ignoring[0] not in mapping.byte_keys:
+                raise ValueError("An invalid byte was specified for the ignoring field.")
+            skip = mapping.to_index(ignoring[0])
+        for i in range(S):
+            for j in range(S):
+                if skip is not None and (skip == i or skip == j):
+                    continue
+                w[i, j] = matching if i == j else mismatch
+        return WeightMatrix(w, mapping)
+
+    @staticmethod
+    def new_custom(mapping: ByteIndexMap, weights) -> "WeightMatrix":
+        w = np.asarray(weights, dtype=np.int8)
+        S = len(mapping)
+        if w.shape != (S, S):
+            raise ValueError("weights must be SxS")
+        return WeightMatrix(w, mapping)
+
+    @staticmethod
+    def new_dna_matrix(matching: int, mismatch: int, ignoring: Optional[bytes]) -> "WeightMatrix":
+        return WeightMatrix.new(DNA_PROFILE_MAP, matching, mismatch, ignoring)
+
+    @staticmethod
+    def new_biased_dna_matrix(matching: int, mismatch: int, ignoring: Optional[bytes]) -> "WeightMatrix":
+        return WeightMatrix.new_dna_matrix(matching, mismatch, ignoring).to_biased_matrix()
+
+    def get_bias(self) -> int:
+        return int(min(0, int(self.weights.min())))
+
+    def to_biased_matrix(self) -> "WeightMatrix":
+        if not self.signed:
+            return self
+        b = self.get_bias()
+        w = (self.weights.astype(np.int16) - b).astype(np.uint8)
+        return WeightMatrix(w, self.mapping, bias=-b, signed=False)
+
+    def signed_weights(self) -> np.ndarray:
+        if self.signed:
+            return self.weights.astype(np.int8)
+        return (self.weights.astype(np.int16) - self.bias).astype(np.int8)
+
+    def get_weight(self, ref_residue: int, query_residue: int) -> int:
+        return int(self.weights[self.mapping.to_index(ref_residue)][self.mapping.to_index(query_residue)])
+
+
+@dataclass(frozen=True)
+class SeqSrc:
+    """src/alignment/mod.rs:161-166: tells an alignment call which role the non-profile sequence plays."""
+
+    seq: bytes
+    is_query: bool
+
+    @staticmethod
+    def Reference(seq) -> "SeqSrc":
+        return SeqSrc(bytes(seq), False)
+
+    @staticmethod
+    def Query(seq) -> "SeqSrc":
+        return SeqSrc(bytes(seq), True)
+
+
+# ------------------------------------------------------------------------------------------------
+def _torch():
+    import torch
+
+    return torch
+
+
+class SwContext:
+    """One zsw_context per GPU (include/zoe_sw.h). Raises if the HIP library or the device is missing."""
+
+    _cache = {}
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        self.device = device
+        h = C.c_void_p()
+        rc = self.lib.zsw_create(device, C.byref(h))
+        if rc != 0:
+            raise _lib.ZswError(rc, "zsw_create")
+        self.h = h
+        self._scoring_key = None
+        self._ref_key = None
+
+    @classmethod
+    def get(cls, device: int = 0) -> "SwContext":
+        if device not in cls._cache:
+            cls._cache[device] = SwContext(device)
+        return cls._cache[device]
+
+    def check(self, rc: int, profile_errors: bool = True):
+        if rc == 0:
+            return
+        if profile_errors and 1 <= rc <= 4:
+            raise ProfileError(rc)
+        raise _lib.ZswError(rc, self.lib.zsw_last_error_string(self.h).decode())
+
+    def set_scoring(self, matrix: WeightMatrix, gap_open: int, gap_extend: int):
+        w = np.ascontiguousarray(matrix.signed_weights(), dtype=np.int8)
+        key = (w.tobytes(), matrix.mapping.index_map.tobytes(), gap_open, gap_extend)
+        if key == self._scoring_key:
+            return
+        im = matrix.mapping.index_map
+        self.check(self.lib.zsw_set_scoring(self.h, w.ctypes.data, w.shape[0], im.ctypes.data, gap_open, gap_extend))
+        self._scoring_key = key
+
+    def set_reference(self, reference) -> None:
+        torch = _torch()
+        if isinstance(reference, torch.Tensor):
+            ref = reference.contiguous()
+            key = ("t", ref.data_ptr(), ref.numel())
+            if key == self._ref_key:
+                return
+            mem = _lib.MEM_DEVICE if ref.is_cuda else _lib.MEM_HOST
+            self.check(self.lib.zsw_set_reference(self.h, ref.data_ptr(), ref.numel(), mem))
+            self._ref_key = None  # tensor contents may change; do not cache
+            return
+        ref = bytes(reference)
+        key = ("b", ref)
+        if key == self._ref_key:
+            return
+        buf = np.frombuffer(ref, dtype=np.uint8) if ref else np.zeros(1, dtype=np.uint8)
+        self.check(self.lib.zsw_set_reference(self.h, buf.ctypes.data, len(ref), _lib.MEM_HOST))
+        self._ref_key = key
+
+    def stream(self) -> int:
+        torch = _torch()
+        return int(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def selftest(self):
+        self.check(self.lib.zsw_selftest(self.h), profile_errors=False)
+
+    def timing_enable(self, on: bool):
+        self.check(self.lib.zsw_timing_enable(self.h, int(on)))
+
+    def timing_read(self):
+        s, n = C.c_double(0), C.c_uint64(0)
+        self.check(self.lib.zsw_timing_read(self.h, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
+
+class ReadBatch:
+    """Device-resident reads: `bases` uint8 (concatenated), and either `fixed_len` or `offsets` (int64[n+1])."""
+
+    def __init__(self, bases, n_reads: int, fixed_len: int = 0, offsets=None, min_len: Optional[int] = None):
+        self.bases = bases
+        self.n_reads = int(n_reads)
+        self.fixed_len = int(fixed_len)
+        self.offsets = offsets
+        self.min_len = min_len  # known on the host when built from host data
+
+    @staticmethod
+    def from_sequences(seqs: Sequence[bytes], device: int = 0) -> "ReadBatch":
+        torch = _torch()
+        lens = [len(s) for s in seqs]
+        dev = torch.device("cuda", device)
+        cat = b"".join(bytes(s) for s in seqs)
+        bases = torch.frombuffer(bytearray(cat if cat else b"\0"), dtype=torch.uint8).to(dev)
+        if lens and all(l == lens[0] for l in lens) and lens[0] > 0:
+            return ReadBatch(bases, len(seqs), fixed_len=lens[0], min_len=lens[0])
+        off = np.zeros(len(seqs) + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        return ReadBatch(bases, len(seqs), offsets=torch.from_numpy(off).to(dev), min_len=min(lens) if lens else None)
+
+    @staticmethod
+    def from_fixed(bases, fixed_len: int) -> "ReadBatch":
+        return ReadBatch(bases, bases.numel() // fixed_len, fixed_len=fixed_len, min_len=fixed_len)
+
+    def c_batch(self) -> _lib.ZswBatch:
+        b = _lib.ZswBatch()
+        b.bases = self.bases.data_ptr()
+        b.offsets = self.offsets.data_ptr() if self.offsets is not None else None
+        b.fixed_len = self.fixed_len
+        b.n_reads = self.n_reads
+        b.mem = _lib.MEM_DEVICE
+        return b
+
+    @property
+    def device_index(self) -> int:
+        return self.bases.device.index or 0
+
+
+@dataclass
+class ScoreBatch:
+    """MaybeAligned<u32> per read: status (SOME/OVERFLOWED/UNMAPPED/EMPTY) + score (valid where SOME)."""
+
+    score: "object"
+    status: "object"
+    tier: Optional["object"] = None
+    ref_end: Optional["object"] = None
+    query_end: Optional["object"] = None
+
+    def maybe_aligned(self, i: int):
+        st = int(self.status[i])
+        return ("Some", int(self.score[i])) if st == SOME else ({1: "Overflowed", 2: "Unmapped", 3: "Empty"}[st], None)
+
+
+@dataclass
+class AlignmentBatch:
+    """MaybeAligned<Alignment<u32>> per read; ciglets flattened (inc, op) with per-read offsets."""
+
+    status: np.ndarray
+    records: np.ndarray  # structured: score, ref_start, ref_end, query_start, query_end, ref_len, query_len, n_ciglets, ciglet_offset
+    inc: np.ndarray
+    op: np.ndarray
+    tier: Optional[np.ndarray] = None
+
+    def cigar(self, i: int) -> str:
+        r = self.records[i]
+        o, n = int(r["ciglet_offset"]), int(r["n_ciglets"])
+        return "".join(f"{int(self.inc[o + k])}{chr(int(self.op[o + k]))}" for k in range(n))
+
+    def key(self, i: int):
+        st = int(self.status[i])
+        if st != SOME:
+            return (st, 0, (0, 0), (0, 0), "", 0, 0)
+        r = self.records[i]
+        return (st, int(r["score"]), (int(r["ref_start"]), int(r["ref_end"])), (int(r["query_start"]), int(r["query_end"])),
+                self.cigar(i), int(r["ref_len"]), int(r["query_len"]))
+
+
+ALN_DTYPE = np.dtype(
+    [("score", "<u4"), ("ref_start", "<u4"), ("ref_end", "<u4"), ("query_start", "<u4"), ("query_end", "<u4"),
+     ("ref_len", "<u4"), ("query_len", "<u4"), ("n_ciglets", "<u4"), ("ciglet_offset", "<u8")]
+)
+
+
+def _as_batch(reads, device: int) -> ReadBatch:
+    if isinstance(reads, ReadBatch):
+        return reads
+    return ReadBatch.from_sequences(list(reads), device)
+
+
+class _ProfileBatchBase:
+    def __init__(self, reads, matrix: WeightMatrix, gap_open: int, gap_extend: int, device: int = 0):
+        rb = _as_batch(reads, device)
+        # validate_profile_args: the sequence check is per read; an empty read known on the host raises here,
+        # one only visible on the device comes back with status EMPTY.
+        validate_profile_args(1 if rb.min_len is None else rb.min_len, gap_open, gap_extend)
+        self.reads = rb
+        self.matrix = matrix
+        self.gap_open = gap_open
+        self.gap_extend = gap_extend
+        self.ctx = SwContext.get(rb.device_index)
+
+    def _prep(self, reference):
+        self.ctx.set_scoring(self.matrix, self.gap_open, self.gap_extend)
+        self.ctx.set_reference(reference)
+
+    def _align(self, seq: SeqSrc, direct, from_width=None, preset=None) -> AlignmentBatch:
+        torch = _torch()
+        self._prep(seq.seq)
+        n = self.reads.n_reads
+        dev = self.reads.bases.device
+        aln = torch.zeros(max(n, 1) * ALN_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        status = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+        tier = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+        cap = max(16 * n, 64)
+        b = self.reads.c_batch()
+        total = C.c_uint64(0)
+        while True:
+            inc = torch.zeros(cap, dtype=torch.int32, device=dev)
+            op = torch.zeros(cap, dtype=torch.uint8, device=dev)
+            if direct is not None:
+                rc = self.ctx.lib.zsw_align_batch(self.ctx.h, C.byref(b), direct[0], direct[1], int(seq.is_query), aln.data_ptr(),
+                                                  status.data_ptr(), inc.data_ptr(), op.data_ptr(), cap, C.byref(total), self.ctx.stream())
+            else:
+                rc = self.ctx.lib.zsw_align_batch_from(self.ctx.h, C.byref(b), from_width, preset, int(seq.is_query), aln.data_ptr(),
+                                                       status.data_ptr(), tier.data_ptr(), inc.data_ptr(), op.data_ptr(), cap,
+                                                       C.byref(total), self.ctx.stream())
+            if rc == -1 and total.value > cap:
+                cap = int(total.value)
+                continue
+            self.ctx.check(rc)
+            break
+        torch.cuda.synchronize(dev)
+        rec = np.frombuffer(aln.cpu().numpy().tobytes(), dtype=ALN_DTYPE)[:n]
+        return AlignmentBatch(status.cpu().numpy()[:n], rec, inc.cpu().numpy().view(np.uint32)[: total.value],
+                              op.cpu().numpy()[: total.value], tier.cpu().numpy()[:n] if direct is None else None)
+
+
+class StripedProfileBatch(_ProfileBatchBase):
+    """`StripedProfile::<T, N, S>::new(read_i, &matrix, gap_open, gap_extend)` for every read of a batch.
+
+    For unsigned T pass matrix.to_biased_matrix() exactly as the reference requires (profile.rs:215-219)."""
+
+    def __init__(self, reads, matrix: WeightMatrix, gap_open: int, gap_extend: int, T: str = "i16", N: int = 16, device: int = 0):
+        if T not in _lib.INT_TYPES:
+            raise ValueError(f"T must be one of {list(_lib.INT_TYPES)}")
+        if T.startswith("u") and matrix.signed:
+            raise ValueError("unsigned T needs matrix.to_biased_matrix() (profile.rs:215-219)")
+        if T.startswith("i") and not matrix.signed:
+            raise ValueError("signed T needs the signed matrix")
+        super().__init__(reads, matrix, gap_open, gap_extend, device)
+        self.T, self.N = T, N
+
+    new = classmethod(lambda cls, *a, **k: cls(*a, **k))
+
+    def sw_score(self, reference) -> ScoreBatch:
+        """profile.rs:440-446 → sw_simd_score (striped.rs:65-142)"""
+        torch = _torch()
+        self._prep(reference)
+        n = self.reads.n_reads
+        dev = self.reads.bases.device
+        score = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        b = self.reads.c_batch()
+        self.ctx.check(self.ctx.lib.zsw_score_batch(self.ctx.h, C.byref(b), _lib.INT_TYPES[self.T], self.N, score.data_ptr(),
+                                                    status.data_ptr(), self.ctx.stream()))
+        return ScoreBatch(score[:n], status[:n])
+
+    def sw_score_ends(self, seq: SeqSrc) -> ScoreBatch:
+        """profile.rs:456-460 → sw_simd_score_ends (striped.rs:153-162). SeqSrc::Query swaps the two ends."""
+        torch = _torch()
+        self._prep(seq.seq)
+        n = self.reads.n_reads
+        dev = self.reads.bases.device
+        score = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        rend = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        qend = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        b = self.reads.c_batch()
+        self.ctx.check(self.ctx.lib.zsw_score_ends_batch(self.ctx.h, C.byref(b), _lib.INT_TYPES[self.T], self.N, score.data_ptr(),
+                                                         rend.data_ptr(), qend.data_ptr(), status.data_ptr(), self.ctx.stream()))
+        if seq.is_query:
+            rend, qend = qend, rend
+        return ScoreBatch(score[:n], status[:n], ref_end=rend[:n], query_end=qend[:n])
+
+    def sw_align(self, seq: SeqSrc) -> AlignmentBatch:
+        """profile.rs:515-519 → sw_simd_align (striped.rs:449-598)"""
+        return self._align(seq, (_lib.INT_TYPES[self.T], self.N))
+
+
+class LocalProfilesBatch(_ProfileBatchBase):
+    """`LocalProfiles::new_with_w{128,256,512}(read_i, &matrix, gap_open, gap_extend)` for every read."""
+
+    def __init__(self, reads, matrix: WeightMatrix, gap_open: int, gap_extend: int, preset: int = 256, device: int = 0):
+        if not matrix.signed:
+            raise ValueError("profile sets take the signed matrix (profile_set.rs:382-390)")
+        if preset not in (128, 256, 512):
+            raise ValueError("preset must be 128, 256 or 512")
+        super().__init__(reads, matrix, gap_open, gap_extend, device)
+        self.preset = preset
+
+    @classmethod
+    def new_with_w128(cls, reads, matrix, gap_open, gap_extend, device=0):
+        return cls(reads, matrix, gap_open, gap_extend, 128, device)
+
+    @classmethod
+    def new_with_w256(cls, reads, matrix, gap_open, gap_extend, device=0):
+        return cls(reads, matrix, gap_open, gap_extend, 256, device)
+
+    @classmethod
+    def new_with_w512(cls, reads, matrix, gap_open, gap_extend, device=0):
+        return cls(reads, matrix, gap_open, gap_extend, 512, device)
+
+    def _score_from(self, reference, width: int) -> ScoreBatch:
+        torch = _torch()
+        self._prep(reference)
+        n = self.reads.n_reads
+        dev = self.reads.bases.device
+        score = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        tier = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        b = self.reads.c_batch()
+        self.ctx.check(self.ctx.lib.zsw_score_batch_from(self.ctx.h, C.byref(b), width, self.preset, score.data_ptr(),
+                                                         status.data_ptr(), tier.data_ptr(), self.ctx.stream()))
+        return ScoreBatch(score[:n], status[:n], tier=tier[:n])
+
+    def sw_score_from_i8(self, reference) -> ScoreBatch:
+        return self._score_from(reference, 8)
+
+    def sw_score_from_i16(self, reference) -> ScoreBatch:
+        return self._score_from(reference, 16)
+
+    def sw_score_from_i32(self, reference) -> ScoreBatch:
+        return self._score_from(reference, 32)
+
+    def sw_align_from_i8(self, seq: SeqSrc) -> AlignmentBatch:
+        return self._align(seq, None, 8, self.preset)
+
+    def sw_align_from_i16(self, seq: SeqSrc) -> AlignmentBatch:
+        return self._align(seq, None, 16, self.preset)
+
+    def sw_align_from_i32(self, seq: SeqSrc) -> AlignmentBatch:
+        return self._align(seq, None, 32, self.preset)
+
+
+def into_local_profile(reads, matrix: WeightMatrix, gap_open: int, gap_extend: int, device: int = 0) -> LocalProfilesBatch:
+    """Nucleotides::into_local_profile (nucleotides/mod.rs:262-266): the w256 preset."""
+    return LocalProfilesBatch.new_with_w256(reads, matrix, gap_open, gap_extend, device)

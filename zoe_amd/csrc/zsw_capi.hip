@@ -1,0 +1,456 @@
+// zsw_capi.hip — the C ABI (include/zoe_sw.h): context, scoring/reference upload, batched entry points.
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "zsw_internal.hpp"
+#include "zsw_synth.h"
+#include "zsw_timer.hpp"
+
+using namespace zsw;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct zsw_context {
+    int device = 0;
+    bool scoring_set = false, reference_set = false;
+    ScoringDev h_sc{};
+    int bias = 0;
+    DevBuf d_sc, d_ref, d_fb_list, d_fb_count, d_scratch, d_maxlen;
+    size_t ref_len = 0;
+    uint32_t scratch_len = 0;
+    // staging for host-memory batches
+    DevBuf s_bases, s_offsets, s_score, s_status, s_tier, s_rend, s_qend;
+    // alignment workspace (zsw_align.hip)
+    DevBuf a_ws[8];
+    KernelTimer timer;
+    std::string err;
+};
+
+namespace {
+
+constexpr size_t EXACT_SLOTS = 64 * 256;
+
+zsw_error fail(zsw_context* ctx, zsw_error code, const char* what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        ctx->err = what;
+        if (e != hipSuccess) {
+            ctx->err += ": ";
+            ctx->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define ZSW_HIP(ctx, call)                                                     \
+    do {                                                                       \
+        hipError_t _e = (call);                                                \
+        if (_e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, #call, _e);        \
+    } while (0)
+
+bool valid_lanes(int lanes) { return lanes == 2 || lanes == 4 || lanes == 8 || lanes == 16 || lanes == 32 || lanes == 64; }
+
+uint64_t signed_thr(int bits) { return bits == 8 ? 255ull : bits == 16 ? 65535ull : 4294967295ull; }
+
+// score_to_maybe_aligned (striped.rs:610-633) as a threshold on the true score:
+//   signed T  : Overflowed  <=>  best >= T::MAX            <=>  s >= 2^bits - 1
+//   unsigned T: Overflowed  <=>  best + bias + 1 > T::MAX  <=>  s >= T::MAX - bias
+bool rule_direct(zsw_int_type t, int bias, ResultRule* r) {
+    r->n_tiers = 1;
+    switch (t) {
+        case ZSW_I8: r->thr[0] = signed_thr(8); r->tier_code[0] = 8; return true;
+        case ZSW_I16: r->thr[0] = signed_thr(16); r->tier_code[0] = 16; return true;
+        case ZSW_I32: r->thr[0] = signed_thr(32); r->tier_code[0] = 32; return true;
+        case ZSW_U8: r->thr[0] = 255ull - (uint64_t)bias; r->tier_code[0] = 8; return bias < 255;
+        case ZSW_U16: r->thr[0] = 65535ull - (uint64_t)bias; r->tier_code[0] = 16; return true;
+        case ZSW_U32: r->thr[0] = 4294967295ull - (uint64_t)bias; r->tier_code[0] = 32; return true;
+    }
+    return false;
+}
+
+// or_else_overflowed chain (profile_set.rs:71-107): i8 -> i16 -> i32 from `from_width`
+bool rule_cascade(int from_width, ResultRule* r) {
+    if (from_width != 8 && from_width != 16 && from_width != 32) return false;
+    r->n_tiers = 0;
+    for (int w = from_width; w <= 32; w *= 2) {
+        r->thr[r->n_tiers] = signed_thr(w);
+        r->tier_code[r->n_tiers] = (uint8_t)w;
+        ++r->n_tiers;
+    }
+    return true;
+}
+
+__global__ void maxlen_kernel(const uint64_t* offsets, uint32_t n, uint32_t* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t m = 0;
+    for (; i < n; i += gridDim.x * blockDim.x) m = max(m, (uint32_t)(offsets[i + 1] - offsets[i]));
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+__global__ void synth_kernel(uint64_t seed, uint64_t first, uint64_t n, uint32_t len, const uint8_t* ref, uint32_t R,
+                             uint8_t* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) zsw_synth_read(seed, first + i, ref, R, len, out + i * len);
+}
+
+__global__ void synth_ragged_kernel(uint64_t seed, uint64_t first, uint64_t n, uint32_t min_len, uint32_t max_len,
+                                    const uint64_t* offsets, const uint8_t* ref, uint32_t R, uint8_t* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) zsw_synth_read(seed, first + i, ref, R, zsw_synth_len(seed, first + i, min_len, max_len), out + offsets[i]);
+}
+
+__global__ void selftest_kernel(uint32_t* out) {
+    const int lane = threadIdx.x;
+    // 1. v_perm_b32 byte order: selector bytes 0-3 pick from the SECOND operand
+    out[lane] = __builtin_amdgcn_perm(0x77665544u, 0x33221100u, 0x07040300u);
+    // 2. shuffle direction within groups of 4
+    out[64 + lane] = (uint32_t)__shfl_up(lane, 1, 4);
+    // 3. packed saturation
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    s2 a = {(short)32000, (short)-32000}, b = {(short)1000, (short)-1000};
+    s2 c = __builtin_elementwise_add_sat(a, b);
+    out[128 + lane] = __builtin_bit_cast(uint32_t, c);
+    s2 d = __builtin_elementwise_sub_sat(b, a);  // 1000-32000, -1000+32000
+    out[192 + lane] = __builtin_bit_cast(uint32_t, d);
+}
+
+struct Staged {
+    BatchDev b{};
+    uint32_t max_len = 0;
+    uint32_t* d_score = nullptr;
+    uint8_t* d_status = nullptr;
+    uint8_t* d_tier = nullptr;
+    uint32_t* d_rend = nullptr;
+    uint32_t* d_qend = nullptr;
+};
+
+// Brings a batch to the device (or validates device pointers), finds the longest read and sizes the workspace.
+zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bool want_tier, bool want_ends,
+                uint32_t* out_score, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_rend, uint32_t* out_qend,
+                Staged* st) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!ctx->scoring_set || !ctx->reference_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "scoring/reference not set");
+    if (!reads || !out_score || !out_status) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
+    if (reads->n_reads > 0x7fffffffull) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "n_reads > 2^31-1 per call");
+    if (reads->n_reads && !reads->bases) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null bases");
+    if (!reads->offsets && reads->fixed_len == 0 && reads->n_reads) return ZSW_ERR_EMPTY_SEQUENCE;
+    const uint32_t n = (uint32_t)reads->n_reads;
+    ZSW_HIP(ctx, hipSetDevice(ctx->device));
+    st->b.n_reads = n;
+    st->b.n_items = n;
+    st->b.items = nullptr;
+    st->b.fixed_len = reads->fixed_len;
+    if (reads->mem == ZSW_MEM_HOST) {
+        size_t total = reads->offsets ? (size_t)reads->offsets[n] : (size_t)n * reads->fixed_len;
+        ZSW_HIP(ctx, ctx->s_bases.ensure(total + 16));
+        ZSW_HIP(ctx, hipMemcpyAsync(ctx->s_bases.p, reads->bases, total, hipMemcpyHostToDevice, stream));
+        st->b.bases = ctx->s_bases.as<uint8_t>();
+        st->b.offsets = nullptr;
+        st->max_len = reads->fixed_len;
+        if (reads->offsets) {
+            ZSW_HIP(ctx, ctx->s_offsets.ensure((size_t)(n + 1) * 8));
+            ZSW_HIP(ctx, hipMemcpyAsync(ctx->s_offsets.p, reads->offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, stream));
+            st->b.offsets = ctx->s_offsets.as<uint64_t>();
+            uint32_t m = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                if (reads->offsets[i + 1] < reads->offsets[i]) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "offsets not monotone");
+                m = std::max<uint32_t>(m, (uint32_t)(reads->offsets[i + 1] - reads->offsets[i]));
+            }
+            st->max_len = m;
+        }
+        ZSW_HIP(ctx, ctx->s_score.ensure((size_t)n * 4 + 4));
+        ZSW_HIP(ctx, ctx->s_status.ensure((size_t)n + 4));
+        st->d_score = ctx->s_score.as<uint32_t>();
+        st->d_status = ctx->s_status.as<uint8_t>();
+        if (want_tier && out_tier) {
+            ZSW_HIP(ctx, ctx->s_tier.ensure((size_t)n + 4));
+            st->d_tier = ctx->s_tier.as<uint8_t>();
+        }
+        if (want_ends) {
+            ZSW_HIP(ctx, ctx->s_rend.ensure((size_t)n * 4 + 4));
+            ZSW_HIP(ctx, ctx->s_qend.ensure((size_t)n * 4 + 4));
+            st->d_rend = ctx->s_rend.as<uint32_t>();
+            st->d_qend = ctx->s_qend.as<uint32_t>();
+        }
+    } else {
+        st->b.bases = reads->bases;
+        st->b.offsets = reads->offsets;
+        st->max_len = reads->fixed_len;
+        if (reads->offsets && n) {
+            ZSW_HIP(ctx, ctx->d_maxlen.ensure(4));
+            ZSW_HIP(ctx, hipMemsetAsync(ctx->d_maxlen.p, 0, 4, stream));
+            hipLaunchKernelGGL(maxlen_kernel, dim3(std::min<uint32_t>(1024, (n + 255) / 256)), dim3(256), 0, stream,
+                               reads->offsets, n, ctx->d_maxlen.as<uint32_t>());
+            uint32_t m = 0;
+            ZSW_HIP(ctx, hipMemcpyAsync(&m, ctx->d_maxlen.p, 4, hipMemcpyDeviceToHost, stream));
+            ZSW_HIP(ctx, hipStreamSynchronize(stream));
+            st->max_len = m;
+        }
+        st->d_score = out_score;
+        st->d_status = out_status;
+        st->d_tier = want_tier ? out_tier : nullptr;
+        st->d_rend = out_rend;
+        st->d_qend = out_qend;
+    }
+    // workspace
+    ZSW_HIP(ctx, ctx->d_fb_list.ensure((size_t)n * 4 + 4));
+    ZSW_HIP(ctx, ctx->d_fb_count.ensure(4));
+    uint32_t need = std::max<uint32_t>(512, (st->max_len + 127) / 128 * 128);
+    if (need > ctx->scratch_len || !ctx->d_scratch.p) {
+        ZSW_HIP(ctx, ctx->d_scratch.ensure(2 * EXACT_SLOTS * (size_t)need * sizeof(int32_t)));
+        ctx->scratch_len = need;
+    }
+    return ZSW_OK;
+}
+
+zsw_error unstage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, const Staged& st, uint32_t* out_score,
+                  uint8_t* out_status, uint8_t* out_tier, uint32_t* out_rend, uint32_t* out_qend) {
+    if (reads->mem != ZSW_MEM_HOST) return ZSW_OK;
+    const size_t n = reads->n_reads;
+    ZSW_HIP(ctx, hipMemcpyAsync(out_score, st.d_score, n * 4, hipMemcpyDeviceToHost, stream));
+    ZSW_HIP(ctx, hipMemcpyAsync(out_status, st.d_status, n, hipMemcpyDeviceToHost, stream));
+    if (st.d_tier && out_tier) ZSW_HIP(ctx, hipMemcpyAsync(out_tier, st.d_tier, n, hipMemcpyDeviceToHost, stream));
+    if (st.d_rend && out_rend) ZSW_HIP(ctx, hipMemcpyAsync(out_rend, st.d_rend, n * 4, hipMemcpyDeviceToHost, stream));
+    if (st.d_qend && out_qend) ZSW_HIP(ctx, hipMemcpyAsync(out_qend, st.d_qend, n * 4, hipMemcpyDeviceToHost, stream));
+    ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    return ZSW_OK;
+}
+
+zsw_error run_score(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, bool want_ends, uint32_t* out_score,
+                    uint8_t* out_status, uint8_t* out_tier, uint32_t* out_rend, uint32_t* out_qend, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    Staged st;
+    zsw_error ze = stage(ctx, reads, stream, out_tier != nullptr, want_ends, out_score, out_status, out_tier, out_rend,
+                         out_qend, &st);
+    if (ze != ZSW_OK) return ze;
+    if (reads->n_reads == 0) return ZSW_OK;
+    ScoreOut out;
+    out.score = st.d_score;
+    out.status = st.d_status;
+    out.tier = st.d_tier;
+    out.ref_end = st.d_rend;
+    out.query_end = st.d_qend;
+    out.fb_list = ctx->d_fb_list.as<uint32_t>();
+    out.fb_count = ctx->d_fb_count.as<uint32_t>();
+    hipError_t e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(),
+                                (uint32_t)ctx->ref_len, rule, out, ctx->d_scratch.as<int32_t>(), EXACT_SLOTS,
+                                ctx->scratch_len, stream, &ctx->timer, want_ends);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "score launch", e);
+    return unstage(ctx, reads, stream, st, out_score, out_status, out_tier, out_rend, out_qend);
+}
+
+}  // namespace
+
+extern "C" {
+
+int zsw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+zsw_error zsw_create(int device_id, zsw_context** out) {
+    if (!out) return ZSW_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ZSW_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= n) return ZSW_ERR_INVALID_ARGUMENT;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return ZSW_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ZSW_ERR_NO_DEVICE;  // kernels are built for gfx950 only
+    if (hipSetDevice(device_id) != hipSuccess) return ZSW_ERR_NO_DEVICE;
+    zsw_context* c = new (std::nothrow) zsw_context();
+    if (!c) return ZSW_ERR_INVALID_ARGUMENT;
+    c->device = device_id;
+    *out = c;
+    return ZSW_OK;
+}
+
+void zsw_destroy(zsw_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen,
+                      &ctx->s_bases, &ctx->s_offsets, &ctx->s_score, &ctx->s_status, &ctx->s_tier, &ctx->s_rend, &ctx->s_qend};
+    for (DevBuf* b : bufs) b->release();
+    for (DevBuf& b : ctx->a_ws) b.release();
+    ctx->timer.destroy();
+    delete ctx;
+}
+
+const char* zsw_last_error_string(const zsw_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+zsw_error zsw_set_scoring(zsw_context* ctx, const int8_t* weights, int S, const uint8_t* index_map, int gap_open,
+                          int gap_extend) {
+    if (!ctx || !weights || !index_map) return ZSW_ERR_INVALID_ARGUMENT;
+    if (S < 1 || S > MAX_S) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "S out of range");
+    // validate_profile_args (profile.rs:32-44), sequence checks are per read
+    if (gap_open < -127 || gap_open > 0) return ZSW_ERR_GAP_OPEN_OUT_OF_RANGE;
+    if (gap_extend < -127 || gap_extend > 0) return ZSW_ERR_GAP_EXTEND_OUT_OF_RANGE;
+    if (gap_extend < gap_open) return ZSW_ERR_BAD_GAP_WEIGHTS;
+    for (int b = 0; b < 256; ++b)
+        if (index_map[b] >= S) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "index_map entry >= S");
+    ScoringDev& s = ctx->h_sc;
+    memset(&s, 0, sizeof(s));
+    memcpy(s.index_map, index_map, 256);
+    int mn = 0;
+    for (int i = 0; i < S * S; ++i) {
+        s.w[i] = weights[i];
+        mn = std::min<int>(mn, weights[i]);
+    }
+    s.S = S;
+    s.gap_open = -gap_open;
+    s.gap_extend = -gap_extend;
+    ctx->bias = -mn;  // WeightMatrix::get_bias / to_biased_matrix (matrices/mod.rs:452-491)
+    ZSW_HIP(ctx, hipSetDevice(ctx->device));
+    ZSW_HIP(ctx, ctx->d_sc.ensure(sizeof(ScoringDev)));
+    ZSW_HIP(ctx, hipMemcpy(ctx->d_sc.p, &s, sizeof(ScoringDev), hipMemcpyHostToDevice));
+    ctx->scoring_set = true;
+    return ZSW_OK;
+}
+
+zsw_error zsw_set_reference(zsw_context* ctx, const uint8_t* reference, size_t len, zsw_mem mem) {
+    if (!ctx || (!reference && len)) return ZSW_ERR_INVALID_ARGUMENT;
+    if (len > 0x7fffffffull) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "reference too long");
+    ZSW_HIP(ctx, hipSetDevice(ctx->device));
+    ZSW_HIP(ctx, ctx->d_ref.ensure(len + 16));
+    if (len)
+        ZSW_HIP(ctx, hipMemcpy(ctx->d_ref.p, reference, len, mem == ZSW_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
+    ctx->ref_len = len;
+    ctx->reference_set = true;
+    return ZSW_OK;
+}
+
+zsw_error zsw_score_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes,
+                          uint32_t* out_score, uint8_t* out_status, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!valid_lanes(lanes)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "lanes must be a power of two in 2..64");
+    ResultRule rule;
+    if (!rule_direct(int_type, ctx->bias, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "bad int_type");
+    return run_score(ctx, reads, rule, false, out_score, out_status, nullptr, nullptr, nullptr, stream);
+}
+
+zsw_error zsw_score_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits,
+                               uint32_t* out_score, uint8_t* out_status, uint8_t* out_tier, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (preset_bits != 128 && preset_bits != 256 && preset_bits != 512) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "preset_bits");
+    ResultRule rule;
+    if (!rule_cascade(from_width, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "from_width");
+    return run_score(ctx, reads, rule, false, out_score, out_status, out_tier, nullptr, nullptr, stream);
+}
+
+zsw_error zsw_score_ends_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes,
+                               uint32_t* out_score, uint32_t* out_ref_end, uint32_t* out_query_end,
+                               uint8_t* out_status, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!out_ref_end || !out_query_end) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
+    if (!valid_lanes(lanes)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "lanes must be a power of two in 2..64");
+    ResultRule rule;
+    if (!rule_direct(int_type, ctx->bias, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "bad int_type");
+    return run_score(ctx, reads, rule, true, out_score, out_status, nullptr, out_ref_end, out_query_end, stream);
+}
+
+zsw_error zsw_synth_reads(zsw_context* ctx, uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint8_t* out_device,
+                          void* stream) {
+    if (!ctx || !out_device || len == 0) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!ctx->reference_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "reference not set");
+    ZSW_HIP(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return ZSW_OK;
+    hipLaunchKernelGGL(synth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, first, n,
+                       len, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len, out_device);
+    ZSW_HIP(ctx, hipGetLastError());
+    return ZSW_OK;
+}
+
+zsw_error zsw_synth_reads_ragged(zsw_context* ctx, uint64_t seed, uint64_t first, uint64_t n, uint32_t min_len,
+                                 uint32_t max_len, const uint64_t* offsets_device, uint8_t* out_device, void* stream) {
+    if (!ctx || !out_device || !offsets_device || min_len == 0 || max_len < min_len) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!ctx->reference_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "reference not set");
+    ZSW_HIP(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return ZSW_OK;
+    hipLaunchKernelGGL(synth_ragged_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                       first, n, min_len, max_len, offsets_device, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len,
+                       out_device);
+    ZSW_HIP(ctx, hipGetLastError());
+    return ZSW_OK;
+}
+
+uint32_t zsw_synth_length(uint64_t seed, uint64_t index, uint32_t min_len, uint32_t max_len) {
+    return zsw_synth_len(seed, index, min_len, max_len);
+}
+
+// Host twins of the generator (no GPU needed): tests and the CPU baseline consume the same bytes.
+void zsw_synth_reference_host(uint64_t seed, uint64_t len, uint8_t* out) {
+    for (uint64_t j = 0; j < len; ++j) out[j] = zsw_synth_ref_base(seed, j);
+}
+void zsw_synth_reads_host(uint64_t seed, uint64_t first, uint64_t n, uint32_t len, const uint8_t* ref, uint32_t R,
+                          uint8_t* out) {
+    for (uint64_t i = 0; i < n; ++i) zsw_synth_read(seed, first + i, ref, R, len, out + i * len);
+}
+void zsw_synth_reads_ragged_host(uint64_t seed, uint64_t first, uint64_t n, uint32_t min_len, uint32_t max_len,
+                                 const uint64_t* offsets, const uint8_t* ref, uint32_t R, uint8_t* out) {
+    for (uint64_t i = 0; i < n; ++i)
+        zsw_synth_read(seed, first + i, ref, R, zsw_synth_len(seed, first + i, min_len, max_len), out + offsets[i]);
+}
+
+zsw_error zsw_selftest(zsw_context* ctx) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    ZSW_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t* d = nullptr;
+    ZSW_HIP(ctx, hipMalloc(&d, 256 * 4));
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, 0, d);
+    uint32_t h[256];
+    hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "selftest copy", e);
+    for (int l = 0; l < 64; ++l) {
+        if (h[l] != 0x77443300u) return fail(ctx, ZSW_ERR_HIP, "selftest: v_perm_b32 byte order");
+        uint32_t want = (l % 4 == 0) ? (uint32_t)l : (uint32_t)(l - 1);
+        if (h[64 + l] != want) return fail(ctx, ZSW_ERR_HIP, "selftest: __shfl_up direction");
+        if (h[128 + l] != 0x80007fffu) return fail(ctx, ZSW_ERR_HIP, "selftest: packed saturating add");
+        if (h[192 + l] != (uint32_t)(((uint32_t)(uint16_t)(int16_t)31000 << 16) | (uint16_t)(int16_t)-31000))
+            return fail(ctx, ZSW_ERR_HIP, "selftest: packed saturating sub");
+    }
+    return ZSW_OK;
+}
+
+zsw_error zsw_timing_enable(zsw_context* ctx, int enable) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    ctx->timer.enabled = enable != 0;
+    ctx->timer.used = 0;
+    return ZSW_OK;
+}
+
+zsw_error zsw_timing_read(zsw_context* ctx, double* seconds, uint64_t* launches) {
+    if (!ctx || !seconds || !launches) return ZSW_ERR_INVALID_ARGUMENT;
+    ZSW_HIP(ctx, hipSetDevice(ctx->device));
+    ZSW_HIP(ctx, ctx->timer.collect(seconds, launches));
+    return ZSW_OK;
+}
+
+}  // extern "C"

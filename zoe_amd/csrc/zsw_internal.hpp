@@ -1,0 +1,78 @@
+// zsw_internal.hpp — shared declarations of the gfx950 striped-SW library (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/zoe_sw.h"
+
+namespace zsw {
+
+constexpr int MAX_S = 32;
+constexpr uint32_t MIN2 = 0x80008000u;  // two packed i16 at T::MIN (= true score 0)
+
+// How a true Smith-Waterman score s becomes MaybeAligned<u32> for the requested instantiation
+// (score_to_maybe_aligned, striped.rs:610-633, composed over the tiers of or_else_overflowed,
+// profile_set.rs:71-107). Tier k answers iff s < thr[k].
+struct ResultRule {
+    uint64_t thr[3];
+    uint8_t tier_code[3];
+    int n_tiers;
+};
+
+__host__ __device__ inline void apply_rule(const ResultRule& r, uint64_t s, uint32_t* score, uint8_t* status,
+                                           uint8_t* tier) {
+    for (int k = 0; k < r.n_tiers; ++k) {
+        if (s < r.thr[k]) {
+            *score = (uint32_t)s;
+            *status = s == 0 ? ZSW_STATUS_UNMAPPED : ZSW_STATUS_SOME;
+            if (s == 0) *score = 0;
+            *tier = r.tier_code[k];
+            return;
+        }
+    }
+    *score = 0;
+    *status = ZSW_STATUS_OVERFLOWED;
+    *tier = r.tier_code[r.n_tiers - 1];
+}
+
+// Device-resident scoring tables derived from WeightMatrix + ByteIndexMap.
+struct ScoringDev {
+    uint8_t index_map[256];
+    int32_t w[MAX_S * MAX_S];  // signed weights, row = reference residue
+    int32_t S;
+    int32_t gap_open, gap_extend;  // positive magnitudes (StripedProfile stores them negated, profile.rs:300-301)
+};
+
+// Inputs of one batched launch.
+struct BatchDev {
+    const uint8_t* bases;
+    const uint64_t* offsets;  // may be null
+    uint32_t fixed_len;
+    uint32_t n_reads;
+    const uint32_t* items;  // optional indirection: item j -> read index (bucketed launches); null = identity
+    uint32_t n_items;
+};
+
+struct ScoreOut {
+    uint32_t* score;
+    uint8_t* status;
+    uint8_t* tier;      // may be null
+    uint32_t* ref_end;  // ends kernels only (may be null)
+    uint32_t* query_end;
+    uint32_t* fb_list;  // reads that need the exact 32-bit kernel
+    uint32_t* fb_count;
+};
+
+struct KernelTimer;
+
+// launchers (zsw_score.hip)
+hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
+                        const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
+                        int32_t* d_scratch, size_t scratch_slots, uint32_t scratch_len, hipStream_t stream,
+                        KernelTimer* timer, bool want_ends);
+bool score_config_for(uint32_t max_len, int* G, int* C);
+
+}  // namespace zsw

@@ -1,0 +1,479 @@
+// zsw_score.hip — score / score+ends kernels for gfx950 (MI355X).
+//
+// What is computed: for every read (the profile sequence, "query") the Smith-Waterman affine-gap
+// local score against the context's reference, i.e. the value sw_simd_score returns
+// (reference: src/alignment/sw/striped.rs:65-142) and, in ENDS mode, the (ref_end, query_end) of
+// sw_simd_score_ends (striped.rs:213-336: first row holding the maximum, then first column).
+// Both are invariant to Zoe's SIMD lane count N (they equal the Gotoh recurrence that
+// src/alignment/sw/scalar.rs:55-122 states), so this kernel is free to parallelise differently:
+//
+//   * inter-read: each 32-bit lane carries TWO reads as packed i16 (v_pk_add_i16/v_pk_sub_i16 with
+//     clamp = Zoe's saturating_add/sub, v_pk_max_i16); scores live at offset i16::MIN exactly as in
+//     Zoe's signed profiles, so saturation at MIN is the zero floor of local alignment;
+//   * a group of G adjacent lanes owns one read pair; lane g keeps columns [g*C, (g+1)*C) of H and E
+//     in VGPRs and walks down the reference one row per step, skewed by g steps (anti-diagonal
+//     wavefront at strip granularity); the only cross-lane traffic is the strip's last H and F, one
+//     wave shuffle each per step;
+//   * the reference row's four substitution scores (8 bytes) come from an LDS table built once per
+//     block; the per-column score is ONE v_perm_b32 of that row by a per-column selector register
+//     that encodes the two reads' residues — no per-cell memory access at all.
+//
+// 10 VALU instructions per packed cell pair; no MFMA (this is not a contraction); HBM traffic is the
+// read bytes in and 4-5 bytes out per read. The binding roof is integer VALU issue.
+#include "zsw_internal.hpp"
+#include "zsw_timer.hpp"
+
+namespace zsw {
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ s2 S2(uint32_t x) { return __builtin_bit_cast(s2, x); }
+__device__ __forceinline__ uint32_t U(s2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return U(__builtin_elementwise_add_sat(S2(a), S2(b))); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return U(__builtin_elementwise_sub_sat(S2(a), S2(b))); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return U(__builtin_elementwise_max(S2(a), S2(b))); }
+
+constexpr int BLOCK = 256;
+constexpr int CH = 2048;       // reference rows staged in LDS per chunk
+constexpr int NEUTRAL = 8;     // table row used outside [0, R): scores 0 for every residue
+constexpr int PAD_K = 255;     // residue code of a padded query column
+
+struct ScoreArgs {
+    BatchDev b;
+    const uint8_t* ref;
+    uint32_t ref_len;
+    const ScoringDev* sc;
+    uint32_t wtab[9][2];  // per reference residue: the 8 table bytes v_perm selects from
+    uint32_t go2, ge2, bias2;
+    ResultRule rule;
+    ScoreOut out;
+};
+
+// Waves per SIMD the register allocator must leave room for: H, E and the selectors take 3*C VGPRs
+// (4*C with the MODE 2 snapshot row).
+constexpr int min_waves(int C, int MODE) { return (MODE == 2 ? 4 * C : 3 * C) + 14 <= 80 ? 6 : (MODE == 2 ? 4 * C : 3 * C) + 14 <= 128 ? 4 : (MODE == 2 ? 4 * C : 3 * C) + 14 <= 168 ? 3 : 2; }
+
+// MODE 0: score; 1: score + ref_end; 2: score + ref_end + query_end
+template <int G, int C, bool FAST, int MODE>
+__global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreArgs a) {
+    __shared__ uint2 rp[CH + G];
+    __shared__ uint2 swt[9];
+    __shared__ uint32_t lut32[64];
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut32);
+
+    const int tid = threadIdx.x;
+    const int g = tid & (G - 1);
+    const uint32_t group = blockIdx.x * (BLOCK / G) + tid / G;
+    const uint32_t itemA = 2 * group, itemB = 2 * group + 1;
+    const bool validA = itemA < a.b.n_items, validB = itemB < a.b.n_items;
+    const uint32_t idA = validA ? (a.b.items ? a.b.items[itemA] : itemA) : 0;
+    const uint32_t idB = validB ? (a.b.items ? a.b.items[itemB] : itemB) : 0;
+
+    if (tid < 64) lut32[tid] = reinterpret_cast<const uint32_t*>(a.sc->index_map)[tid];
+    if (tid < 9) swt[tid] = make_uint2(a.wtab[tid][0], a.wtab[tid][1]);
+    __syncthreads();
+
+    uint64_t offA = 0, offB = 0;
+    uint32_t lenA = 0, lenB = 0;
+    if (validA) {
+        if (a.b.offsets) {
+            offA = a.b.offsets[idA];
+            lenA = (uint32_t)(a.b.offsets[idA + 1] - offA);
+        } else {
+            offA = (uint64_t)idA * a.b.fixed_len;
+            lenA = a.b.fixed_len;
+        }
+    }
+    if (validB) {
+        if (a.b.offsets) {
+            offB = a.b.offsets[idB];
+            lenB = (uint32_t)(a.b.offsets[idB + 1] - offB);
+        } else {
+            offB = (uint64_t)idB * a.b.fixed_len;
+            lenB = a.b.fixed_len;
+        }
+    }
+
+    // per-column selectors: which table bytes v_perm picks for read A (low half) and read B (high half)
+    uint32_t sel[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const uint32_t q = (uint32_t)(g * C + c);
+        uint32_t kA = PAD_K, kB = PAD_K;
+        if (q < lenA) kA = lut[a.b.bases[offA + q]];
+        if (q < lenB) kB = lut[a.b.bases[offB + q]];
+        uint32_t sA, sB;
+        if (FAST) {  // table = W[r][0..3] as i16; residue >= 4 (an all-zero matrix column) and padding -> 0
+            sA = kA < 4 ? 0x0100u + kA * 0x0202u : 0x0c0cu;
+            sB = kB < 4 ? 0x0100u + kB * 0x0202u : 0x0c0cu;
+        } else {  // table = biased u8 weights in bytes 0..6, byte 7 = bias (padding scores 0)
+            sA = (kA == PAD_K ? 7u : kA) | 0x0c00u;
+            sB = (kB == PAD_K ? 7u : kB) | 0x0c00u;
+        }
+        sel[c] = sA | (sB << 16);
+    }
+
+    uint32_t H[C], E[C];
+    uint32_t snap[MODE == 2 ? C : 1];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        H[c] = MIN2;
+        E[c] = MIN2;
+    }
+    if (MODE == 2) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) snap[MODE == 2 ? c : 0] = MIN2;
+    }
+    uint32_t best = MIN2;  // running maximum (MODE 0) / best row maximum so far (MODE >= 1)
+    uint32_t Fout = MIN2, Hlast = MIN2, Hin_prev = MIN2;
+    int rA = 0, rB = 0;
+    const uint32_t go2 = a.go2, ge2 = a.ge2, bias2 = a.bias2;
+    const int R = (int)a.ref_len;
+    const int T = R + G - 1;
+
+    for (int base = 0; base < T; base += CH) {
+        __syncthreads();
+        for (int j = tid; j < CH + G - 1; j += BLOCK) {
+            const int row = base - (G - 1) + j;
+            int idx = NEUTRAL;
+            if (row >= 0 && row < R) idx = lut[a.ref[row]];
+            rp[j] = swt[idx];
+        }
+        __syncthreads();
+        const int tend = (T < base + CH) ? T : base + CH;
+        const int joff = (G - 1 - g) - base;
+        uint2 w = rp[base + joff];
+#pragma unroll 1
+        for (int t = base; t < tend; ++t) {
+            const uint2 wn = rp[t + 1 + joff];
+            uint32_t Fin = (uint32_t)__shfl_up((int)Fout, 1, G);
+            uint32_t Hin = (uint32_t)__shfl_up((int)Hlast, 1, G);
+            if (g == 0) {
+                Fin = MIN2;
+                Hin = MIN2;
+            }
+            // hd = H(r-1,c-1) + W(r,c) is formed one column ahead, so the previous row's H[c] is dead
+            // before this row's H[c] is written (same register, no copy in the loop).
+            uint32_t hd = pk_adds(Hin_prev, __builtin_amdgcn_perm(w.y, w.x, sel[0]));
+            if (!FAST) hd = pk_subs(hd, bias2);
+            Hin_prev = Hin;
+            uint32_t F = Fin;
+            uint32_t rmax = MIN2;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                uint32_t hd_next = 0;
+                if (c + 1 < C) {
+                    hd_next = pk_adds(H[c], __builtin_amdgcn_perm(w.y, w.x, sel[c + 1 < C ? c + 1 : c]));
+                    if (!FAST) hd_next = pk_subs(hd_next, bias2);
+                }
+                if (MODE == 0) best = pk_max(best, hd);  // E, F never exceed an H already folded into best
+                uint32_t h = pk_max(hd, E[c]);
+                h = pk_max(h, F);
+                if (MODE != 0) rmax = pk_max(rmax, h);
+                H[c] = h;
+                const uint32_t hg = pk_subs(h, go2);
+                E[c] = pk_max(pk_subs(E[c], ge2), hg);
+                F = pk_max(pk_subs(F, ge2), hg);
+                hd = hd_next;
+            }
+            Fout = F;
+            Hlast = H[C - 1];
+            if (MODE != 0) {
+                const uint32_t nb = pk_max(best, rmax);
+                const uint32_t ch = nb ^ best;  // a non-zero half = that read's maximum rose in this row
+                best = nb;
+                const int row = t - g;
+                if (ch & 0xffffu) rA = row;
+                if (ch >> 16) rB = row;
+                if (MODE == 2) {
+                    const uint32_t m = ((ch & 0xffffu) ? 0xffffu : 0u) | ((ch >> 16) ? 0xffff0000u : 0u);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) snap[MODE == 2 ? c : 0] = (H[c] & m) | (snap[MODE == 2 ? c : 0] & ~m);
+                }
+            }
+            w = wn;
+        }
+    }
+
+    // ---- per-read reduction over the G lanes of the group ----
+    int bA = (int)(int16_t)(best & 0xffffu), bB = (int)(int16_t)(best >> 16);
+    int gbA = bA, gbB = bB;
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) {
+        gbA = max(gbA, __shfl_xor(gbA, d, G));
+        gbB = max(gbB, __shfl_xor(gbB, d, G));
+    }
+    uint32_t reA = 0, reB = 0, qeA = 0, qeB = 0;
+    if (MODE != 0) {
+        int kA = (bA == gbA) ? rA : 0x7fffffff, kB = (bB == gbB) ? rB : 0x7fffffff;
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) {
+            kA = min(kA, __shfl_xor(kA, d, G));
+            kB = min(kB, __shfl_xor(kB, d, G));
+        }
+        reA = (uint32_t)kA + 1;
+        reB = (uint32_t)kB + 1;
+        if (MODE == 2) {
+            int cA = 0x7fffffff, cB = 0x7fffffff;
+#pragma unroll
+            for (int c = C - 1; c >= 0; --c) {
+                const uint32_t sv = snap[MODE == 2 ? c : 0];
+                if ((int)(int16_t)(sv & 0xffffu) == gbA) cA = g * C + c;
+                if ((int)(int16_t)(sv >> 16) == gbB) cB = g * C + c;
+            }
+            if (!(bA == gbA && rA == kA)) cA = 0x7fffffff;
+            if (!(bB == gbB && rB == kB)) cB = 0x7fffffff;
+#pragma unroll
+            for (int d = 1; d < G; d <<= 1) {
+                cA = min(cA, __shfl_xor(cA, d, G));
+                cB = min(cB, __shfl_xor(cB, d, G));
+            }
+            qeA = (uint32_t)cA + 1;
+            qeB = (uint32_t)cB + 1;
+        }
+    }
+
+    if (g == 0) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const bool valid = half ? validB : validA;
+            if (!valid) continue;
+            const uint32_t id = half ? idB : idA;
+            const uint32_t len = half ? lenB : lenA;
+            const int stored = half ? gbB : gbA;
+            if (len == 0) {  // StripedProfile::new -> Err(ProfileError::EmptySequence)
+                a.out.score[id] = 0;
+                a.out.status[id] = ZSW_STATUS_EMPTY;
+                if (a.out.tier) a.out.tier[id] = 0;
+                if (MODE != 0 && a.out.ref_end) a.out.ref_end[id] = 0;
+                if (MODE == 2 && a.out.query_end) a.out.query_end[id] = 0;
+                continue;
+            }
+            if (stored >= 32767 - 256) {  // at or near i16 saturation: recompute exactly in 32 bits
+                const uint32_t k = atomicAdd(a.out.fb_count, 1u);
+                a.out.fb_list[k] = id;
+                continue;
+            }
+            uint32_t score;
+            uint8_t status, tier;
+            apply_rule(a.rule, (uint64_t)(stored + 32768), &score, &status, &tier);
+            a.out.score[id] = score;
+            a.out.status[id] = status;
+            if (a.out.tier) a.out.tier[id] = tier;
+            const bool some = status == ZSW_STATUS_SOME;
+            if (MODE != 0 && a.out.ref_end) a.out.ref_end[id] = some ? (half ? reB : reA) : 0;
+            if (MODE == 2 && a.out.query_end) a.out.query_end[id] = some ? (half ? qeB : qeA) : 0;
+        }
+    }
+}
+
+// Exact 32-bit kernel: any alphabet size, any read length, no saturation below 2^31. One thread per
+// read, H/E rows in global scratch ([column][slot], coalesced over threads). Used for reads whose
+// packed-i16 score saturated, for alphabets the table kernels do not cover (S > 7) and for reads
+// longer than the largest strip configuration. Follows scalar.rs:55-122 (same recurrence, same
+// strict-greater scan order = first row, then first column).
+__global__ __launch_bounds__(64) void exact32_kernel(BatchDev b, const uint32_t* list, const uint32_t* list_count,
+                                                     const uint8_t* ref, uint32_t ref_len, const ScoringDev* sc,
+                                                     ResultRule rule, ScoreOut out, int32_t* scratch, uint32_t slots,
+                                                     uint32_t scratch_len) {
+    __shared__ uint8_t lut[256];
+    __shared__ int32_t w[MAX_S * MAX_S];
+    for (int i = threadIdx.x; i < 256; i += 64) lut[i] = sc->index_map[i];
+    for (int i = threadIdx.x; i < MAX_S * MAX_S; i += 64) w[i] = sc->w[i];
+    __syncthreads();
+    const int S = sc->S;
+    const int go = sc->gap_open, ge = sc->gap_extend;
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t n = list ? *list_count : b.n_items;
+    int32_t* Hrow = scratch + slot;
+    int32_t* Erow = scratch + (size_t)slots * scratch_len + slot;
+    for (uint32_t item = slot; item < n; item += slots) {
+        const uint32_t id = list ? list[item] : (b.items ? b.items[item] : item);
+        uint64_t off;
+        uint32_t len;
+        if (b.offsets) {
+            off = b.offsets[id];
+            len = (uint32_t)(b.offsets[id + 1] - off);
+        } else {
+            off = (uint64_t)id * b.fixed_len;
+            len = b.fixed_len;
+        }
+        if (len == 0 || len > scratch_len) {
+            out.score[id] = 0;
+            out.status[id] = len == 0 ? ZSW_STATUS_EMPTY : ZSW_STATUS_OVERFLOWED;
+            if (out.tier) out.tier[id] = 0;
+            if (out.ref_end) out.ref_end[id] = 0;
+            if (out.query_end) out.query_end[id] = 0;
+            continue;
+        }
+        for (uint32_t c = 0; c < len; ++c) {
+            Hrow[(size_t)c * slots] = 0;
+            Erow[(size_t)c * slots] = 0;
+        }
+        int64_t best = 0;
+        uint32_t r_end = 0, c_end = 0;
+        for (uint32_t r = 0; r < ref_len; ++r) {
+            const int32_t* wr = &w[lut[ref[r]] * S];
+            int32_t f = 0, diag = 0;
+            for (uint32_t c = 0; c < len; ++c) {
+                const int32_t up = Hrow[(size_t)c * slots];
+                int32_t e = Erow[(size_t)c * slots];
+                int32_t h = diag + wr[lut[b.bases[off + c]]];
+                h = max(max(h, e), max(f, 0));
+                if (h > best) {
+                    best = h;
+                    r_end = r;
+                    c_end = c;
+                }
+                Hrow[(size_t)c * slots] = h;
+                e = max(max(e - ge, h - go), 0);
+                f = max(max(f - ge, h - go), 0);
+                Erow[(size_t)c * slots] = e;
+                diag = up;
+            }
+        }
+        uint32_t score;
+        uint8_t status, tier;
+        apply_rule(rule, (uint64_t)best, &score, &status, &tier);
+        out.score[id] = score;
+        out.status[id] = status;
+        if (out.tier) out.tier[id] = tier;
+        const bool some = status == ZSW_STATUS_SOME;
+        if (out.ref_end) out.ref_end[id] = some ? r_end + 1 : 0;
+        if (out.query_end) out.query_end[id] = some ? c_end + 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Cfg {
+    int G, C;
+};
+// strip configurations, ascending capacity G*C
+static const Cfg kCfgs[] = {{4, 19}, {4, 25}, {4, 32}, {4, 38}, {8, 19}, {8, 25}, {8, 32}, {8, 38},
+                            {16, 25}, {16, 32}, {16, 38}, {64, 19}, {64, 38}};
+
+bool score_config_for(uint32_t max_len, int* G, int* C) {
+    for (const Cfg& c : kCfgs)
+        if ((uint32_t)(c.G * c.C) >= max_len) {
+            *G = c.G;
+            *C = c.C;
+            return true;
+        }
+    return false;
+}
+
+template <int G, int C>
+static hipError_t launch_cfg(const ScoreArgs& a, bool fast, int mode, hipStream_t stream) {
+    const uint32_t reads_per_block = 2 * (BLOCK / G);
+    const uint32_t grid = (a.b.n_items + reads_per_block - 1) / reads_per_block;
+    if (grid == 0) return hipSuccess;
+#define ZSW_LAUNCH(FASTV, MODEV) hipLaunchKernelGGL((score_kernel<G, C, FASTV, MODEV>), dim3(grid), dim3(BLOCK), 0, stream, a)
+    if (fast) {
+        if (mode == 0) ZSW_LAUNCH(true, 0);
+        else if (mode == 1) ZSW_LAUNCH(true, 1);
+        else ZSW_LAUNCH(true, 2);
+    } else {
+        if (mode == 0) ZSW_LAUNCH(false, 0);
+        else if (mode == 1) ZSW_LAUNCH(false, 1);
+        else ZSW_LAUNCH(false, 2);
+    }
+#undef ZSW_LAUNCH
+    return hipGetLastError();
+}
+
+// Chooses the table form. FAST needs every query residue code >= 4 to score 0 against every
+// reference residue (true for S <= 4, and for DNA matrices built with `ignoring = Some(b'N')`).
+static bool fast_ok(const ScoringDev& s) {
+    if (s.S > 8) return false;
+    for (int r = 0; r < s.S; ++r)
+        for (int q = 4; q < s.S; ++q)
+            if (s.w[r * s.S + q] != 0) return false;
+    return true;
+}
+
+static void build_tables(const ScoringDev& s, bool fast, ScoreArgs* a) {
+    int bias = 0;
+    for (int i = 0; i < s.S * s.S; ++i) bias = s.w[i] < -bias ? -s.w[i] : bias;
+    auto pk = [](uint32_t lo, uint32_t hi) { return (lo & 0xffffu) | (hi << 16); };
+    for (int r = 0; r < 9; ++r) {
+        uint32_t lo = 0, hi = 0;
+        if (fast) {
+            int v[4] = {0, 0, 0, 0};
+            if (r < s.S)
+                for (int q = 0; q < 4 && q < s.S; ++q) v[q] = s.w[r * s.S + q];
+            lo = pk((uint32_t)v[0], (uint32_t)v[1]);
+            hi = pk((uint32_t)v[2], (uint32_t)v[3]);
+        } else {
+            uint8_t by[8];
+            for (int q = 0; q < 8; ++q) by[q] = (uint8_t)bias;
+            if (r < s.S)
+                for (int q = 0; q < s.S && q < 7; ++q) by[q] = (uint8_t)(s.w[r * s.S + q] + bias);
+            lo = by[0] | (by[1] << 8) | (by[2] << 16) | ((uint32_t)by[3] << 24);
+            hi = by[4] | (by[5] << 8) | (by[6] << 16) | ((uint32_t)by[7] << 24);
+        }
+        a->wtab[r][0] = lo;
+        a->wtab[r][1] = hi;
+    }
+    a->go2 = pk((uint32_t)s.gap_open, (uint32_t)s.gap_open);
+    a->ge2 = pk((uint32_t)s.gap_extend, (uint32_t)s.gap_extend);
+    a->bias2 = pk((uint32_t)bias, (uint32_t)bias);
+}
+
+hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
+                        const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
+                        int32_t* d_scratch, size_t scratch_slots, uint32_t scratch_len, hipStream_t stream,
+                        KernelTimer* timer, bool want_ends) {
+    hipError_t e = hipMemsetAsync(out.fb_count, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    int G = 0, C = 0;
+    const bool table_ok = h_sc.S <= 7 || fast_ok(h_sc);
+    const bool cfg_ok = score_config_for(max_len, &G, &C);
+    const int mode = want_ends ? 2 : 0;
+    const uint32_t exact_grid = (uint32_t)(scratch_slots / 64);
+    if (table_ok && cfg_ok) {
+        ScoreArgs a;
+        a.b = b;
+        a.ref = d_ref;
+        a.ref_len = ref_len;
+        a.sc = d_sc;
+        a.rule = rule;
+        a.out = out;
+        const bool fast = fast_ok(h_sc);
+        build_tables(h_sc, fast, &a);
+        if (timer) timer->begin(stream);
+        switch (G * 100 + C) {
+#define ZSW_CASE(GV, CV) \
+    case GV * 100 + CV: e = launch_cfg<GV, CV>(a, fast, mode, stream); break;
+            ZSW_CASE(4, 19)
+            ZSW_CASE(4, 25)
+            ZSW_CASE(4, 32)
+            ZSW_CASE(4, 38)
+            ZSW_CASE(8, 19)
+            ZSW_CASE(8, 25)
+            ZSW_CASE(8, 32)
+            ZSW_CASE(8, 38)
+            ZSW_CASE(16, 25)
+            ZSW_CASE(16, 32)
+            ZSW_CASE(16, 38)
+            ZSW_CASE(64, 19)
+            ZSW_CASE(64, 38)
+#undef ZSW_CASE
+            default: e = hipErrorInvalidValue;
+        }
+        if (timer) timer->end(stream);
+        if (e != hipSuccess) return e;
+        // reads that saturated i16: exact pass over the device-side worklist (usually empty)
+        hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, b, out.fb_list, out.fb_count, d_ref,
+                           ref_len, d_sc, rule, out, d_scratch, (uint32_t)scratch_slots, scratch_len);
+        return hipGetLastError();
+    }
+    // alphabet or length outside the table kernels: exact kernel over the whole batch
+    if (timer) timer->begin(stream);
+    hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, b, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, d_ref, ref_len, d_sc, rule, out, d_scratch, (uint32_t)scratch_slots,
+                       scratch_len);
+    if (timer) timer->end(stream);
+    return hipGetLastError();
+}
+
+}  // namespace zsw
