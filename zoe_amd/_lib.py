@@ -76,6 +76,11 @@ def load() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ZswError(-3, f"{LIB_PATH} not built: run `python -m zoe_amd.build` (hipcc, gfx950)")
+    # PyTorch owns device memory and streams here and bundles its own libamdhip64 (SONAME libamdhip64.so.7).
+    # It must be loaded first so that this library binds to the SAME HIP runtime instance; the other order
+    # puts two runtimes in one process and torch's device pointers would mean nothing to ours.
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     vp, u8p, u32p, u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
     lib.zsw_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]

@@ -197,7 +197,7 @@ class SwContext:
         h = C.c_void_p()
         rc = self.lib.zsw_create(device, C.byref(h))
         if rc != 0:
-            raise _lib.ZswError(rc, "zsw_create")
+            raise _lib.ZswError(rc, "zsw_create: " + self.lib.zsw_last_error_string(None).decode())
         self.h = h
         self._scoring_key = None
         self._ref_key = None

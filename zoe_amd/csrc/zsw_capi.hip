@@ -275,16 +275,36 @@ int zsw_device_count(void) {
     return n;
 }
 
+static thread_local std::string g_create_error;
+
 zsw_error zsw_create(int device_id, zsw_context** out) {
     if (!out) return ZSW_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ZSW_ERR_NO_DEVICE;
-    if (device_id < 0 || device_id >= n) return ZSW_ERR_INVALID_ARGUMENT;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("hipGetDeviceCount: ") + (e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+        return ZSW_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) {
+        g_create_error = "device_id out of range";
+        return ZSW_ERR_INVALID_ARGUMENT;
+    }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return ZSW_ERR_NO_DEVICE;
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ZSW_ERR_NO_DEVICE;  // kernels are built for gfx950 only
-    if (hipSetDevice(device_id) != hipSuccess) return ZSW_ERR_NO_DEVICE;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return ZSW_ERR_NO_DEVICE;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {  // kernels are built for gfx950 only
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950";
+        return ZSW_ERR_NO_DEVICE;
+    }
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return ZSW_ERR_NO_DEVICE;
+    }
     zsw_context* c = new (std::nothrow) zsw_context();
     if (!c) return ZSW_ERR_INVALID_ARGUMENT;
     c->device = device_id;
@@ -303,7 +323,8 @@ void zsw_destroy(zsw_context* ctx) {
     delete ctx;
 }
 
-const char* zsw_last_error_string(const zsw_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+// ctx == NULL: the reason the last zsw_create on this thread failed
+const char* zsw_last_error_string(const zsw_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 zsw_error zsw_set_scoring(zsw_context* ctx, const int8_t* weights, int S, const uint8_t* index_map, int gap_open,
                           int gap_extend) {
