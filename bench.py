@@ -29,7 +29,9 @@ READ_LEN = 150
 REF_LEN = 2000
 ALGO_BYTES_PER_READ = READ_LEN + 4  # read bytes in + u32 score out
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD-32 x 2.4 GHz (32-bit lane-ops/s)
+# v_pk_{add,sub,max}_i16 and v_perm_b32 issue at one wave64 instruction per 4 cycles per SIMD on gfx950
+# (profiles/r01_valu_issue_rates_ubench.txt: half the v_fma_f32/v_add_u32 rate), i.e. 16 lanes/clk/SIMD.
+VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9  # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (32-bit lane-ops/s)
 PACKED_OPS_PER_CELL_PAIR = 10       # zsw_score.hip inner loop: 10 VALU per two cells
 
 
@@ -45,6 +47,30 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores() -> int:
+    """Usable host cores: affinity mask capped by the cgroup CPU quota (a 1-GPU box gets a share of the host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(reference: bytes, target_s: float):
     """Restated Zoe CPU path (oracle/zoe_cpu_fast.cpp): fresh i8x32 -> i16x16 profiles per read, all host cores."""
     from oracle import oracle
@@ -52,15 +78,12 @@ def cpu_baseline(reference: bytes, target_s: float):
 
     oracle.build()
     sc = oracle.dna_scoring(2, -5, b"N", -10, -1)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    probe = synth.reads_host(reference, 0, 2000 * min(cores, 8), READ_LEN)
+    cores = host_cores()
+    probe = synth.reads_host(reference, 0, 1000 * cores, READ_LEN)
     t0 = time.perf_counter()
     oracle.batch_score_w256(8, sc, probe, reference, fixed_len=READ_LEN, threads=cores)
     rate = probe.shape[0] / (time.perf_counter() - t0)
-    n = int(max(probe.shape[0], min(rate * target_s, 4_000_000)))
+    n = int(max(probe.shape[0], min(rate * target_s, 8_000_000)))
     reads = synth.reads_host(reference, 0, n, READ_LEN)
     t0 = time.perf_counter()
     oracle.batch_score_w256(8, sc, reads, reference, fixed_len=READ_LEN, threads=cores)
@@ -199,7 +222,7 @@ def main():
                 "bound": "valu",
                 "achieved": lane_ops / 1e12,
                 "peak": VALU_LANE_OPS_PEAK / 1e12,
-                "unit": "T lane-ops/s (32-bit lanes; each packed op = 2 i16 cells)",
+                "unit": "T lane-ops/s (32-bit lanes of packed-i16 VALU; each lane-op advances 2 cells)",
                 "frac": lane_ops / VALU_LANE_OPS_PEAK,
             },
             "parity_checked_reads": args.verify if verified else 0,

@@ -233,36 +233,39 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
         }
     }
 
-    if (g == 0) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const bool valid = half ? validB : validA;
-            if (!valid) continue;
-            const uint32_t id = half ? idB : idA;
-            const uint32_t len = half ? lenB : lenA;
-            const int stored = half ? gbB : gbA;
-            if (len == 0) {  // StripedProfile::new -> Err(ProfileError::EmptySequence)
-                a.out.score[id] = 0;
-                a.out.status[id] = ZSW_STATUS_EMPTY;
-                if (a.out.tier) a.out.tier[id] = 0;
-                if (MODE != 0 && a.out.ref_end) a.out.ref_end[id] = 0;
-                if (MODE == 2 && a.out.query_end) a.out.query_end[id] = 0;
-                continue;
-            }
-            if (stored >= 32767 - 256) {  // at or near i16 saturation: recompute exactly in 32 bits
-                const uint32_t k = atomicAdd(a.out.fb_count, 1u);
-                a.out.fb_list[k] = id;
-                continue;
-            }
+    // ---- outputs: regroup so that lane l of the wave owns the wave's l-th read (coalesced stores) ----
+    const int lane = tid & 63;
+    constexpr int RW = 2 * (64 / G);          // reads per wave
+    const int src = (lane >> 1) * G;          // first lane of the group that holds read `lane`
+    const bool hi = lane & 1;
+#define ZSW_PICK(A, B) (hi ? __shfl((int)(B), src, 64) : __shfl((int)(A), src, 64))
+    const uint32_t o_valid = (uint32_t)ZSW_PICK(validA, validB);
+    const uint32_t o_id = (uint32_t)ZSW_PICK(idA, idB);
+    const uint32_t o_len = (uint32_t)ZSW_PICK(lenA, lenB);
+    const int o_stored = ZSW_PICK(gbA, gbB);
+    const uint32_t o_re = (uint32_t)ZSW_PICK(reA, reB);
+    const uint32_t o_qe = (uint32_t)ZSW_PICK(qeA, qeB);
+#undef ZSW_PICK
+    if (lane < RW && o_valid) {
+        if (o_len == 0) {  // StripedProfile::new -> Err(ProfileError::EmptySequence)
+            a.out.score[o_id] = 0;
+            a.out.status[o_id] = ZSW_STATUS_EMPTY;
+            if (a.out.tier) a.out.tier[o_id] = 0;
+            if (MODE != 0 && a.out.ref_end) a.out.ref_end[o_id] = 0;
+            if (MODE == 2 && a.out.query_end) a.out.query_end[o_id] = 0;
+        } else if (o_stored >= 32767 - 256) {  // at or near i16 saturation: recompute exactly in 32 bits
+            const uint32_t k = atomicAdd(a.out.fb_count, 1u);
+            a.out.fb_list[k] = o_id;
+        } else {
             uint32_t score;
             uint8_t status, tier;
-            apply_rule(a.rule, (uint64_t)(stored + 32768), &score, &status, &tier);
-            a.out.score[id] = score;
-            a.out.status[id] = status;
-            if (a.out.tier) a.out.tier[id] = tier;
+            apply_rule(a.rule, (uint64_t)(o_stored + 32768), &score, &status, &tier);
+            a.out.score[o_id] = score;
+            a.out.status[o_id] = status;
+            if (a.out.tier) a.out.tier[o_id] = tier;
             const bool some = status == ZSW_STATUS_SOME;
-            if (MODE != 0 && a.out.ref_end) a.out.ref_end[id] = some ? (half ? reB : reA) : 0;
-            if (MODE == 2 && a.out.query_end) a.out.query_end[id] = some ? (half ? qeB : qeA) : 0;
+            if (MODE != 0 && a.out.ref_end) a.out.ref_end[o_id] = some ? o_re : 0;
+            if (MODE == 2 && a.out.query_end) a.out.query_end[o_id] = some ? o_qe : 0;
         }
     }
 }
