@@ -1,0 +1,225 @@
+"""GPU parity tests for the alignment path (sw_simd_align + traceback + CIGAR), through the C ABI.
+
+Checker = oracle/ at the SAME <T, N> instantiation (the striped traceback is layout dependent).
+Bar: bit-exact status, score, ref_range, query_range, CIGAR, ref_len, query_len.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+S_, O_, U_ = 0, 1, 2
+
+
+@pytest.fixture(scope="module")
+def za():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests need an MI355X")
+    import zoe_amd
+
+    return zoe_amd
+
+
+def osc(oracle, m, go, ge):
+    return oracle.Scoring(m.signed_weights(), m.mapping.index_map, go, ge)
+
+
+def okey(a):
+    return a.key() if a.status == S_ else (a.status, 0, (0, 0), (0, 0), "", 0, 0)
+
+
+def test_doc_examples(za):
+    # striped.rs:418-441
+    m = za.WeightMatrix.new_biased_dna_matrix(4, -2, b"N")
+    a = za.StripedProfileBatch([b"CGTTCGCCATAAAGGGGG"], m, -3, -1, "u8", 8).sw_align(za.SeqSrc.Reference(b"ATGCATCGATCGATCGATCGATCGATCGATGC"))
+    assert a.key(0)[:2] == (S_, 26) and a.cigar(0) == "6M2D9M3S"
+    # sw/mod.rs:164-188 and :224-248
+    m = za.WeightMatrix.new_dna_matrix(4, -2, b"N")
+    a = za.StripedProfileBatch([b"CTCAGATTG"], m, -3, -1, "i8", 32).sw_align(za.SeqSrc.Reference(b"GGCCACAGGATTGAG"))
+    assert a.key(0)[:2] == (S_, 27) and a.cigar(0) == "5M1D4M" and a.key(0)[2][0] == 3
+    a = za.into_local_profile([b"CTCAGATTG"], m, -3, -1).sw_align_from_i8(za.SeqSrc.Reference(b"GGCCACAGGATTGAG"))
+    assert a.key(0)[:2] == (S_, 27) and a.cigar(0) == "5M1D4M" and int(a.tier[0]) == 8
+    # sw/mod.rs:193-218 custom alphabet
+    mp = za.ByteIndexMap.new(b"ABCD", b"A")
+    m4 = za.WeightMatrix.new(mp, 1, -1, None)
+    a = za.StripedProfileBatch([b"AABDDAB"], m4, -4, -2, "i8", 32).sw_align(za.SeqSrc.Reference(b"BDAACAABDDDB"))
+    assert a.key(0)[:2] == (S_, 5) and a.cigar(0) == "5M2S"
+
+
+MACRO = [
+    (b"TTTAG", b"AAACTA", "i8", "u8", 2),
+    (b"AAAAAATAAA", b"AAAAAAAAAA", "i8", "u8", 4),
+    (b"CCCCA", b"TAAAA", "i8", "u8", 4),
+    (b"CCCCC", b"TCCCC", "i8", "u8", 4),
+    (b"CCCCT", b"GCTTTTC", "i8", "u8", 4),
+    (b"TTTTTGTTTTCTTTTTTGTTTA", b"TTGTTTTTTTTTGTT", "i8", "u8", 16),
+    (b"TTGTTTTGGGGAAAAA", b"TTTTTGTTTGGGAAAAATTCTT", "i8", "u8", 8),
+    (b"TTTTTTTCTTGTTTTTG", b"TTTTTGTTTTCTTGGT", "i8", "u8", 16),
+    (b"TTTTTTTTACTATTTTTAAATTTATGTTTTGTTA", b"TTTTTTTTTTTTAAAATTTGTAAACGTTTTGTTA", "i8", "u8", 8),
+    (b"TTTTTTTTTTTTTTTTTTTCCTTTTTTTTTTTTTTTTTTTTTTTTTTCCCCCCTTTA", b"TTTATTTTTTTTTTTTTTCCCCCCCTTTTTTTTTTTTTTTTTCCCCCCTTT", "i8", "u8", 8),
+    (b"TTTTTTTTTTTTTTTCCTTTTTTTTTTTTTTTTTTTCCCCCCCCCTA", b"TTTTTTTTTTTTTTTCCCCCTTTTTTTTTTCCCCCCCCCTT", "i8", "u8", 8),
+]
+
+
+@pytest.mark.parametrize("case", range(len(MACRO)))
+def test_sw_simd_align_macro_cases(za, oracle, case):
+    """test_sw_simd_align! (src/alignment/sw/test.rs:7-51, 116-195): striped == scalar, signed and unsigned."""
+    p, r, it, ut, lanes = MACRO[case]
+    m = za.WeightMatrix.new(za.DNA_PROFILE_MAP, 2, -5, b"N")
+    want = oracle.scalar_align(osc(oracle, m, -10, -1), p, r)
+    a = za.StripedProfileBatch([p], m, -10, -1, it, lanes).sw_align(za.SeqSrc.Reference(r))
+    assert a.key(0) == okey(want)
+    a = za.StripedProfileBatch([p], m.to_biased_matrix(), -10, -1, ut, lanes).sw_align(za.SeqSrc.Reference(r))
+    assert a.key(0) == okey(want)
+
+
+def test_h5_h1_i16x8(za, oracle, h5, h1):
+    # src/alignment/sw/test.rs:116-119 (profile = H5, 1,760 bp: nv = 220 at N = 8)
+    m = za.WeightMatrix.new(za.DNA_PROFILE_MAP, 2, -5, b"N")
+    want = oracle.scalar_align(osc(oracle, m, -10, -1), h5, h1)
+    a = za.StripedProfileBatch([h5], m, -10, -1, "i16", 16).sw_align(za.SeqSrc.Reference(h1))
+    assert a.key(0) == okey(oracle.align("i16", 16, osc(oracle, m, -10, -1), h5, h1))
+    assert a.key(0) == okey(want)
+
+
+def test_layout_dependent_cigars(za, oracle):
+    """SURVEY.md §7 hard part 1: equal score and ends, different CIGAR per lane count — the GPU must follow N."""
+    cases = [
+        (4, -2, -3, -1, b"GGACTAAGCTAACACAGGTAGGCTTTATAAAAGGTTAAAGTGCGTGAGCTAGGGTGGCTCTCACT", b"TATAAAAGGTTAAAGTGCTGTAGCTTAGGGTTGCTCTC"),
+        (3, -1, -4, -1, b"TGGGGCATTTATGCGATGCAAGACAGGTCTAATATTGAAATTTATTCTAGACTATGCGAGGCCGCTCAAAGGAACCATTACCTTTTTCCGTAGGTCTCCCGATCGCGGCTAACTACTGC", b"ATAGCGATCGCAGCGCCAGGTCT"),
+    ]
+    for ma, mi, go, ge, ref, read in cases:
+        m = za.WeightMatrix.new_dna_matrix(ma, mi, b"N")
+        seen = set()
+        for N in (2, 4, 8, 16, 32, 64):
+            want = oracle.align("i16", N, osc(oracle, m, go, ge), read, ref)
+            got = za.StripedProfileBatch([read], m, go, ge, "i16", N).sw_align(za.SeqSrc.Reference(ref))
+            assert got.key(0) == okey(want), N
+            seen.add(got.cigar(0))
+        assert len(seen) == 2
+
+
+@pytest.mark.parametrize("scheme", [(4, -2, -3, -1), (2, -5, -10, -1), (3, -1, 0, 0), (1, -1, -1, -1), (5, -4, -2, 0)])
+def test_random_pairs_all_lane_counts(za, oracle, scheme):
+    ma, mi, go, ge = scheme
+    rng = np.random.default_rng(hash(scheme) % (2**32))
+    m = za.WeightMatrix.new_dna_matrix(ma, mi, b"N")
+    sc = osc(oracle, m, go, ge)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = bytes(rng.choice(alpha, 160))
+    reads = []
+    for _ in range(120):
+        L = int(rng.integers(8, 60))
+        if rng.random() < 0.7:  # sampled from the reference with edits (ties between I and D paths)
+            s = int(rng.integers(0, 160 - L))
+            r = bytearray(ref[s : s + L])
+            for _ in range(int(rng.integers(0, 4))):
+                k = int(rng.integers(0, len(r)))
+                t = rng.random()
+                if t < 0.4:
+                    r[k] = int(rng.choice(alpha))
+                elif t < 0.7:
+                    del r[k]
+                else:
+                    r.insert(k, int(rng.choice(alpha)))
+            reads.append(bytes(r) if r else b"A")
+        else:  # low complexity
+            reads.append(bytes(rng.choice(alpha[:2], L)))
+    for N in (2, 4, 8, 16, 32, 64):
+        got = za.StripedProfileBatch(reads, m, go, ge, "i16", N).sw_align(za.SeqSrc.Reference(ref))
+        for i, rd in enumerate(reads):
+            want = oracle.align("i16", N, sc, rd, ref)
+            assert got.key(i) == okey(want), (N, i, rd)
+
+
+def test_config3_sample_cascade_w256(za, oracle):
+    """BASELINE.json configs[2] shape: 150 bp reads vs a 2 kb reference, sw_align_from_i8 at the w256 preset
+    (CIGAR from i16x16 when the score >= 255, from i8x32 otherwise)."""
+    from zoe_amd import synth
+
+    ref = synth.reference_host(2000)
+    n = 3000
+    host = synth.reads_host(ref, 0, n, 150)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    sc = osc(oracle, dna, -10, -1)
+    import torch
+
+    rb = za.ReadBatch.from_fixed(torch.from_numpy(host.reshape(-1)).cuda(), 150)
+    got = za.into_local_profile(rb, dna, -10, -1).sw_align_from_i8(za.SeqSrc.Reference(ref))
+    tiers = set()
+    for i in range(n):
+        want, tier = oracle.cascade_align(8, 256, sc, host[i], ref)
+        assert got.key(i) == okey(want), i
+        if want.status == S_:
+            assert int(got.tier[i]) == tier
+            tiers.add(tier)
+            # sw_score_from_path-style self check (sw/mod.rs:399-454)
+            rr = got.records[i]
+            assert oracle.score_from_path(sc, host[i], ref[int(rr["ref_start"]) : int(rr["ref_end"])], got.cigar(i)) == int(rr["score"])
+    assert tiers == {8, 16}
+
+
+def test_invert_seqsrc_query(za, oracle):
+    # src/alignment/types/test.rs:14-38 through the striped path (+ random pairs)
+    m = za.WeightMatrix.new_dna_matrix(4, -2, b"N")
+    sc = osc(oracle, m, -3, -1)
+    ref, q = b"GGCCACAGGATTGAGC", b"TCTCAGATTGCAGTTT"
+    a = za.StripedProfileBatch([q], m, -3, -1, "i16", 16).sw_align(za.SeqSrc.Query(ref))
+    assert a.key(0) == okey(oracle.align("i16", 16, sc, q, ref, other_is_query=True))
+    rng = np.random.default_rng(8)
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    other = bytes(rng.choice(alpha, 90))
+    reads = [bytes(rng.choice(alpha[:4], int(rng.integers(5, 50)))) for _ in range(80)] + [other[10:60], other[40:85]]
+    a = za.StripedProfileBatch(reads, m, -3, -1, "i8", 16).sw_align(za.SeqSrc.Query(other))
+    for i, rd in enumerate(reads):
+        assert a.key(i) == okey(oracle.align("i8", 16, sc, rd, other, other_is_query=True)), i
+
+
+def test_long_gap_leaves_window_and_many_ciglets(za, oracle):
+    """A free-extension deletion of 700 reference bases makes the traceback span far more rows than the retained
+    window (fallback: full window); an alternating M/I/D pattern needs more than the 32 fast-path ciglet slots."""
+    rng = np.random.default_rng(21)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = bytes(rng.choice(alpha, 1200))
+    read = ref[100:160] + ref[860:920]
+    m = za.WeightMatrix.new_dna_matrix(3, -4, b"N")
+    sc = osc(oracle, m, -5, 0)
+    reads = [read, ref[300:380], ref[500:540] + ref[900:940]]
+    got = za.StripedProfileBatch(reads, m, -5, 0, "i16", 16).sw_align(za.SeqSrc.Reference(ref))
+    for i, rd in enumerate(reads):
+        want = oracle.align("i16", 16, sc, rd, ref)
+        assert got.key(i) == okey(want), i
+    assert "700D" in got.cigar(0)
+    # many ciglets: read = reference with a base deleted every 6 bases (gaps are cheap)
+    src = ref[0:400]
+    rd = bytes(b for k, b in enumerate(src) if k % 6 != 5)
+    m2 = za.WeightMatrix.new_dna_matrix(5, -9, b"N")
+    got = za.StripedProfileBatch([rd], m2, -1, -1, "i16", 16).sw_align(za.SeqSrc.Reference(ref))
+    want = oracle.align("i16", 16, osc(oracle, m2, -1, -1), rd, ref)
+    assert got.key(0) == okey(want)
+    assert want.n_ciglets > 32
+
+
+def test_overflow_unmapped_and_ragged(za, oracle):
+    from zoe_amd import synth
+
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    sc = osc(oracle, dna, -10, -1)
+    ref = synth.reference_host(800)
+    hb, hoff = synth.reads_ragged_host(ref, 11, 301, 20, 260)
+    reads = [hb[hoff[i] : hoff[i + 1]].tobytes() for i in range(301)]
+    reads[7] = b"N" * 33
+    # direct i8: reads scoring >= 255 are Overflowed (striped.rs:557-559), the others align at i8x32
+    got = za.StripedProfileBatch(reads, dna, -10, -1, "i8", 32).sw_align(za.SeqSrc.Reference(ref))
+    n_over = 0
+    for i, rd in enumerate(reads):
+        want = oracle.align("i8", 32, sc, rd, ref)
+        assert got.key(i) == okey(want), i
+        n_over += want.status == O_
+    assert n_over > 10 and int(got.status[7]) == U_
+    got = za.LocalProfilesBatch.new_with_w512(reads, dna, -10, -1).sw_align_from_i8(za.SeqSrc.Reference(ref))
+    for i, rd in enumerate(reads):
+        want, tier = oracle.cascade_align(8, 512, sc, rd, ref)
+        assert got.key(i) == okey(want), i

@@ -1,18 +1,452 @@
-// zsw_align.hip — full alignment (traceback) entry points. Placeholder until the striped-emulation
-// kernel lands: the calls fail loudly rather than fall back to anything else.
-#include "zsw_internal.hpp"
+// zsw_align.hip — full alignment: sw_simd_align (striped.rs:449-598) + traceback (backtrack.rs:290-342)
+// + AlignmentStates (state.rs) + SeqSrc inversion (alignment/mod.rs:176-190, output.rs:396-425), batched.
+//
+// Zoe's traceback flags depend on the striped layout (which cells see F in the main pass and which only
+// in the lazy-F pass, and where the vector-wide `any()` stops the lazy-F loop), so — unlike the score —
+// they must be produced by the SAME <N lanes, nv = ceil(L/N) vectors> recurrence the CPU runs.  The kernel
+// below therefore emulates one `Simd<T,N>` with N adjacent GPU lanes (64/N reads per wavefront):
+//   shift_elements_right::<1>  -> __shfl_up within the N-lane group, lane 0 filled with T::MIN (true 0)
+//   mask.any()                 -> wave ballot restricted to the group's N lanes (padding lanes included)
+//   StripedProfile             -> per-wave LDS table prof[ref_idx][v][lane] (profile.rs:270-306)
+//   load/store/e_scores        -> per-wave LDS rows H[v][lane], E[v][lane]
+// Values are kept as true scores in i32 (offset T::MIN removed); every saturating_sub of the reference
+// that floors at T::MIN is a max(0, .) here. Width (i8/i16/i32, signed/unsigned) only decides whether the
+// read is Overflowed, which pass 1 (the packed score kernel) has already settled.
+//
+// Memory: the CPU materialises R*nv*N flag bytes per call. Here pass 1 supplies (score, ref_end); pass 2
+// recomputes rows 0..=r_end and keeps only the last W rows of flags in a per-wave ring in HBM/L2, then one
+// lane walks the traceback. A read whose walk leaves the window (or overflows the ciglet scratch) is
+// re-run with a window covering every row.
+#include <algorithm>
+#include <vector>
 
-extern "C" {
+#include "zsw_align.hpp"
 
-zsw_error zsw_align_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, int invert,
-                          zsw_alignment* out_aln, uint8_t* out_status, uint32_t* out_inc, uint8_t* out_op,
-                          uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream) {
-    return ZSW_ERR_UNSUPPORTED;
+namespace zsw {
+
+constexpr uint8_t BT_UP = 1, BT_UP_EXT = 2, BT_LEFT = 4, BT_LEFT_EXT = 8, BT_STOP = 16;  // backtrack.rs:18-34
+
+struct AlignArgs {
+    BatchDev b;
+    const uint8_t* ref;
+    uint32_t ref_len;
+    const ScoringDev* sc;
+    const uint32_t* score;    // pass-1 results, indexed by read id
+    const uint32_t* ref_end;  // exclusive end (r_end + 1)
+    const uint8_t* status;
+    uint32_t nv, W, maxc;
+    uint8_t* ring;           // [gridDim.x][64/N][W][nv][N] flag bytes
+    uint32_t* cig;           // ciglet pool of this launch: (inc << 8 | op) in traceback order, maxc slots per read
+    uint64_t pool_base;      // first pool slot of this launch
+    int by_item;             // slot = pool_base + (by_item ? item : read id) * maxc
+    uint64_t* cig_start;     // per read: device address of its first slot (pools differ between launches)
+    uint32_t* cig_raw;       // per read: ciglets written to the pool (traceback order)
+    zsw_alignment* aln;      // per read; n_ciglets = count after the optional inversion
+    uint32_t* fb_list;
+    uint32_t* fb_count;
+    int invert;
+};
+
+__device__ __forceinline__ uint32_t read_len(const BatchDev& b, uint32_t id, uint64_t* off) {
+    if (b.offsets) {
+        *off = b.offsets[id];
+        return (uint32_t)(b.offsets[id + 1] - *off);
+    }
+    *off = (uint64_t)id * b.fixed_len;
+    return b.fixed_len;
 }
 
-zsw_error zsw_align_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, int invert,
-                               zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
-                               uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream) {
-    return ZSW_ERR_UNSUPPORTED;
+template <int N>
+__global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ uint8_t lut[256];
+    __shared__ int32_t wsh[MAX_S * MAX_S];
+    constexpr int RPW = 64 / N;
+    const int lane = threadIdx.x;
+    const int li = lane % N, grp = lane / N;
+    const uint32_t nv = a.nv;
+    const int S = a.sc->S;
+    const int go = a.sc->gap_open, ge = a.sc->gap_extend;
+    int32_t* Hs = reinterpret_cast<int32_t*>(smem);  // [nv][64]
+    int32_t* Es = Hs + nv * 64;                      // [nv][64]
+    int8_t* prof = reinterpret_cast<int8_t*>(Es + nv * 64);  // [S][nv][64]
+    uint8_t* fl = reinterpret_cast<uint8_t*>(prof + (size_t)S * nv * 64);  // [nv][64]
+    for (int i = lane; i < 256; i += 64) lut[i] = a.sc->index_map[i];
+    for (int i = lane; i < S * S; i += 64) wsh[i] = a.sc->w[i];
+    __syncthreads();
+    const unsigned long long gmask = (N == 64) ? ~0ull : (((1ull << N) - 1ull) << (grp * N));
+    const size_t row_bytes = (size_t)nv * N;
+    uint8_t* ring = a.ring + ((size_t)blockIdx.x * RPW + grp) * (size_t)a.W * row_bytes;
+
+    for (uint32_t first = blockIdx.x * RPW; first < a.b.n_items; first += gridDim.x * RPW) {
+        const uint32_t item = first + grp;
+        const bool valid = item < a.b.n_items;
+        const uint32_t id = valid ? (a.b.items ? a.b.items[item] : item) : 0;
+        uint64_t off = 0;
+        const uint32_t len = valid ? read_len(a.b, id, &off) : 0;
+        const bool active = valid && a.status[id] == ZSW_STATUS_SOME && len > 0 && (len + N - 1) / N == nv;
+        const int rend = active ? (int)a.ref_end[id] - 1 : -1;
+        const int32_t best = active ? (int32_t)a.score[id] : 0;
+
+        // StripedProfile::new_unchecked (profile.rs:270-306): position q = v + lane*nv; padding scores bias (= true 0)
+        for (uint32_t v = 0; v < nv; ++v) {
+            const uint32_t q = v + (uint32_t)li * nv;
+            const int k = (active && q < len) ? (int)lut[a.b.bases[off + q]] : -1;
+            for (int ri = 0; ri < S; ++ri) prof[((size_t)ri * nv + v) * 64 + lane] = k < 0 ? (int8_t)0 : (int8_t)wsh[ri * S + k];
+            Hs[v * 64 + lane] = 0;
+            Es[v * 64 + lane] = 0;
+        }
+        int rmax = rend;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) rmax = max(rmax, __shfl_xor(rmax, d, 64));
+
+        for (int r = 0; r <= rmax; ++r) {
+            const bool act = r <= rend;
+            const int ri = lut[a.ref[r]];
+            const int8_t* prow = prof + (size_t)ri * nv * 64 + lane;
+            // main pass (striped.rs:481-526)
+            int32_t F = 0;
+            int32_t H = __shfl_up(Hs[(nv - 1) * 64 + lane], 1, N);
+            if (li == 0) H = 0;
+            for (uint32_t v = 0; v < nv; ++v) {
+                int32_t E = Es[v * 64 + lane];
+                const int32_t hold = Hs[v * 64 + lane];
+                H = max(H + (int32_t)prow[v * 64], 0);
+                H = max(H, max(E, F));
+                uint32_t flags = (E == H ? BT_UP : 0) | (F == H ? BT_LEFT : 0);
+                const bool stopped = H == 0;
+                const int32_t Hn = H;
+                H = max(H - go, 0);
+                E = max(max(E - ge, 0), H);
+                F = max(max(F - ge, 0), H);
+                flags |= (E > H ? BT_UP_EXT : 0) | (F > H ? BT_LEFT_EXT : 0);
+                if (stopped) flags = BT_STOP;
+                if (act) {
+                    Hs[v * 64 + lane] = Hn;
+                    Es[v * 64 + lane] = E;
+                    fl[v * 64 + lane] = (uint8_t)flags;
+                }
+                H = hold;
+            }
+            // lazy-F pass (striped.rs:528-553): per read, up to N rounds, stops at the first vector where no lane
+            // of THAT read has F > H - gap_open
+            bool done = !act;
+            for (int it = 0; it < N; ++it) {
+                F = __shfl_up(F, 1, N);
+                if (li == 0) F = 0;
+                bool all_done = false;
+                for (uint32_t v = 0; v < nv; ++v) {
+                    H = Hs[v * 64 + lane];
+                    const bool cond = !done && F > max(H - go, 0);
+                    const unsigned long long bal = __ballot(cond);
+                    if ((bal & gmask) == 0) done = true;
+                    if (bal == 0) {  // every read of the wave has left its lazy-F loop
+                        all_done = true;
+                        break;
+                    }
+                    if (!done) {
+                        H = max(H, F);
+                        uint32_t flags = fl[v * 64 + lane];
+                        const bool stopped = H == 0;
+                        if (F == H) flags = (flags & BT_UP_EXT) | BT_LEFT;  // simd_correct_and_set_left
+                        Hs[v * 64 + lane] = H;
+                        H = max(H - go, 0);
+                        F = max(F - ge, 0);
+                        if (F > H) flags |= BT_LEFT_EXT;
+                        if (stopped) flags = BT_STOP;
+                        fl[v * 64 + lane] = (uint8_t)flags;
+                    }
+                }
+                if (all_done) break;
+            }
+            // keep the last W rows of flags of every read still running
+            if (act && r + (int)a.W > rend) {
+                uint8_t* dst = ring + (size_t)(r % (int)a.W) * row_bytes;
+                for (uint32_t v = 0; v < nv; ++v) dst[(size_t)v * N + li] = fl[v * 64 + lane];
+            }
+        }
+
+        // c_end: first query position of row r_end whose H equals the best score (striped.rs:571-583)
+        int cend = 0x7fffffff;
+        if (active) {
+            for (int v = (int)nv - 1; v >= 0; --v) {
+                const uint32_t ci = (uint32_t)v + (uint32_t)li * nv;
+                if (ci < len && Hs[v * 64 + lane] == best) cend = (int)ci;
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < N; d <<= 1) cend = min(cend, __shfl_xor(cend, d, N));
+        __threadfence_block();  // this wave's ring stores are visible to its own traceback loads
+
+        if (active && li == 0) {
+            // BackTrackable::to_alignment (backtrack.rs:290-342) with AlignmentStates::add_ciglet merging (state.rs:142-152)
+            const uint64_t slot0 = a.pool_base + (uint64_t)(a.by_item ? item : id) * a.maxc;
+            uint32_t* cig = a.cig + slot0;
+            uint32_t ncig = 0, cur_op = 0, cur_inc = 0;
+            bool overflow = cend == 0x7fffffff;
+            auto push = [&](uint32_t inc, uint32_t op) {
+                if (inc == 0) return;
+                if (cur_inc && cur_op == op) {
+                    cur_inc += inc;
+                    return;
+                }
+                if (cur_inc) {
+                    if (ncig < a.maxc) cig[ncig] = (cur_inc << 8) | cur_op;
+                    else overflow = true;
+                    ++ncig;
+                }
+                cur_op = op;
+                cur_inc = inc;
+            };
+            const int r_end1 = rend + 1, c_end1 = cend + 1;
+            int r = r_end1, c = c_end1;
+            uint32_t n_nons = 0;  // ciglets that are not soft clips (for the inverted count)
+            if (!overflow) {
+                push(len - (uint32_t)c, 'S');
+                auto cell = [&](int rr, int cc) -> uint32_t {
+                    // agent-scope load: served by L2, never by a stale L1 line of an earlier item's window
+                    return __hip_atomic_load(ring + (size_t)(rr % (int)a.W) * row_bytes + (size_t)(cc % (int)nv) * N + (size_t)(cc / (int)nv),
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                };
+                uint32_t f = cell(rend, cend);
+                uint32_t op = 0;
+                while (!(f & BT_STOP) && r > 0 && c > 0) {
+                    if (op == 'D' && (f & BT_UP_EXT)) {
+                        r -= 1;
+                    } else if (op == 'I' && (f & BT_LEFT_EXT)) {
+                        c -= 1;
+                    } else if (f & BT_UP) {
+                        op = 'D';
+                        r -= 1;
+                    } else if (f & BT_LEFT) {
+                        op = 'I';
+                        c -= 1;
+                    } else {
+                        op = 'M';
+                        r -= 1;
+                        c -= 1;
+                    }
+                    if (!(cur_inc && cur_op == op)) ++n_nons;
+                    push(1, op);
+                    if (r > 0 && c > 0) {
+                        if (r - 1 + (int)a.W <= rend) {  // the walk left the retained window
+                            overflow = true;
+                            break;
+                        }
+                        f = cell(r - 1, c - 1);
+                    }
+                }
+                push((uint32_t)c, 'S');
+                push(1, 0);  // flush the pending ciglet (the sentinel op 0 itself is never stored)
+            }
+            if (overflow || ncig > a.maxc) {
+                const uint32_t k = atomicAdd(a.fb_count, 1u);
+                a.fb_list[k] = id;
+            } else {
+                zsw_alignment out;
+                out.score = (uint32_t)best;
+                out.ref_start = (uint32_t)r;
+                out.ref_end = (uint32_t)r_end1;
+                out.query_start = (uint32_t)c;
+                out.query_end = (uint32_t)c_end1;
+                out.ref_len = a.ref_len;
+                out.query_len = len;
+                // forward count; inverted: clips re-derived from ref_range (output.rs:399-414)
+                out.n_ciglets = a.invert ? n_nons + (r > 0 ? 1u : 0u) + (a.ref_len > (uint32_t)r_end1 ? 1u : 0u) : ncig;
+                out.ciglet_offset = 0;  // filled by write_ciglets_kernel
+                a.aln[id] = out;
+                a.cig_start[id] = (uint64_t)(uintptr_t)cig;
+                a.cig_raw[id] = ncig;
+            }
+        }
+    }
 }
+
+// ---- exclusive scan of n_ciglets and the final packed write -------------------------------------
+constexpr int SCAN_BLOCK = 1024;
+
+__global__ void count_block_kernel(const zsw_alignment* aln, const uint8_t* status, uint32_t n, uint64_t* block_sums) {
+    __shared__ uint64_t sh[SCAN_BLOCK / 64];
+    const uint32_t i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    uint64_t v = (i < n && status[i] == ZSW_STATUS_SOME) ? aln[i].n_ciglets : 0;
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor((long long)v, d, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x / 64] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int k = 0; k < SCAN_BLOCK / 64; ++k) t += sh[k];
+        block_sums[blockIdx.x] = t;
+    }
 }
+
+__global__ void scan_sums_kernel(uint64_t* block_sums, uint32_t nblocks, uint64_t* total) {
+    // single thread: nblocks <= ~2M/1024; tiny
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint64_t run = 0;
+        for (uint32_t k = 0; k < nblocks; ++k) {
+            const uint64_t t = block_sums[k];
+            block_sums[k] = run;
+            run += t;
+        }
+        *total = run;
+    }
+}
+
+__global__ void write_ciglets_kernel(zsw_alignment* aln, const uint8_t* status, uint32_t n, const uint64_t* block_sums,
+                                     const uint64_t* cig_start, const uint32_t* cig_raw, int invert, uint32_t* out_inc,
+                                     uint8_t* out_op, uint64_t cap) {
+    __shared__ uint64_t sh[SCAN_BLOCK];
+    const uint32_t i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const bool some = i < n && status[i] == ZSW_STATUS_SOME;
+    const uint64_t mine = some ? aln[i].n_ciglets : 0;
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 1; d < SCAN_BLOCK; d <<= 1) {  // Hillis-Steele inclusive scan
+        uint64_t t = threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (i >= n) return;
+    if (!some) {
+        zsw_alignment z = {};
+        aln[i] = z;
+        return;
+    }
+    const uint64_t off = block_sums[blockIdx.x] + sh[threadIdx.x] - mine;
+    zsw_alignment rec = aln[i];
+    const uint32_t raw = cig_raw[i];
+    rec.ciglet_offset = off;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>((uintptr_t)cig_start[i]);
+    if (off + mine <= cap) {
+        uint64_t w = off;
+        if (!invert) {
+            for (uint32_t k = 0; k < raw; ++k) {  // make_reverse (state.rs:281-283)
+                const uint32_t e = src[raw - 1 - k];
+                out_inc[w] = e >> 8;
+                out_op[w] = (uint8_t)(e & 0xff);
+                ++w;
+            }
+        } else {  // Alignment::invert (output.rs:396-425)
+            if (rec.ref_start > 0) {
+                out_inc[w] = rec.ref_start;
+                out_op[w] = 'S';
+                ++w;
+            }
+            for (uint32_t k = 0; k < raw; ++k) {
+                const uint32_t e = src[raw - 1 - k];
+                uint8_t op = (uint8_t)(e & 0xff);
+                if (op == 'S' || op == 'H') continue;
+                if (op == 'D') op = 'I';
+                else if (op == 'I') op = 'D';
+                out_inc[w] = e >> 8;
+                out_op[w] = op;
+                ++w;
+            }
+            if (rec.ref_len > rec.ref_end) {
+                out_inc[w] = rec.ref_len - rec.ref_end;
+                out_op[w] = 'S';
+                ++w;
+            }
+        }
+    }
+    if (invert) {
+        const uint32_t rs = rec.ref_start, re = rec.ref_end, rl = rec.ref_len;
+        rec.ref_start = rec.query_start;
+        rec.ref_end = rec.query_end;
+        rec.ref_len = rec.query_len;
+        rec.query_start = rs;
+        rec.query_end = re;
+        rec.query_len = rl;
+    }
+    aln[i] = rec;
+}
+
+static size_t align_lds_bytes(uint32_t nv, int S) { return (size_t)nv * 64 * (4 + 4 + (size_t)S + 1); }
+
+template <int N>
+static hipError_t launch_align_n(const AlignArgs& a, uint32_t grid, size_t lds, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&align_kernel<N>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((align_kernel<N>), dim3(grid), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace zsw
+
+using namespace zsw;
+
+namespace {
+
+hipError_t run_group(int N, AlignArgs a, int S, uint32_t grid, hipStream_t stream) {
+    const size_t lds = align_lds_bytes(a.nv, S);
+    switch (N) {
+        case 2: return launch_align_n<2>(a, grid, lds, stream);
+        case 4: return launch_align_n<4>(a, grid, lds, stream);
+        case 8: return launch_align_n<8>(a, grid, lds, stream);
+        case 16: return launch_align_n<16>(a, grid, lds, stream);
+        case 32: return launch_align_n<32>(a, grid, lds, stream);
+        case 64: return launch_align_n<64>(a, grid, lds, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+// The host orchestration (zsw_align_batch / zsw_align_batch_from) lives in zsw_capi.hip because it needs the
+// context internals; it calls these entry points.
+namespace zsw {
+
+hipError_t align_pass2(int N, uint32_t nv, const BatchDev& b, const uint8_t* d_ref, uint32_t ref_len, const ScoringDev* d_sc,
+                       int S, const uint32_t* d_score, const uint32_t* d_ref_end, const uint8_t* d_status, uint32_t W,
+                       uint32_t maxc, uint8_t* d_ring, uint32_t grid, uint32_t* d_cig, uint64_t pool_base, int by_item,
+                       uint64_t* d_cig_start, uint32_t* d_cig_raw, zsw_alignment* d_aln, uint32_t* d_fb_list,
+                       uint32_t* d_fb_count, int invert, hipStream_t stream) {
+    AlignArgs a;
+    a.b = b;
+    a.ref = d_ref;
+    a.ref_len = ref_len;
+    a.sc = d_sc;
+    a.score = d_score;
+    a.ref_end = d_ref_end;
+    a.status = d_status;
+    a.nv = nv;
+    a.W = W;
+    a.maxc = maxc;
+    a.ring = d_ring;
+    a.cig = d_cig;
+    a.pool_base = pool_base;
+    a.by_item = by_item;
+    a.cig_start = d_cig_start;
+    a.cig_raw = d_cig_raw;
+    a.aln = d_aln;
+    a.fb_list = d_fb_list;
+    a.fb_count = d_fb_count;
+    a.invert = invert;
+    return run_group(N, a, S, grid, stream);
+}
+
+size_t align_ring_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid) { return (size_t)grid * (64 / N) * (size_t)W * nv * N; }
+size_t align_lds_need(uint32_t nv, int S) { return align_lds_bytes(nv, S); }
+
+hipError_t align_finalize(zsw_alignment* d_aln, const uint8_t* d_status, uint32_t n, uint64_t* d_block_sums,
+                          uint64_t* d_total, const uint64_t* d_cig_start, const uint32_t* d_cig_raw, int invert,
+                          uint32_t* out_inc, uint8_t* out_op, uint64_t cap, bool count_only, hipStream_t stream) {
+    const uint32_t nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (nblocks == 0) return hipSuccess;
+    if (count_only) {
+        hipLaunchKernelGGL(count_block_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, stream, d_aln, d_status, n, d_block_sums);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(64), 0, stream, d_block_sums, nblocks, d_total);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(write_ciglets_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, stream, d_aln, d_status, n, d_block_sums,
+                       d_cig_start, d_cig_raw, invert, out_inc, out_op, cap);
+    return hipGetLastError();
+}
+
+}  // namespace zsw

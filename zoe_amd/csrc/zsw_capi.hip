@@ -3,8 +3,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <new>
+#include <utility>
+#include <vector>
 
+#include "zsw_align.hpp"
 #include "zsw_internal.hpp"
 #include "zsw_synth.h"
 #include "zsw_timer.hpp"
@@ -47,7 +51,7 @@ struct zsw_context {
     // staging for host-memory batches
     DevBuf s_bases, s_offsets, s_score, s_status, s_tier, s_rend, s_qend;
     // alignment workspace (zsw_align.hip)
-    DevBuf a_ws[8];
+    DevBuf a_ws[20];
     KernelTimer timer;
     std::string err;
 };
@@ -260,14 +264,241 @@ zsw_error run_score(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     out.fb_count = ctx->d_fb_count.as<uint32_t>();
     hipError_t e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(),
                                 (uint32_t)ctx->ref_len, rule, out, ctx->d_scratch.as<int32_t>(), EXACT_SLOTS,
-                                ctx->scratch_len, stream, &ctx->timer, want_ends);
+                                ctx->scratch_len, stream, &ctx->timer, want_ends ? 2 : 0);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "score launch", e);
     return unstage(ctx, reads, stream, st, out_score, out_status, out_tier, out_rend, out_qend);
+}
+
+
+enum { WS_SCORE = 0, WS_STATUS, WS_TIER, WS_REND, WS_ITEMS, WS_RING, WS_CIG, WS_ALN, WS_CIGSTART, WS_CIGRAW, WS_BSUMS, WS_TOTAL,
+       WS_FBLIST, WS_FBCOUNT, WS_OINC, WS_OOP, WS_CIG2, WS_RING2 };
+
+typedef std::map<std::pair<int, uint32_t>, std::vector<uint32_t>> Groups;  // <N lanes, nv vectors> -> read ids
+
+// lanes_w*: lane count of the profile whose width answered (direct call: the caller's N for its one width).
+zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, int lanes_w8, int lanes_w16, int lanes_w32,
+                    int invert, zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
+                    uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!reads || !out_aln || !out_status || !out_n_ciglets || (ciglet_cap && (!out_inc || !out_op)))
+        return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
+    const uint32_t n = (uint32_t)reads->n_reads;
+    Staged st;
+    {
+        uint32_t dummy_score = 0;
+        uint8_t dummy_status = 0;
+        zsw_error ze = stage(ctx, reads, stream, false, false, &dummy_score, &dummy_status, nullptr, nullptr, nullptr, &st);
+        if (ze != ZSW_OK) return ze;
+    }
+    *out_n_ciglets = 0;
+    if (n == 0) return ZSW_OK;
+    const bool host = reads->mem == ZSW_MEM_HOST;
+    DevBuf* ws = ctx->a_ws;
+    ZSW_HIP(ctx, ws[WS_SCORE].ensure((size_t)n * 4 + 4));
+    ZSW_HIP(ctx, ws[WS_STATUS].ensure((size_t)n + 4));
+    ZSW_HIP(ctx, ws[WS_TIER].ensure((size_t)n + 4));
+    ZSW_HIP(ctx, ws[WS_REND].ensure((size_t)n * 4 + 4));
+    // pass 1: packed score kernel with the reference-end row (sw_simd_align's `best` and `r_end`)
+    ScoreOut so;
+    so.score = ws[WS_SCORE].as<uint32_t>();
+    so.status = ws[WS_STATUS].as<uint8_t>();
+    so.tier = ws[WS_TIER].as<uint8_t>();
+    so.ref_end = ws[WS_REND].as<uint32_t>();
+    so.query_end = nullptr;
+    so.fb_list = ctx->d_fb_list.as<uint32_t>();
+    so.fb_count = ctx->d_fb_count.as<uint32_t>();
+    hipError_t e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(),
+                                (uint32_t)ctx->ref_len, rule, so, ctx->d_scratch.as<int32_t>(), EXACT_SLOTS, ctx->scratch_len,
+                                stream, nullptr, 1);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align pass 1", e);
+
+    // group the reads that have an alignment by the <N, nv> of the instantiation that answered
+    std::vector<uint8_t> h_status(n), h_tier(n);
+    ZSW_HIP(ctx, hipMemcpyAsync(h_status.data(), so.status, n, hipMemcpyDeviceToHost, stream));
+    ZSW_HIP(ctx, hipMemcpyAsync(h_tier.data(), so.tier, n, hipMemcpyDeviceToHost, stream));
+    std::vector<uint64_t> h_off;
+    const uint64_t* offs = nullptr;
+    if (reads->offsets) {
+        if (host) {
+            offs = reads->offsets;
+        } else {
+            h_off.resize((size_t)n + 1);
+            ZSW_HIP(ctx, hipMemcpyAsync(h_off.data(), reads->offsets, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, stream));
+            offs = h_off.data();
+        }
+    }
+    ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    auto key_of = [&](uint32_t i) {
+        const int N = h_tier[i] == 8 ? lanes_w8 : h_tier[i] == 16 ? lanes_w16 : lanes_w32;
+        const uint32_t len = offs ? (uint32_t)(offs[i + 1] - offs[i]) : reads->fixed_len;
+        return std::make_pair(N, (len + (uint32_t)N - 1) / (uint32_t)N);
+    };
+    Groups groups;
+    for (uint32_t i = 0; i < n; ++i)
+        if (h_status[i] == ZSW_STATUS_SOME) groups[key_of(i)].push_back(i);
+    const int S = ctx->h_sc.S;
+    for (auto& g : groups)
+        if (align_lds_need(g.first.second, S) + 4352 + 64 > 160 * 1024)
+            return fail(ctx, ZSW_ERR_UNSUPPORTED, "read too long for the alignment kernel's LDS-resident profile");
+
+    const uint32_t MAXC = 32;
+    ZSW_HIP(ctx, ws[WS_ALN].ensure((size_t)n * sizeof(zsw_alignment)));
+    ZSW_HIP(ctx, ws[WS_CIGSTART].ensure((size_t)n * 8));
+    ZSW_HIP(ctx, ws[WS_CIGRAW].ensure((size_t)n * 4));
+    ZSW_HIP(ctx, ws[WS_FBLIST].ensure((size_t)n * 4 + 4));
+    ZSW_HIP(ctx, ws[WS_FBCOUNT].ensure(4));
+    ZSW_HIP(ctx, ws[WS_ITEMS].ensure((size_t)n * 4 + 4));
+    ZSW_HIP(ctx, ws[WS_CIG].ensure((size_t)n * MAXC * 4));
+    ZSW_HIP(ctx, hipMemsetAsync(ws[WS_FBCOUNT].p, 0, 4, stream));
+
+    auto run_groups = [&](Groups& gs, bool full, DevBuf& ringbuf, DevBuf& cigbuf) -> zsw_error {
+        std::vector<uint32_t> all;
+        for (auto& g : gs) all.insert(all.end(), g.second.begin(), g.second.end());
+        if (all.empty()) return ZSW_OK;
+        ZSW_HIP(ctx, hipMemcpyAsync(ws[WS_ITEMS].p, all.data(), all.size() * 4, hipMemcpyHostToDevice, stream));
+        ZSW_HIP(ctx, hipStreamSynchronize(stream));  // `all` is a temporary
+        if (full) {
+            uint64_t need = 0;
+            for (auto& g : gs) need += (uint64_t)g.second.size() * ((uint64_t)g.first.first * g.first.second + ctx->ref_len + 4);
+            ZSW_HIP(ctx, cigbuf.ensure(need * 4));
+        }
+        size_t pos = 0;
+        uint64_t pool = 0;
+        for (auto& g : gs) {
+            const int N = g.first.first;
+            const uint32_t nv = g.first.second;
+            const uint32_t cnt = (uint32_t)g.second.size();
+            const uint32_t rpw = 64 / (uint32_t)N;
+            const uint32_t lpad = nv * (uint32_t)N;
+            uint32_t W = full ? (uint32_t)ctx->ref_len : std::min<uint32_t>((uint32_t)ctx->ref_len, 2 * lpad + 32);
+            if (W == 0) W = 1;
+            const uint32_t maxc = full ? lpad + (uint32_t)ctx->ref_len + 4 : MAXC;
+            uint32_t grid = std::min<uint32_t>((cnt + rpw - 1) / rpw, full ? 256u : 4096u);
+            while (grid > 1 && align_ring_bytes(N, nv, W, grid) > (size_t(3) << 30)) grid /= 2;
+            // one ring per launch; launches on one stream run in order, so the buffer can be shared but must be
+            // large enough for the biggest group: size it before the first launch
+            ZSW_HIP(ctx, ringbuf.ensure(align_ring_bytes(N, nv, W, grid)));
+            BatchDev b = st.b;
+            b.items = ws[WS_ITEMS].as<uint32_t>() + pos;
+            b.n_items = cnt;
+            hipError_t he = align_pass2(N, nv, b, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len, ctx->d_sc.as<ScoringDev>(), S,
+                                        so.score, so.ref_end, so.status, W, maxc, ringbuf.as<uint8_t>(), grid,
+                                        cigbuf.as<uint32_t>(), pool, full ? 1 : 0, ws[WS_CIGSTART].as<uint64_t>(),
+                                        ws[WS_CIGRAW].as<uint32_t>(), ws[WS_ALN].as<zsw_alignment>(),
+                                        ws[WS_FBLIST].as<uint32_t>(), ws[WS_FBCOUNT].as<uint32_t>(), invert, stream);
+            if (he != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align pass 2", he);
+            if (full) pool += (uint64_t)cnt * maxc;
+            pos += cnt;
+        }
+        return ZSW_OK;
+    };
+    // DevBuf::ensure frees and reallocates: size the shared ring for the largest group up front
+    {
+        size_t ring_need = 0;
+        for (auto& g : groups) {
+            const int N = g.first.first;
+            const uint32_t nv = g.first.second, rpw = 64 / (uint32_t)N, lpad = nv * (uint32_t)N;
+            uint32_t W = std::min<uint32_t>((uint32_t)ctx->ref_len, 2 * lpad + 32);
+            if (W == 0) W = 1;
+            uint32_t grid = std::min<uint32_t>(((uint32_t)g.second.size() + rpw - 1) / rpw, 4096u);
+            while (grid > 1 && align_ring_bytes(N, nv, W, grid) > (size_t(3) << 30)) grid /= 2;
+            ring_need = std::max(ring_need, align_ring_bytes(N, nv, W, grid));
+        }
+        ZSW_HIP(ctx, ws[WS_RING].ensure(ring_need + 64));
+    }
+    ctx->timer.begin(stream);
+    zsw_error ze = run_groups(groups, false, ws[WS_RING], ws[WS_CIG]);
+    ctx->timer.end(stream);
+    if (ze != ZSW_OK) return ze;
+    // reads whose traceback left the retained window (or overflowed their ciglet slots): rerun keeping every row
+    uint32_t n_fb = 0;
+    ZSW_HIP(ctx, hipMemcpyAsync(&n_fb, ws[WS_FBCOUNT].p, 4, hipMemcpyDeviceToHost, stream));
+    ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    if (n_fb) {
+        std::vector<uint32_t> fb(n_fb);
+        ZSW_HIP(ctx, hipMemcpy(fb.data(), ws[WS_FBLIST].p, (size_t)n_fb * 4, hipMemcpyDeviceToHost));
+        Groups g2;
+        for (uint32_t id : fb) g2[key_of(id)].push_back(id);
+        ZSW_HIP(ctx, hipMemsetAsync(ws[WS_FBCOUNT].p, 0, 4, stream));
+        size_t ring_need = 0;
+        for (auto& g : g2) {
+            const int N = g.first.first;
+            const uint32_t nv = g.first.second, rpw = 64 / (uint32_t)N;
+            uint32_t W = std::max<uint32_t>(1, (uint32_t)ctx->ref_len);
+            uint32_t grid = std::min<uint32_t>(((uint32_t)g.second.size() + rpw - 1) / rpw, 256u);
+            while (grid > 1 && align_ring_bytes(N, nv, W, grid) > (size_t(3) << 30)) grid /= 2;
+            ring_need = std::max(ring_need, align_ring_bytes(N, nv, W, grid));
+        }
+        ZSW_HIP(ctx, ws[WS_RING2].ensure(ring_need + 64));
+        ze = run_groups(g2, true, ws[WS_RING2], ws[WS_CIG2]);
+        if (ze != ZSW_OK) return ze;
+        uint32_t again = 0;
+        ZSW_HIP(ctx, hipMemcpyAsync(&again, ws[WS_FBCOUNT].p, 4, hipMemcpyDeviceToHost, stream));
+        ZSW_HIP(ctx, hipStreamSynchronize(stream));
+        if (again) return fail(ctx, ZSW_ERR_HIP, "alignment traceback did not complete with the full window");
+    }
+
+    // pack the ciglets: count, scan, write (reversal and SeqSrc::Query inversion happen in the writer)
+    const uint32_t nblocks = (n + 1023) / 1024;
+    ZSW_HIP(ctx, ws[WS_BSUMS].ensure((size_t)nblocks * 8 + 8));
+    ZSW_HIP(ctx, ws[WS_TOTAL].ensure(8));
+    e = align_finalize(ws[WS_ALN].as<zsw_alignment>(), so.status, n, ws[WS_BSUMS].as<uint64_t>(), ws[WS_TOTAL].as<uint64_t>(),
+                       ws[WS_CIGSTART].as<uint64_t>(), ws[WS_CIGRAW].as<uint32_t>(), invert, nullptr, nullptr, 0, true, stream);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align count", e);
+    uint64_t total = 0;
+    ZSW_HIP(ctx, hipMemcpyAsync(&total, ws[WS_TOTAL].p, 8, hipMemcpyDeviceToHost, stream));
+    ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    *out_n_ciglets = total;
+    if (total > ciglet_cap) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "ciglet capacity too small; required size returned");
+    uint32_t* d_inc = out_inc;
+    uint8_t* d_op = out_op;
+    if (host) {
+        ZSW_HIP(ctx, ws[WS_OINC].ensure(total * 4 + 4));
+        ZSW_HIP(ctx, ws[WS_OOP].ensure(total + 4));
+        d_inc = ws[WS_OINC].as<uint32_t>();
+        d_op = ws[WS_OOP].as<uint8_t>();
+    }
+    e = align_finalize(ws[WS_ALN].as<zsw_alignment>(), so.status, n, ws[WS_BSUMS].as<uint64_t>(), ws[WS_TOTAL].as<uint64_t>(),
+                       ws[WS_CIGSTART].as<uint64_t>(), ws[WS_CIGRAW].as<uint32_t>(), invert, d_inc, d_op, ciglet_cap, false, stream);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align write", e);
+    const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    ZSW_HIP(ctx, hipMemcpyAsync(out_aln, ws[WS_ALN].p, (size_t)n * sizeof(zsw_alignment), kind, stream));
+    ZSW_HIP(ctx, hipMemcpyAsync(out_status, so.status, n, kind, stream));
+    if (out_tier) ZSW_HIP(ctx, hipMemcpyAsync(out_tier, so.tier, n, kind, stream));
+    if (host && total) {
+        ZSW_HIP(ctx, hipMemcpyAsync(out_inc, d_inc, total * 4, kind, stream));
+        ZSW_HIP(ctx, hipMemcpyAsync(out_op, d_op, total, kind, stream));
+    }
+    ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    return ZSW_OK;
 }
 
 }  // namespace
 
 extern "C" {
+
+zsw_error zsw_align_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, int invert,
+                          zsw_alignment* out_aln, uint8_t* out_status, uint32_t* out_inc, uint8_t* out_op,
+                          uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!valid_lanes(lanes)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "lanes must be a power of two in 2..64");
+    ResultRule rule;
+    if (!rule_direct(int_type, ctx->bias, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "bad int_type");
+    return run_align(ctx, reads, rule, lanes, lanes, lanes, invert, out_aln, out_status, nullptr, out_inc, out_op, ciglet_cap,
+                     out_n_ciglets, stream);
+}
+
+zsw_error zsw_align_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, int invert,
+                               zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
+                               uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (preset_bits != 128 && preset_bits != 256 && preset_bits != 512) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "preset_bits");
+    ResultRule rule;
+    if (!rule_cascade(from_width, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "from_width");
+    return run_align(ctx, reads, rule, preset_bits / 8, preset_bits / 16, preset_bits / 32, invert, out_aln, out_status, out_tier,
+                     out_inc, out_op, ciglet_cap, out_n_ciglets, stream);
+}
 
 int zsw_device_count(void) {
     int n = 0;

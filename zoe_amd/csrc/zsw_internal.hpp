@@ -72,7 +72,7 @@ struct KernelTimer;
 hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
                         const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
                         int32_t* d_scratch, size_t scratch_slots, uint32_t scratch_len, hipStream_t stream,
-                        KernelTimer* timer, bool want_ends);
+                        KernelTimer* timer, int mode /* 0 score, 1 +ref_end, 2 +both ends */);
 bool score_config_for(uint32_t max_len, int* G, int* C);
 
 }  // namespace zsw

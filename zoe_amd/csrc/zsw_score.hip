@@ -238,7 +238,12 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
     constexpr int RW = 2 * (64 / G);          // reads per wave
     const int src = (lane >> 1) * G;          // first lane of the group that holds read `lane`
     const bool hi = lane & 1;
-#define ZSW_PICK(A, B) (hi ? __shfl((int)(B), src, 64) : __shfl((int)(A), src, 64))
+    // both shuffles run with every lane active (a lane that sits out a divergent branch cannot be a shuffle source)
+    auto pick = [&](int va, int vb) {
+        const int xa = __shfl(va, src, 64), xb = __shfl(vb, src, 64);
+        return hi ? xb : xa;
+    };
+#define ZSW_PICK(A, B) pick((int)(A), (int)(B))
     const uint32_t o_valid = (uint32_t)ZSW_PICK(validA, validB);
     const uint32_t o_id = (uint32_t)ZSW_PICK(idA, idB);
     const uint32_t o_len = (uint32_t)ZSW_PICK(lenA, lenB);
@@ -425,13 +430,12 @@ static void build_tables(const ScoringDev& s, bool fast, ScoreArgs* a) {
 hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
                         const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
                         int32_t* d_scratch, size_t scratch_slots, uint32_t scratch_len, hipStream_t stream,
-                        KernelTimer* timer, bool want_ends) {
+                        KernelTimer* timer, int mode) {
     hipError_t e = hipMemsetAsync(out.fb_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     int G = 0, C = 0;
     const bool table_ok = h_sc.S <= 7 || fast_ok(h_sc);
     const bool cfg_ok = score_config_for(max_len, &G, &C);
-    const int mode = want_ends ? 2 : 0;
     const uint32_t exact_grid = (uint32_t)(scratch_slots / 64);
     if (table_ok && cfg_ok) {
         ScoreArgs a;
