@@ -17,6 +17,8 @@
 // recomputes rows 0..=r_end and keeps only the last W rows of flags in a per-wave ring in HBM/L2, then one
 // lane walks the traceback. A read whose walk leaves the window (or overflows the ciglet scratch) is
 // re-run with a window covering every row.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -45,6 +47,7 @@ struct AlignArgs {
     uint32_t* fb_list;
     uint32_t* fb_count;
     int invert;
+    int debug;  // ZSW_ALIGN_DEBUG experiments: 1 = skip traceback, 2 = skip ring stores
 };
 
 __device__ __forceinline__ uint32_t read_len(const BatchDev& b, uint32_t id, uint64_t* off) {
@@ -56,6 +59,88 @@ __device__ __forceinline__ uint32_t read_len(const BatchDev& b, uint32_t id, uin
     return b.fixed_len;
 }
 
+
+// BackTrackable::to_alignment (backtrack.rs:290-342) with AlignmentStates::add_ciglet merging (state.rs:142-152),
+// run by one lane per read. `cell(r, c)` returns the flag byte of DP cell (r, c) from the retained window.
+template <typename CellFn>
+__device__ __forceinline__ void traceback_emit(const AlignArgs& a, uint32_t id, uint32_t item, uint32_t len, int rend, int cend,
+                                               int32_t best, CellFn cell) {
+    const uint64_t slot0 = a.pool_base + (uint64_t)(a.by_item ? item : id) * a.maxc;
+    uint32_t* cig = a.cig + slot0;
+    uint32_t ncig = 0, cur_op = 0, cur_inc = 0;
+    bool overflow = cend == 0x7fffffff;
+    auto push = [&](uint32_t inc, uint32_t op) {
+        if (inc == 0) return;
+        if (cur_inc && cur_op == op) {
+            cur_inc += inc;
+            return;
+        }
+        if (cur_inc) {
+            if (ncig < a.maxc) cig[ncig] = (cur_inc << 8) | cur_op;
+            else overflow = true;
+            ++ncig;
+        }
+        cur_op = op;
+        cur_inc = inc;
+    };
+    const int r_end1 = rend + 1, c_end1 = cend + 1;
+    int r = r_end1, c = c_end1;
+    uint32_t n_nons = 0;  // ciglets that are not soft clips (for the inverted count)
+    if (!overflow) {
+        push(len - (uint32_t)c, 'S');
+        uint32_t f = cell(rend, cend);
+        uint32_t op = 0;
+        while (!(f & BT_STOP) && r > 0 && c > 0) {
+            if (op == 'D' && (f & BT_UP_EXT)) {
+                r -= 1;
+            } else if (op == 'I' && (f & BT_LEFT_EXT)) {
+                c -= 1;
+            } else if (f & BT_UP) {
+                op = 'D';
+                r -= 1;
+            } else if (f & BT_LEFT) {
+                op = 'I';
+                c -= 1;
+            } else {
+                op = 'M';
+                r -= 1;
+                c -= 1;
+            }
+            if (!(cur_inc && cur_op == op)) ++n_nons;
+            push(1, op);
+            if (r > 0 && c > 0) {
+                if (r - 1 + (int)a.W <= rend) {  // the walk left the retained window
+                    overflow = true;
+                    break;
+                }
+                f = cell(r - 1, c - 1);
+            }
+        }
+        push((uint32_t)c, 'S');
+        push(1, 0);  // flush the pending ciglet (the sentinel op 0 itself is never stored)
+    }
+    if (overflow || ncig > a.maxc) {
+        const uint32_t k = atomicAdd(a.fb_count, 1u);
+        a.fb_list[k] = id;
+    } else {
+        zsw_alignment out;
+        out.score = (uint32_t)best;
+        out.ref_start = (uint32_t)r;
+        out.ref_end = (uint32_t)r_end1;
+        out.query_start = (uint32_t)c;
+        out.query_end = (uint32_t)c_end1;
+        out.ref_len = a.ref_len;
+        out.query_len = len;
+        // forward count; inverted: clips re-derived from ref_range (output.rs:399-414)
+        out.n_ciglets = a.invert ? n_nons + (r > 0 ? 1u : 0u) + (a.ref_len > (uint32_t)r_end1 ? 1u : 0u) : ncig;
+        out.ciglet_offset = 0;  // filled by write_ciglets_kernel
+        a.aln[id] = out;
+        a.cig_start[id] = (uint64_t)(uintptr_t)cig;
+        a.cig_raw[id] = ncig;
+    }
+}
+
+// Generic form: any nv, DP rows in LDS.
 template <int N>
 __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -179,85 +264,183 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
         __threadfence_block();  // this wave's ring stores are visible to its own traceback loads
 
         if (active && li == 0) {
-            // BackTrackable::to_alignment (backtrack.rs:290-342) with AlignmentStates::add_ciglet merging (state.rs:142-152)
-            const uint64_t slot0 = a.pool_base + (uint64_t)(a.by_item ? item : id) * a.maxc;
-            uint32_t* cig = a.cig + slot0;
-            uint32_t ncig = 0, cur_op = 0, cur_inc = 0;
-            bool overflow = cend == 0x7fffffff;
-            auto push = [&](uint32_t inc, uint32_t op) {
-                if (inc == 0) return;
-                if (cur_inc && cur_op == op) {
-                    cur_inc += inc;
-                    return;
-                }
-                if (cur_inc) {
-                    if (ncig < a.maxc) cig[ncig] = (cur_inc << 8) | cur_op;
-                    else overflow = true;
-                    ++ncig;
-                }
-                cur_op = op;
-                cur_inc = inc;
+            auto cell = [&](int rr, int cc) -> uint32_t {
+                // agent-scope load: served by L2, never by a stale L1 line of an earlier item's window
+                return __hip_atomic_load(ring + (size_t)(rr % (int)a.W) * row_bytes + (size_t)(cc % (int)nv) * N + (size_t)(cc / (int)nv),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
-            const int r_end1 = rend + 1, c_end1 = cend + 1;
-            int r = r_end1, c = c_end1;
-            uint32_t n_nons = 0;  // ciglets that are not soft clips (for the inverted count)
-            if (!overflow) {
-                push(len - (uint32_t)c, 'S');
-                auto cell = [&](int rr, int cc) -> uint32_t {
-                    // agent-scope load: served by L2, never by a stale L1 line of an earlier item's window
-                    return __hip_atomic_load(ring + (size_t)(rr % (int)a.W) * row_bytes + (size_t)(cc % (int)nv) * N + (size_t)(cc / (int)nv),
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                };
-                uint32_t f = cell(rend, cend);
-                uint32_t op = 0;
-                while (!(f & BT_STOP) && r > 0 && c > 0) {
-                    if (op == 'D' && (f & BT_UP_EXT)) {
-                        r -= 1;
-                    } else if (op == 'I' && (f & BT_LEFT_EXT)) {
-                        c -= 1;
-                    } else if (f & BT_UP) {
-                        op = 'D';
-                        r -= 1;
-                    } else if (f & BT_LEFT) {
-                        op = 'I';
-                        c -= 1;
-                    } else {
-                        op = 'M';
-                        r -= 1;
-                        c -= 1;
-                    }
-                    if (!(cur_inc && cur_op == op)) ++n_nons;
-                    push(1, op);
-                    if (r > 0 && c > 0) {
-                        if (r - 1 + (int)a.W <= rend) {  // the walk left the retained window
-                            overflow = true;
-                            break;
+            traceback_emit(a, id, item, len, rend, cend, best, cell);
+        }
+    }
+}
+
+// Register-resident form for nv <= NVMAX: H and E rows live in VGPRs (the unrolled vector loop exits at the
+// runtime nv, which is wave-uniform), the profile stays in LDS packed four scores per dword, and each row's
+// flags are assembled four per dword and stored as one run of dwords per lane.
+// Ring row layout: [lane in group][nvq*4 bytes]  (nvq = ceil(nv/4)); cell (r, c) is byte (c % nv) of lane c / nv.
+template <int N, int NVMAX>
+__global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ uint8_t lut[256];
+    __shared__ int32_t wsh[MAX_S * MAX_S];
+    constexpr int RPW = 64 / N;
+    constexpr int NVQMAX = NVMAX / 4;
+    const int lane = threadIdx.x;
+    const int li = lane % N, grp = lane / N;
+    const int nv = (int)a.nv;
+    const int nvq = (nv + 3) / 4;
+    const int S = a.sc->S;
+    const int go = a.sc->gap_open, ge = a.sc->gap_extend;
+    uint32_t* prof4 = reinterpret_cast<uint32_t*>(smem);  // [S][nvq][64]
+    for (int i = lane; i < 256; i += 64) lut[i] = a.sc->index_map[i];
+    for (int i = lane; i < S * S; i += 64) wsh[i] = a.sc->w[i];
+    __syncthreads();
+    const unsigned long long gmask = (N == 64) ? ~0ull : (((1ull << N) - 1ull) << (grp * N));
+    const size_t row_bytes = (size_t)N * nvq * 4;
+    uint8_t* ring = a.ring + ((size_t)blockIdx.x * RPW + grp) * (size_t)a.W * row_bytes;
+    const int W = (int)a.W;
+
+    for (uint32_t first = blockIdx.x * RPW; first < a.b.n_items; first += gridDim.x * RPW) {
+        const uint32_t item = first + grp;
+        const bool valid = item < a.b.n_items;
+        const uint32_t id = valid ? (a.b.items ? a.b.items[item] : item) : 0;
+        uint64_t off = 0;
+        const uint32_t len = valid ? read_len(a.b, id, &off) : 0;
+        const bool active = valid && a.status[id] == ZSW_STATUS_SOME && len > 0 && (int)((len + N - 1) / N) == nv;
+        const int rend = active ? (int)a.ref_end[id] - 1 : -1;
+        const int32_t best = active ? (int32_t)a.score[id] : 0;
+
+        // StripedProfile::new_unchecked (profile.rs:270-306), four consecutive vectors per dword
+        for (int vq = 0; vq < nvq; ++vq) {
+            int k[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = 4 * vq + j;
+                const uint32_t q = (uint32_t)v + (uint32_t)li * (uint32_t)nv;
+                k[j] = (active && v < nv && q < len) ? (int)lut[a.b.bases[off + q]] : -1;
+            }
+            for (int ri = 0; ri < S; ++ri) {
+                uint32_t p = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p |= (uint32_t)(uint8_t)(k[j] < 0 ? 0 : wsh[ri * S + k[j]]) << (8 * j);
+                prof4[((size_t)ri * nvq + vq) * 64 + lane] = p;
+            }
+        }
+        int32_t H[NVMAX], E[NVMAX];
+#pragma unroll
+        for (int v = 0; v < NVMAX; ++v) {
+            H[v] = 0;
+            E[v] = 0;
+        }
+        int32_t Hlast = 0;  // previous row's H of vector nv-1
+        int cend = 0x7fffffff;
+        int rmax = rend;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) rmax = max(rmax, __shfl_xor(rmax, d, 64));
+
+        for (int r = 0; r <= rmax; ++r) {
+            const bool act = r <= rend;
+            const int ri = lut[a.ref[r]];
+            const uint32_t* prow = prof4 + (size_t)ri * nvq * 64 + lane;
+            // main pass (striped.rs:481-526)
+            int32_t F = 0;
+            int32_t Hd = __shfl_up(Hlast, 1, N);
+            if (li == 0) Hd = 0;
+            uint32_t flg[NVMAX];  // one flag byte per vector, packed four per dword only when the row is stored
+#pragma unroll
+            for (int vq = 0; vq < NVQMAX; ++vq) {
+                if (vq < nvq) {
+                    const uint32_t p4 = prow[vq * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int v = 4 * vq + j;
+                        flg[v] = 0;
+                        if (v < nv) {
+                            const int32_t s = __builtin_amdgcn_sbfe((int)p4, 8 * j, 8);
+                            const int32_t Eo = E[v];
+                            const int32_t hold = H[v];
+                            int32_t h = max(Hd + s, 0);
+                            h = max(h, max(Eo, F));
+                            uint32_t fl = (Eo == h ? (uint32_t)BT_UP : 0u) | (F == h ? (uint32_t)BT_LEFT : 0u);
+                            const bool stopped = h == 0;
+                            H[v] = h;
+                            if (v == nv - 1) Hlast = h;
+                            const int32_t hg = max(h - go, 0);
+                            const int32_t En = max(max(Eo - ge, 0), hg);
+                            F = max(max(F - ge, 0), hg);
+                            E[v] = En;
+                            fl |= (En > hg ? (uint32_t)BT_UP_EXT : 0u) | (F > hg ? (uint32_t)BT_LEFT_EXT : 0u);
+                            if (stopped) fl = BT_STOP;
+                            flg[v] = fl;
+                            Hd = hold;
                         }
-                        f = cell(r - 1, c - 1);
                     }
                 }
-                push((uint32_t)c, 'S');
-                push(1, 0);  // flush the pending ciglet (the sentinel op 0 itself is never stored)
             }
-            if (overflow || ncig > a.maxc) {
-                const uint32_t k = atomicAdd(a.fb_count, 1u);
-                a.fb_list[k] = id;
-            } else {
-                zsw_alignment out;
-                out.score = (uint32_t)best;
-                out.ref_start = (uint32_t)r;
-                out.ref_end = (uint32_t)r_end1;
-                out.query_start = (uint32_t)c;
-                out.query_end = (uint32_t)c_end1;
-                out.ref_len = a.ref_len;
-                out.query_len = len;
-                // forward count; inverted: clips re-derived from ref_range (output.rs:399-414)
-                out.n_ciglets = a.invert ? n_nons + (r > 0 ? 1u : 0u) + (a.ref_len > (uint32_t)r_end1 ? 1u : 0u) : ncig;
-                out.ciglet_offset = 0;  // filled by write_ciglets_kernel
-                a.aln[id] = out;
-                a.cig_start[id] = (uint64_t)(uintptr_t)cig;
-                a.cig_raw[id] = ncig;
+            // lazy-F pass (striped.rs:528-553)
+            bool done = !act;
+            for (int it = 0; it < N; ++it) {
+                F = __shfl_up(F, 1, N);
+                if (li == 0) F = 0;
+                bool stop_all = false;
+#pragma unroll
+                for (int v = 0; v < NVMAX; ++v) {
+                    if (!stop_all && v < nv) {
+                        const int32_t h0 = H[v];
+                        const bool cond = !done && F > max(h0 - go, 0);
+                        const unsigned long long bal = __ballot(cond);
+                        if ((bal & gmask) == 0) done = true;
+                        if (bal == 0) {
+                            stop_all = true;  // every read of the wave has left its lazy-F loop
+                        } else {
+                            const int32_t h = max(h0, F);
+                            uint32_t fl = flg[v];
+                            if (F == h) fl = (fl & BT_UP_EXT) | BT_LEFT;  // simd_correct_and_set_left
+                            const int32_t hg = max(h - go, 0);
+                            const int32_t Fn = max(F - ge, 0);
+                            if (Fn > hg) fl |= BT_LEFT_EXT;
+                            if (h == 0) fl = BT_STOP;
+                            if (!done) {
+                                H[v] = h;
+                                flg[v] = fl;
+                                F = Fn;
+                                if (v == nv - 1) Hlast = h;
+                            }
+                        }
+                    }
+                }
+                if (stop_all) break;
             }
+            // keep the last W rows of flags of every read still running
+            if (act && r + W > rend && !(a.debug & 2)) {
+                uint32_t* dst = reinterpret_cast<uint32_t*>(ring + (size_t)(r % W) * row_bytes) + (size_t)li * nvq;
+#pragma unroll
+                for (int vq = 0; vq < NVQMAX; ++vq)
+                    if (vq < nvq) dst[vq] = flg[4 * vq] | (flg[4 * vq + 1] << 8) | (flg[4 * vq + 2] << 16) | (flg[4 * vq + 3] << 24);
+            }
+            // c_end at the read's last row: first query position whose H equals the best score (striped.rs:571-583)
+            if (__ballot(r == rend) != 0) {
+                if (r == rend) {
+#pragma unroll
+                    for (int v = NVMAX - 1; v >= 0; --v) {
+                        if (v < nv) {
+                            const uint32_t ci = (uint32_t)v + (uint32_t)li * (uint32_t)nv;
+                            if (ci < len && H[v] == best) cend = (int)ci;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < N; d <<= 1) cend = min(cend, __shfl_xor(cend, d, N));
+        __threadfence_block();  // this wave's ring stores are visible to its own traceback loads
+
+        if (active && li == 0 && !(a.debug & 1)) {
+            auto cell = [&](int rr, int cc) -> uint32_t {
+                return __hip_atomic_load(ring + (size_t)(rr % W) * row_bytes + (size_t)(cc / nv) * (size_t)nvq * 4 + (size_t)(cc % nv),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            traceback_emit(a, id, item, len, rend, cend, best, cell);
         }
     }
 }
@@ -363,18 +546,27 @@ __global__ void write_ciglets_kernel(zsw_alignment* aln, const uint8_t* status, 
 }
 
 static size_t align_lds_bytes(uint32_t nv, int S) { return (size_t)nv * 64 * (4 + 4 + (size_t)S + 1); }
+static size_t align_lds_bytes_reg(uint32_t nv, int S) { return (size_t)S * ((nv + 3) / 4) * 64 * 4; }
+
+template <typename K>
+static hipError_t launch_with_lds(K kernel, bool* attr_set, const AlignArgs& a, uint32_t grid, size_t lds, hipStream_t stream) {
+    if (!*attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 6 * 1024);
+        if (e != hipSuccess) return e;
+        *attr_set = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
 
 template <int N>
-static hipError_t launch_align_n(const AlignArgs& a, uint32_t grid, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&align_kernel<N>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((align_kernel<N>), dim3(grid), dim3(64), lds, stream, a);
-    return hipGetLastError();
+static hipError_t launch_align_n(const AlignArgs& a, int S, uint32_t grid, hipStream_t stream) {
+    static bool set_lds = false, set8 = false, set16 = false, set32 = false;
+    if (a.nv <= 8) return launch_with_lds(&align_kernel_reg<N, 8>, &set8, a, grid, align_lds_bytes_reg(a.nv, S), stream);
+    if (a.nv <= 16) return launch_with_lds(&align_kernel_reg<N, 16>, &set16, a, grid, align_lds_bytes_reg(a.nv, S), stream);
+    if (a.nv <= 32) return launch_with_lds(&align_kernel_reg<N, 32>, &set32, a, grid, align_lds_bytes_reg(a.nv, S), stream);
+    return launch_with_lds(&align_kernel<N>, &set_lds, a, grid, align_lds_bytes(a.nv, S), stream);
 }
 
 }  // namespace zsw
@@ -384,14 +576,13 @@ using namespace zsw;
 namespace {
 
 hipError_t run_group(int N, AlignArgs a, int S, uint32_t grid, hipStream_t stream) {
-    const size_t lds = align_lds_bytes(a.nv, S);
     switch (N) {
-        case 2: return launch_align_n<2>(a, grid, lds, stream);
-        case 4: return launch_align_n<4>(a, grid, lds, stream);
-        case 8: return launch_align_n<8>(a, grid, lds, stream);
-        case 16: return launch_align_n<16>(a, grid, lds, stream);
-        case 32: return launch_align_n<32>(a, grid, lds, stream);
-        case 64: return launch_align_n<64>(a, grid, lds, stream);
+        case 2: return launch_align_n<2>(a, S, grid, stream);
+        case 4: return launch_align_n<4>(a, S, grid, stream);
+        case 8: return launch_align_n<8>(a, S, grid, stream);
+        case 16: return launch_align_n<16>(a, S, grid, stream);
+        case 32: return launch_align_n<32>(a, S, grid, stream);
+        case 64: return launch_align_n<64>(a, S, grid, stream);
     }
     return hipErrorInvalidValue;
 }
@@ -428,11 +619,15 @@ hipError_t align_pass2(int N, uint32_t nv, const BatchDev& b, const uint8_t* d_r
     a.fb_list = d_fb_list;
     a.fb_count = d_fb_count;
     a.invert = invert;
+    a.debug = getenv("ZSW_ALIGN_DEBUG") ? atoi(getenv("ZSW_ALIGN_DEBUG")) : 0;
     return run_group(N, a, S, grid, stream);
 }
 
-size_t align_ring_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid) { return (size_t)grid * (64 / N) * (size_t)W * nv * N; }
-size_t align_lds_need(uint32_t nv, int S) { return align_lds_bytes(nv, S); }
+size_t align_ring_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid) {
+    const size_t row = (size_t)N * (nv <= 32 ? ((nv + 3) / 4) * 4 : nv);
+    return (size_t)grid * (64 / N) * (size_t)W * row;
+}
+size_t align_lds_need(uint32_t nv, int S) { return nv <= 32 ? align_lds_bytes_reg(nv, S) : align_lds_bytes(nv, S); }
 
 hipError_t align_finalize(zsw_alignment* d_aln, const uint8_t* d_status, uint32_t n, uint64_t* d_block_sums,
                           uint64_t* d_total, const uint64_t* d_cig_start, const uint32_t* d_cig_raw, int invert,

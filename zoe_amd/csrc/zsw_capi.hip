@@ -315,6 +315,8 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
 
     // group the reads that have an alignment by the <N, nv> of the instantiation that answered
     std::vector<uint8_t> h_status(n), h_tier(n);
+    std::vector<uint32_t> h_rend(n);
+    ZSW_HIP(ctx, hipMemcpyAsync(h_rend.data(), so.ref_end, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
     ZSW_HIP(ctx, hipMemcpyAsync(h_status.data(), so.status, n, hipMemcpyDeviceToHost, stream));
     ZSW_HIP(ctx, hipMemcpyAsync(h_tier.data(), so.tier, n, hipMemcpyDeviceToHost, stream));
     std::vector<uint64_t> h_off;
@@ -337,6 +339,21 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     Groups groups;
     for (uint32_t i = 0; i < n; ++i)
         if (h_status[i] == ZSW_STATUS_SOME) groups[key_of(i)].push_back(i);
+    // Reads that share a wavefront walk the reference rows together; ordering each group by its reference end row
+    // makes their high-scoring rows (where Zoe's lazy-F loop runs long) coincide and bounds the rows a wave computes
+    // by nearly the same r_end for all of its reads. Counting sort, O(n + R).
+    {
+        std::vector<uint32_t> cnt, tmp;
+        for (auto& g : groups) {
+            std::vector<uint32_t>& ids = g.second;
+            cnt.assign(ctx->ref_len + 2, 0);
+            for (uint32_t id : ids) ++cnt[std::min<size_t>(h_rend[id], ctx->ref_len) + 1];
+            for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+            tmp.resize(ids.size());
+            for (uint32_t id : ids) tmp[cnt[std::min<size_t>(h_rend[id], ctx->ref_len)]++] = id;
+            ids.swap(tmp);
+        }
+    }
     const int S = ctx->h_sc.S;
     for (auto& g : groups)
         if (align_lds_need(g.first.second, S) + 4352 + 64 > 160 * 1024)
@@ -371,7 +388,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
             const uint32_t cnt = (uint32_t)g.second.size();
             const uint32_t rpw = 64 / (uint32_t)N;
             const uint32_t lpad = nv * (uint32_t)N;
-            uint32_t W = full ? (uint32_t)ctx->ref_len : std::min<uint32_t>((uint32_t)ctx->ref_len, 2 * lpad + 32);
+            uint32_t W = full ? (uint32_t)ctx->ref_len : std::min<uint32_t>((uint32_t)ctx->ref_len, lpad + std::max<uint32_t>(32, lpad / 4));
             if (W == 0) W = 1;
             const uint32_t maxc = full ? lpad + (uint32_t)ctx->ref_len + 4 : MAXC;
             uint32_t grid = std::min<uint32_t>((cnt + rpw - 1) / rpw, full ? 256u : 4096u);
@@ -399,7 +416,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
         for (auto& g : groups) {
             const int N = g.first.first;
             const uint32_t nv = g.first.second, rpw = 64 / (uint32_t)N, lpad = nv * (uint32_t)N;
-            uint32_t W = std::min<uint32_t>((uint32_t)ctx->ref_len, 2 * lpad + 32);
+            uint32_t W = std::min<uint32_t>((uint32_t)ctx->ref_len, lpad + std::max<uint32_t>(32, lpad / 4));
             if (W == 0) W = 1;
             uint32_t grid = std::min<uint32_t>(((uint32_t)g.second.size() + rpw - 1) / rpw, 4096u);
             while (grid > 1 && align_ring_bytes(N, nv, W, grid) > (size_t(3) << 30)) grid /= 2;
