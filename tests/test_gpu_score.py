@@ -217,3 +217,30 @@ def test_protein_alphabet_exact_kernel(za, oracle):
     for i, rd in enumerate(reads):
         o_st, o_s = oracle.score("i16", 16, sc, rd, ref)
         assert (int(got.status[i]), int(got.score[i]) if o_st == S_ else 0) == (o_st, o_s if o_st == S_ else 0), i
+
+
+def test_config5_mixed_lengths_30kb_reference(za, oracle, dna):
+    """BASELINE.json configs[4] shape at test size: reads 75-400 bp vs a 30 kb reference, bucketed launches
+    (one per strip configuration) + a few reads longer than every configuration (exact kernel)."""
+    import torch
+
+    from zoe_amd import synth
+
+    ref = synth.reference_host(30000)
+    n = 1200
+    hb, hoff = synth.reads_ragged_host(ref, 0, n, 75, 400)
+    extra = [ref[1000:3600], ref[20000:22500] + b"ACGT" * 10]  # 2,600 and 2,540 bp: beyond the 2,432-column strips
+    bases = np.concatenate([hb, np.frombuffer(b"".join(extra), dtype=np.uint8)])
+    off = np.concatenate([hoff, hoff[-1] + np.cumsum([len(e) for e in extra])]).astype(np.int64)
+    sc = osc(oracle, dna, -10, -1)
+    ws, wst, wt = oracle.batch_score_w256(8, sc, bases, ref, offsets=off.astype(np.uint64), threads=16)
+    rb = za.ReadBatch(torch.from_numpy(bases).cuda(), n + 2, offsets=torch.from_numpy(off).cuda(), min_len=75)
+    got = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1).sw_score_from_i8(ref)
+    assert np.array_equal(got.status.cpu().numpy(), wst)
+    assert np.array_equal(got.score.cpu().numpy().view(np.uint32), ws)
+    assert np.array_equal(got.tier.cpu().numpy(), wt)
+    assert int(got.score[n]) == 5200 and int(got.tier[n]) == 16
+    ends = za.StripedProfileBatch(rb, dna, -10, -1, "i16", 16).sw_score_ends(za.SeqSrc.Reference(ref))
+    for i in list(range(0, n, 97)) + [n, n + 1]:
+        st, (s, re_, qe) = oracle.score_ends("i16", 16, sc, bases[off[i] : off[i + 1]], ref)
+        assert (int(ends.status[i]), int(ends.score[i]), int(ends.ref_end[i]), int(ends.query_end[i])) == (st, s, re_, qe), i

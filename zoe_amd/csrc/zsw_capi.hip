@@ -45,7 +45,7 @@ struct zsw_context {
     bool scoring_set = false, reference_set = false;
     ScoringDev h_sc{};
     int bias = 0;
-    DevBuf d_sc, d_ref, d_fb_list, d_fb_count, d_scratch, d_maxlen;
+    DevBuf d_sc, d_ref, d_fb_list, d_fb_count, d_scratch, d_maxlen, d_bucket_items, d_bucket_counts;
     size_t ref_len = 0;
     uint32_t scratch_len = 0;
     // staging for host-memory batches
@@ -225,12 +225,24 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     // workspace
     ZSW_HIP(ctx, ctx->d_fb_list.ensure((size_t)n * 4 + 4));
     ZSW_HIP(ctx, ctx->d_fb_count.ensure(4));
+    if (reads->offsets) ZSW_HIP(ctx, ctx->d_bucket_items.ensure((size_t)n * 4 + 4));
+    ZSW_HIP(ctx, ctx->d_bucket_counts.ensure(64 * 4));
     uint32_t need = std::max<uint32_t>(512, (st->max_len + 127) / 128 * 128);
     if (need > ctx->scratch_len || !ctx->d_scratch.p) {
         ZSW_HIP(ctx, ctx->d_scratch.ensure(2 * EXACT_SLOTS * (size_t)need * sizeof(int32_t)));
         ctx->scratch_len = need;
     }
     return ZSW_OK;
+}
+
+ScoreWorkspace score_ws(zsw_context* ctx) {
+    ScoreWorkspace w;
+    w.scratch = ctx->d_scratch.as<int32_t>();
+    w.slots = EXACT_SLOTS;
+    w.scratch_len = ctx->scratch_len;
+    w.bucket_items = ctx->d_bucket_items.as<uint32_t>();
+    w.bucket_counts = ctx->d_bucket_counts.as<uint32_t>();
+    return w;
 }
 
 zsw_error unstage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, const Staged& st, uint32_t* out_score,
@@ -263,8 +275,7 @@ zsw_error run_score(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     out.fb_list = ctx->d_fb_list.as<uint32_t>();
     out.fb_count = ctx->d_fb_count.as<uint32_t>();
     hipError_t e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(),
-                                (uint32_t)ctx->ref_len, rule, out, ctx->d_scratch.as<int32_t>(), EXACT_SLOTS,
-                                ctx->scratch_len, stream, &ctx->timer, want_ends ? 2 : 0);
+                                (uint32_t)ctx->ref_len, rule, out, score_ws(ctx), stream, &ctx->timer, want_ends ? 2 : 0);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "score launch", e);
     return unstage(ctx, reads, stream, st, out_score, out_status, out_tier, out_rend, out_qend);
 }
@@ -309,8 +320,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     so.fb_list = ctx->d_fb_list.as<uint32_t>();
     so.fb_count = ctx->d_fb_count.as<uint32_t>();
     hipError_t e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(),
-                                (uint32_t)ctx->ref_len, rule, so, ctx->d_scratch.as<int32_t>(), EXACT_SLOTS, ctx->scratch_len,
-                                stream, nullptr, 1);
+                                (uint32_t)ctx->ref_len, rule, so, score_ws(ctx), stream, nullptr, 1);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align pass 1", e);
 
     // group the reads that have an alignment by the <N, nv> of the instantiation that answered
@@ -563,7 +573,7 @@ zsw_error zsw_create(int device_id, zsw_context** out) {
 void zsw_destroy(zsw_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen,
+    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts,
                       &ctx->s_bases, &ctx->s_offsets, &ctx->s_score, &ctx->s_status, &ctx->s_tier, &ctx->s_rend, &ctx->s_qend};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->a_ws) b.release();

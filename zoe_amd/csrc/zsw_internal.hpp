@@ -69,10 +69,18 @@ struct ScoreOut {
 struct KernelTimer;
 
 // launchers (zsw_score.hip)
+struct ScoreWorkspace {
+    int32_t* scratch;       // exact32 kernel rows: 2 * slots * scratch_len ints
+    size_t slots;
+    uint32_t scratch_len;
+    uint32_t* bucket_items;  // n_reads entries (ragged batches: reads grouped by strip configuration)
+    uint32_t* bucket_counts; // 32 counters + 32 cursors
+};
+
 hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
                         const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
-                        int32_t* d_scratch, size_t scratch_slots, uint32_t scratch_len, hipStream_t stream,
-                        KernelTimer* timer, int mode /* 0 score, 1 +ref_end, 2 +both ends */);
+                        const ScoreWorkspace& ws, hipStream_t stream, KernelTimer* timer,
+                        int mode /* 0 score, 1 +ref_end, 2 +both ends */);
 bool score_config_for(uint32_t max_len, int* G, int* C);
 
 }  // namespace zsw

@@ -20,6 +20,8 @@
 //
 // 10 VALU instructions per packed cell pair; no MFMA (this is not a contraction); HBM traffic is the
 // read bytes in and 4-5 bytes out per read. The binding roof is integer VALU issue.
+#include <algorithm>
+
 #include "zsw_internal.hpp"
 #include "zsw_timer.hpp"
 
@@ -427,59 +429,140 @@ static void build_tables(const ScoringDev& s, bool fast, ScoreArgs* a) {
     a->bias2 = pk((uint32_t)bias, (uint32_t)bias);
 }
 
+static hipError_t launch_table_cfg(const ScoreArgs& a, int G, int C, bool fast, int mode, hipStream_t stream) {
+    switch (G * 100 + C) {
+#define ZSW_CASE(GV, CV) \
+    case GV * 100 + CV: return launch_cfg<GV, CV>(a, fast, mode, stream);
+        ZSW_CASE(4, 19)
+        ZSW_CASE(4, 25)
+        ZSW_CASE(4, 32)
+        ZSW_CASE(4, 38)
+        ZSW_CASE(8, 19)
+        ZSW_CASE(8, 25)
+        ZSW_CASE(8, 32)
+        ZSW_CASE(8, 38)
+        ZSW_CASE(16, 25)
+        ZSW_CASE(16, 32)
+        ZSW_CASE(16, 38)
+        ZSW_CASE(64, 19)
+        ZSW_CASE(64, 38)
+#undef ZSW_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- ragged batches: group the reads by the smallest strip configuration that holds them -------------------
+// class k < NCLS: kCfgs[kBucketCfg[k]]; class NCLS: longer than every table configuration (exact 32-bit kernel)
+static const int kBucketCfg[] = {0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12};  // (8,19) duplicates the capacity of (4,38)
+constexpr int NCLS = 12;
+
+struct BucketCaps {
+    uint32_t cap[NCLS];
+};
+
+__device__ __forceinline__ int bucket_of(const BucketCaps& caps, uint32_t len) {
+    int k = 0;
+    while (k < NCLS && len > caps.cap[k]) ++k;
+    return k;
+}
+
+__global__ void bucket_count_kernel(const uint64_t* offsets, uint32_t n, BucketCaps caps, uint32_t* counts) {
+    __shared__ uint32_t sh[NCLS + 1];
+    if (threadIdx.x <= NCLS) sh[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        atomicAdd(&sh[bucket_of(caps, (uint32_t)(offsets[i + 1] - offsets[i]))], 1u);
+    __syncthreads();
+    if (threadIdx.x <= NCLS && sh[threadIdx.x]) atomicAdd(&counts[threadIdx.x], sh[threadIdx.x]);
+}
+
+__global__ void bucket_scatter_kernel(const uint64_t* offsets, uint32_t n, BucketCaps caps, uint32_t* cursors, uint32_t* items) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int k = bucket_of(caps, (uint32_t)(offsets[i + 1] - offsets[i]));
+        items[atomicAdd(&cursors[k], 1u)] = i;
+    }
+}
+
 hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
                         const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
-                        int32_t* d_scratch, size_t scratch_slots, uint32_t scratch_len, hipStream_t stream,
-                        KernelTimer* timer, int mode) {
+                        const ScoreWorkspace& ws, hipStream_t stream, KernelTimer* timer, int mode) {
     hipError_t e = hipMemsetAsync(out.fb_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     int G = 0, C = 0;
     const bool table_ok = h_sc.S <= 7 || fast_ok(h_sc);
-    const bool cfg_ok = score_config_for(max_len, &G, &C);
-    const uint32_t exact_grid = (uint32_t)(scratch_slots / 64);
-    if (table_ok && cfg_ok) {
-        ScoreArgs a;
-        a.b = b;
-        a.ref = d_ref;
-        a.ref_len = ref_len;
-        a.sc = d_sc;
-        a.rule = rule;
-        a.out = out;
-        const bool fast = fast_ok(h_sc);
-        build_tables(h_sc, fast, &a);
+    const uint32_t exact_grid = (uint32_t)(ws.slots / 64);
+    ScoreArgs a;
+    a.b = b;
+    a.ref = d_ref;
+    a.ref_len = ref_len;
+    a.sc = d_sc;
+    a.rule = rule;
+    a.out = out;
+    const bool fast = fast_ok(h_sc);
+    if (table_ok) build_tables(h_sc, fast, &a);
+    auto exact_all = [&](const BatchDev& bb) {
+        hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, bb, (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, d_ref, ref_len, d_sc, rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len);
+        return hipGetLastError();
+    };
+    if (!table_ok) {  // alphabet outside the table kernels: exact kernel over the whole batch
         if (timer) timer->begin(stream);
-        switch (G * 100 + C) {
-#define ZSW_CASE(GV, CV) \
-    case GV * 100 + CV: e = launch_cfg<GV, CV>(a, fast, mode, stream); break;
-            ZSW_CASE(4, 19)
-            ZSW_CASE(4, 25)
-            ZSW_CASE(4, 32)
-            ZSW_CASE(4, 38)
-            ZSW_CASE(8, 19)
-            ZSW_CASE(8, 25)
-            ZSW_CASE(8, 32)
-            ZSW_CASE(8, 38)
-            ZSW_CASE(16, 25)
-            ZSW_CASE(16, 32)
-            ZSW_CASE(16, 38)
-            ZSW_CASE(64, 19)
-            ZSW_CASE(64, 38)
-#undef ZSW_CASE
-            default: e = hipErrorInvalidValue;
+        e = exact_all(b);
+        if (timer) timer->end(stream);
+        return e;
+    }
+    if (b.offsets && !b.items && b.n_items > 0) {
+        // ragged: one launch per occupied length class (device-side histogram + scatter, counts read back once)
+        BucketCaps caps;
+        for (int k = 0; k < NCLS; ++k) caps.cap[k] = (uint32_t)(kCfgs[kBucketCfg[k]].G * kCfgs[kBucketCfg[k]].C);
+        e = hipMemsetAsync(ws.bucket_counts, 0, 64 * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        const uint32_t hgrid = std::min<uint32_t>(1024, (b.n_items + 255) / 256);
+        hipLaunchKernelGGL(bucket_count_kernel, dim3(hgrid), dim3(256), 0, stream, b.offsets, b.n_items, caps, ws.bucket_counts);
+        uint32_t counts[NCLS + 1];
+        e = hipMemcpyAsync(counts, ws.bucket_counts, sizeof(counts), hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        uint32_t starts[NCLS + 1], run = 0;
+        for (int k = 0; k <= NCLS; ++k) {
+            starts[k] = run;
+            run += counts[k];
+        }
+        e = hipMemcpyAsync(ws.bucket_counts + 32, starts, sizeof(starts), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bucket_scatter_kernel, dim3(hgrid), dim3(256), 0, stream, b.offsets, b.n_items, caps,
+                           ws.bucket_counts + 32, ws.bucket_items);
+        if (timer) timer->begin(stream);
+        for (int k = 0; k <= NCLS; ++k) {
+            if (!counts[k]) continue;
+            BatchDev bk = b;
+            bk.items = ws.bucket_items + starts[k];
+            bk.n_items = counts[k];
+            if (k == NCLS) {
+                e = exact_all(bk);
+            } else {
+                a.b = bk;
+                e = launch_table_cfg(a, kCfgs[kBucketCfg[k]].G, kCfgs[kBucketCfg[k]].C, fast, mode, stream);
+            }
+            if (e != hipSuccess) return e;
         }
         if (timer) timer->end(stream);
+    } else {
+        if (!score_config_for(max_len, &G, &C)) {  // longer than every strip configuration
+            if (timer) timer->begin(stream);
+            e = exact_all(b);
+            if (timer) timer->end(stream);
+            return e;
+        }
+        if (timer) timer->begin(stream);
+        e = launch_table_cfg(a, G, C, fast, mode, stream);
+        if (timer) timer->end(stream);
         if (e != hipSuccess) return e;
-        // reads that saturated i16: exact pass over the device-side worklist (usually empty)
-        hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, b, out.fb_list, out.fb_count, d_ref,
-                           ref_len, d_sc, rule, out, d_scratch, (uint32_t)scratch_slots, scratch_len);
-        return hipGetLastError();
     }
-    // alphabet or length outside the table kernels: exact kernel over the whole batch
-    if (timer) timer->begin(stream);
-    hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, b, (const uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, d_ref, ref_len, d_sc, rule, out, d_scratch, (uint32_t)scratch_slots,
-                       scratch_len);
-    if (timer) timer->end(stream);
+    // reads that saturated i16: exact pass over the device-side worklist (usually empty)
+    hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, b, out.fb_list, out.fb_count, d_ref, ref_len, d_sc,
+                       rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len);
     return hipGetLastError();
 }
 
