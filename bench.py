@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 # v_pk_{add,sub,max}_i16 and v_perm_b32 issue at one wave64 instruction per 4 cycles per SIMD on gfx950
 # (profiles/r01_valu_issue_rates_ubench.txt: half the v_fma_f32/v_add_u32 rate), i.e. 16 lanes/clk/SIMD.
 VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9  # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (32-bit lane-ops/s)
-PACKED_OPS_PER_CELL_PAIR = 10       # zsw_score.hip inner loop: 10 VALU per two cells
+PACKED_OPS_PER_CELL_PAIR = 7.5      # zsw_score.hip score_kernel_v2 inner loop: 7.5 packed VALU per two cells
 
 
 def parse():
@@ -213,10 +213,10 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "kernel": "zsw::score_kernel<4,38,true,0>",
+                "kernel": "zsw::score_kernel_v2<4,38,0>",
                 "kernel_ms": per_launch_s * 1e3,
                 "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
-                "note": "HBM is not the binding roof: ~10 VALU ops per 2 cells, see valu_roofline",
+                "note": "HBM is not the binding roof: 7.5 packed VALU ops per 2 cells at 4 cycles each, see valu_roofline",
             },
             "valu_roofline": {
                 "bound": "valu",

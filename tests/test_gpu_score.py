@@ -244,3 +244,65 @@ def test_config5_mixed_lengths_30kb_reference(za, oracle, dna):
     for i in list(range(0, n, 97)) + [n, n + 1]:
         st, (s, re_, qe) = oracle.score_ends("i16", 16, sc, bases[off[i] : off[i + 1]], ref)
         assert (int(ends.status[i]), int(ends.score[i]), int(ends.ref_end[i]), int(ends.query_end[i])) == (st, s, re_, qe), i
+
+
+def test_v1_and_v2_score_kernels_agree(za, oracle, dna, monkeypatch):
+    """score_kernel_v2 (row-drifted domain + v_pk_maximum3_f16) and score_kernel (saturating packed i16) are both
+    bit-exact: same 10k-read batch through each, scores / ends compared with the oracle."""
+    import torch
+
+    from zoe_amd import synth
+
+    ref = synth.reference_host(2000)
+    host = synth.reads_host(ref, 50_000, 6000, 150)
+    sc = osc(oracle, dna, -10, -1)
+    ws, wst, wt = oracle.batch_score_w256(8, sc, host, ref, fixed_len=150, threads=16)
+    rb = za.ReadBatch.from_fixed(torch.from_numpy(host.reshape(-1)).cuda(), 150)
+    for force_v1 in (False, True):
+        if force_v1:
+            monkeypatch.setenv("ZSW_SCORE_V1", "1")
+        else:
+            monkeypatch.delenv("ZSW_SCORE_V1", raising=False)
+        got = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1).sw_score_from_i8(ref)
+        assert np.array_equal(got.score.cpu().numpy().view(np.uint32), ws), force_v1
+        assert np.array_equal(got.status.cpu().numpy(), wst) and np.array_equal(got.tier.cpu().numpy(), wt)
+        ends = za.StripedProfileBatch(rb, dna, -10, -1, "i16", 16).sw_score_ends(za.SeqSrc.Reference(ref))
+        for i in range(0, 6000, 211):
+            st, (s, re_, qe) = oracle.score_ends("i16", 16, sc, host[i], ref)
+            assert (int(ends.status[i]), int(ends.score[i]), int(ends.ref_end[i]), int(ends.query_end[i])) == (st, s, re_, qe), (force_v1, i)
+
+
+@pytest.mark.parametrize("scheme", [(2, -5, -10, -1), (100, -90, -120, -100), (3, -4, -6, 0), (127, -128, -127, -127), (5, -3, -1, -1), (1, -1, 0, 0)])
+def test_v2_ranges_gap_extremes_and_limit(za, oracle, scheme):
+    """Large gap_extend shortens v2's re-base period; gap_extend = 0 disables the drift; match = 127 is outside v2's
+    signed-byte table (v1 answers); high scores cross v2's representable limit and go to the exact kernel."""
+    ma, mi, go, ge = scheme
+    m = za.WeightMatrix.new_dna_matrix(ma, mi, b"N")
+    sc = osc(oracle, m, go, ge)
+    rng = np.random.default_rng(abs(hash(scheme)) % (2**32))
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    ref = bytes(rng.choice(alpha[:4], 2600))
+    reads = []
+    for _ in range(150):
+        L = int(rng.integers(20, 400))
+        s0 = int(rng.integers(0, 2600 - L))
+        r = bytearray(ref[s0 : s0 + L])
+        for _ in range(int(rng.integers(0, 6))):
+            k = int(rng.integers(0, len(r)))
+            t = rng.random()
+            if t < 0.5:
+                r[k] = int(rng.choice(alpha))
+            elif t < 0.75 and len(r) > 1:
+                del r[k]
+            else:
+                r.insert(k, int(rng.choice(alpha[:4])))
+        reads.append(bytes(r))
+    reads += [bytes(rng.choice(alpha[:4], int(rng.integers(20, 300)))) for _ in range(30)]
+    got = za.LocalProfilesBatch.new_with_w256(reads, m, go, ge).sw_score_from_i8(ref)
+    ends = za.StripedProfileBatch(reads, m, go, ge, "i32", 8).sw_score_ends(za.SeqSrc.Reference(ref))
+    for i, rd in enumerate(reads):
+        o_st, o_s, o_tier = oracle.cascade_score(8, 256, sc, rd, ref)
+        assert (int(got.status[i]), int(got.score[i]) if o_st == S_ else 0, int(got.tier[i])) == (o_st, o_s if o_st == S_ else 0, o_tier), i
+        if i % 7 == 0:
+            st, (s, re_, qe) = oracle.score_ends("i32", 8, sc, rd, ref)
+            assert (int(ends.status[i]), int(ends.score[i]), int(ends.ref_end[i]), int(ends.query_end[i])) == (st, s, re_, qe), i
