@@ -55,7 +55,12 @@ struct ScoreArgs {
 
 // Waves per SIMD the register allocator must leave room for: H, E and the selectors take 3*C VGPRs
 // (4*C with the MODE 2 snapshot row).
-constexpr int min_waves(int C, int MODE) { return (MODE == 2 ? 4 * C : 3 * C) + 14 <= 80 ? 6 : (MODE == 2 ? 4 * C : 3 * C) + 14 <= 128 ? 4 : (MODE == 2 ? 4 * C : 3 * C) + 14 <= 168 ? 3 : 2; }
+constexpr int min_waves(int C, int MODE) {
+    // state registers (H, E, selectors [+ snapshot row]) plus ~40 temporaries; measured on the 150 bp configuration:
+    // 3 vs 4 waves/SIMD is time-neutral for this VALU-issue-bound loop, register spills are not free
+    const int need = (MODE == 2 ? 4 * C : 3 * C) + (MODE == 2 ? 44 : 36);
+    return need <= 80 ? 6 : need <= 96 ? 5 : need <= 128 ? 4 : need <= 168 ? 3 : 2;
+}
 
 // MODE 0: score; 1: score + ref_end; 2: score + ref_end + query_end
 template <int G, int C, bool FAST, int MODE>
