@@ -120,6 +120,13 @@ zsw_error zsw_score_ends_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int
                                uint32_t* out_score, uint32_t* out_ref_end, uint32_t* out_query_end,
                                uint8_t* out_status, void* stream);
 
+/* sw_simd_score_ranges (src/alignment/sw/striped.rs:355-388): the truncated two-pass form — forward score+ends, then
+ * sw_simd_score_ends_reverse on reference[..ref_end] with the profile of reverse(read[..query_end]). Ranges are
+ * 0-based half-open. */
+zsw_error zsw_score_ranges_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes,
+                                 uint32_t* out_score, uint32_t* out_ref_start, uint32_t* out_ref_end,
+                                 uint32_t* out_query_start, uint32_t* out_query_end, uint8_t* out_status, void* stream);
+
 /* ---- full alignment ------------------------------------------------------------------------ */
 /* out_aln[i] / out_status[i] = StripedProfile::<int_type,lanes,S>::new(read_i).sw_align(SeqSrc::Reference(reference))
  * (invert != 0: SeqSrc::Query(reference), i.e. the result passed through Alignment::invert).

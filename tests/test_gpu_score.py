@@ -306,3 +306,45 @@ def test_v2_ranges_gap_extremes_and_limit(za, oracle, scheme):
         if i % 7 == 0:
             st, (s, re_, qe) = oracle.score_ends("i32", 8, sc, rd, ref)
             assert (int(ends.status[i]), int(ends.score[i]), int(ends.ref_end[i]), int(ends.query_end[i])) == (st, s, re_, qe), i
+
+
+def test_score_ranges_vs_oracle(za, oracle, dna):
+    """sw_simd_score_ranges (striped.rs:355-388): the reference's vectors (sw/test.rs:198-262, profile_set.rs:293-310)
+    and synthetic batches against the oracle's two-pass restatement."""
+    import torch
+
+    from zoe_amd import synth
+
+    sc = osc(oracle, dna, -10, -1)
+
+    # sw/test.rs:198-241 and :244-262 (u8x8) — ranges equal the scalar alignment's ranges
+    for q, r in ((b"GGGGGGGCCCCCAAAA", b"TTTTTTCCTTTTTTTTCCCCCTTTTT"), (b"CCCCA", b"TAAAA")):
+        a = oracle.scalar_align(sc, q, r)
+        got = za.StripedProfileBatch([q], dna.to_biased_matrix(), -10, -1, "u8", 8).sw_score_ranges(za.SeqSrc.Reference(r))
+        assert (int(got.status[0]), int(got.score[0])) == (S_, a.score)
+        assert (int(got.ref_start[0]), int(got.ref_end[0])) == a.ref_range
+        assert (int(got.query_start[0]), int(got.query_end[0])) == a.query_range
+    # profile_set.rs:293-310
+    m = za.WeightMatrix.new_dna_matrix(4, -2, b"N")
+    got = za.StripedProfileBatch([b"CGTTCGCCATAAAGGGGG"], m, -3, -1, "i8", 32).sw_score_ranges(za.SeqSrc.Reference(b"ATGCATCGATCGATCGATCGATCGATCGATGC"))
+    assert (int(got.score[0]), int(got.query_start[0]), int(got.query_end[0]), int(got.ref_start[0]), int(got.ref_end[0])) == (26, 0, 15, 14, 31)
+    # synthetic fixed-length batch
+    ref = synth.reference_host(1500)
+    host = synth.reads_host(ref, 777, 500, 120)
+    host[9] = np.frombuffer(b"N" * 120, dtype=np.uint8)
+    rb = za.ReadBatch.from_fixed(torch.from_numpy(host.reshape(-1)).cuda(), 120)
+    got = za.StripedProfileBatch(rb, dna, -10, -1, "i16", 16).sw_score_ranges(za.SeqSrc.Reference(ref))
+    for i in range(500):
+        st, s, rr, qr = oracle.score_ranges("i16", 16, sc, host[i], ref)
+        assert int(got.status[i]) == st, i
+        if st == S_:
+            assert (int(got.score[i]), (int(got.ref_start[i]), int(got.ref_end[i])), (int(got.query_start[i]), int(got.query_end[i]))) == (s, rr, qr), i
+    # ragged + low-complexity + i8 overflow statuses + SeqSrc::Query swap
+    hb, hoff = synth.reads_ragged_host(ref, 5, 200, 20, 300)
+    reads = [hb[hoff[i] : hoff[i + 1]].tobytes() for i in range(200)] + [b"ACACACACACAC", b"TTTTTTTTTT", b"GGGGGCCCCC"]
+    got = za.StripedProfileBatch(reads, dna, -10, -1, "i8", 32).sw_score_ranges(za.SeqSrc.Query(ref))
+    for i, rd in enumerate(reads):
+        st, s, rr, qr = oracle.score_ranges("i8", 32, sc, rd, ref)
+        assert int(got.status[i]) == st, i
+        if st == S_:
+            assert (int(got.score[i]), (int(got.query_start[i]), int(got.query_end[i])), (int(got.ref_start[i]), int(got.ref_end[i]))) == (s, rr, qr), i

@@ -309,6 +309,8 @@ class ScoreBatch:
     tier: Optional["object"] = None
     ref_end: Optional["object"] = None
     query_end: Optional["object"] = None
+    ref_start: Optional["object"] = None
+    query_start: Optional["object"] = None
 
     def maybe_aligned(self, i: int):
         st = int(self.status[i])
@@ -445,6 +447,24 @@ class StripedProfileBatch(_ProfileBatchBase):
         if seq.is_query:
             rend, qend = qend, rend
         return ScoreBatch(score[:n], status[:n], ref_end=rend[:n], query_end=qend[:n])
+
+    def sw_score_ranges(self, seq: SeqSrc) -> ScoreBatch:
+        """profile.rs:529-533 → sw_simd_score_ranges (striped.rs:355-388): ScoreAndRanges per read (0-based half-open);
+        SeqSrc::Query swaps the reference and query ranges."""
+        torch = _torch()
+        self._prep(seq.seq)
+        n = self.reads.n_reads
+        dev = self.reads.bases.device
+        o = [torch.empty(max(n, 1), dtype=torch.int32, device=dev) for _ in range(5)]
+        status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        b = self.reads.c_batch()
+        self.ctx.check(self.ctx.lib.zsw_score_ranges_batch(self.ctx.h, C.byref(b), _lib.INT_TYPES[self.T], self.N, o[0].data_ptr(),
+                                                           o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(),
+                                                           status.data_ptr(), self.ctx.stream()))
+        rs, re_, qs, qe = (x[:n] for x in o[1:])
+        if seq.is_query:
+            rs, re_, qs, qe = qs, qe, rs, re_
+        return ScoreBatch(o[0][:n], status[:n], ref_start=rs, ref_end=re_, query_start=qs, query_end=qe)
 
     def sw_align(self, seq: SeqSrc) -> AlignmentBatch:
         """profile.rs:515-519 → sw_simd_align (striped.rs:449-598)"""

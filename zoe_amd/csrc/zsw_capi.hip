@@ -52,6 +52,8 @@ struct zsw_context {
     DevBuf s_bases, s_offsets, s_score, s_status, s_tier, s_rend, s_qend;
     // alignment workspace (zsw_align.hip)
     DevBuf a_ws[20];
+    // score_ranges workspace
+    DevBuf r_ws[20];
     KernelTimer timer;
     std::string err;
 };
@@ -280,6 +282,107 @@ zsw_error run_score(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     return unstage(ctx, reads, stream, st, out_score, out_status, out_tier, out_rend, out_qend);
 }
 
+
+__global__ void ranges_prep_kernel(uint32_t n, const uint8_t* fstatus, const uint32_t* fqend, uint32_t* qe_masked) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) qe_masked[i] = fstatus[i] == ZSW_STATUS_SOME ? fqend[i] : 0;
+}
+
+// and_then / map chain of sw_simd_score_ranges (striped.rs:361-387)
+__global__ void ranges_combine_kernel(uint32_t n, const uint32_t* fscore, const uint8_t* fstatus, const uint32_t* frend,
+                                      const uint32_t* fqend, const uint32_t* rscore, const uint8_t* rstatus,
+                                      const uint32_t* rrstart, const uint32_t* rqstart, uint32_t* out_score,
+                                      uint32_t* out_rs, uint32_t* out_re, uint32_t* out_qs, uint32_t* out_qe,
+                                      uint8_t* out_status, uint32_t* mismatch) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t st = fstatus[i];
+    if (st == ZSW_STATUS_SOME && rstatus[i] != ZSW_STATUS_SOME) st = rstatus[i] == ZSW_STATUS_EMPTY ? (uint8_t)ZSW_STATUS_UNMAPPED : rstatus[i];
+    const bool some = st == ZSW_STATUS_SOME;
+    if (some && rscore[i] != fscore[i]) atomicAdd(mismatch, 1u);  // debug_assert_eq!(score, score2) (striped.rs:379)
+    out_status[i] = st;
+    out_score[i] = some ? fscore[i] : 0;
+    out_rs[i] = some ? rrstart[i] : 0;
+    out_re[i] = some ? frend[i] : 0;
+    out_qs[i] = some ? rqstart[i] : 0;
+    out_qe[i] = some ? fqend[i] : 0;
+}
+
+enum { RW_FSCORE = 0, RW_FSTATUS, RW_FREND, RW_FQEND, RW_RSCORE, RW_RSTATUS, RW_RRS, RW_RQS, RW_QEM, RW_GTAB, RW_MIS, RW_O0, RW_O1,
+       RW_O2, RW_O3, RW_O4, RW_O5 };
+
+zsw_error run_ranges(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, uint32_t* out_score, uint32_t* out_rs,
+                     uint32_t* out_re, uint32_t* out_qs, uint32_t* out_qe, uint8_t* out_status, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!reads || !out_score || !out_rs || !out_re || !out_qs || !out_qe || !out_status)
+        return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
+    const uint32_t n = (uint32_t)reads->n_reads;
+    Staged st;
+    {
+        uint32_t dummy_score = 0;
+        uint8_t dummy_status = 0;
+        zsw_error ze = stage(ctx, reads, stream, false, false, &dummy_score, &dummy_status, nullptr, nullptr, nullptr, &st);
+        if (ze != ZSW_OK) return ze;
+    }
+    if (n == 0) return ZSW_OK;
+    const bool host = reads->mem == ZSW_MEM_HOST;
+    DevBuf* ws = ctx->r_ws;
+    for (int k : {RW_FSCORE, RW_FREND, RW_FQEND, RW_RSCORE, RW_RRS, RW_RQS, RW_QEM}) ZSW_HIP(ctx, ws[k].ensure((size_t)n * 4 + 4));
+    for (int k : {RW_FSTATUS, RW_RSTATUS}) ZSW_HIP(ctx, ws[k].ensure((size_t)n + 4));
+    ZSW_HIP(ctx, ws[RW_GTAB].ensure(ctx->ref_len * 8 + 8));
+    ZSW_HIP(ctx, ws[RW_MIS].ensure(4));
+    ScoreOut fo;
+    fo.score = ws[RW_FSCORE].as<uint32_t>();
+    fo.status = ws[RW_FSTATUS].as<uint8_t>();
+    fo.tier = nullptr;
+    fo.ref_end = ws[RW_FREND].as<uint32_t>();
+    fo.query_end = ws[RW_FQEND].as<uint32_t>();
+    fo.fb_list = ctx->d_fb_list.as<uint32_t>();
+    fo.fb_count = ctx->d_fb_count.as<uint32_t>();
+    ctx->timer.begin(stream);
+    hipError_t e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(),
+                                (uint32_t)ctx->ref_len, rule, fo, score_ws(ctx), stream, nullptr, 2);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "ranges forward pass", e);
+    const uint32_t g256 = (n + 255) / 256;
+    hipLaunchKernelGGL(ranges_prep_kernel, dim3(g256), dim3(256), 0, stream, n, fo.status, fo.query_end, ws[RW_QEM].as<uint32_t>());
+    ScoreOut ro;
+    ro.score = ws[RW_RSCORE].as<uint32_t>();
+    ro.status = ws[RW_RSTATUS].as<uint8_t>();
+    ro.tier = nullptr;
+    ro.ref_end = ws[RW_RRS].as<uint32_t>();
+    ro.query_end = ws[RW_RQS].as<uint32_t>();
+    ro.fb_list = ctx->d_fb_list.as<uint32_t>();
+    ro.fb_count = ctx->d_fb_count.as<uint32_t>();
+    e = launch_score_rev(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len,
+                         rule, ro, score_ws(ctx), fo.ref_end, ws[RW_QEM].as<uint32_t>(), ws[RW_GTAB].as<uint2>(), stream);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "ranges reverse pass", e);
+    ctx->timer.end(stream);
+    uint32_t *d0 = out_score, *d1 = out_rs, *d2 = out_re, *d3 = out_qs, *d4 = out_qe;
+    uint8_t* d5 = out_status;
+    if (host) {
+        for (int k : {RW_O0, RW_O1, RW_O2, RW_O3, RW_O4}) ZSW_HIP(ctx, ws[k].ensure((size_t)n * 4 + 4));
+        ZSW_HIP(ctx, ws[RW_O5].ensure((size_t)n + 4));
+        d0 = ws[RW_O0].as<uint32_t>();
+        d1 = ws[RW_O1].as<uint32_t>();
+        d2 = ws[RW_O2].as<uint32_t>();
+        d3 = ws[RW_O3].as<uint32_t>();
+        d4 = ws[RW_O4].as<uint32_t>();
+        d5 = ws[RW_O5].as<uint8_t>();
+    }
+    ZSW_HIP(ctx, hipMemsetAsync(ws[RW_MIS].p, 0, 4, stream));
+    hipLaunchKernelGGL(ranges_combine_kernel, dim3(g256), dim3(256), 0, stream, n, fo.score, fo.status, fo.ref_end, fo.query_end,
+                       ro.score, ro.status, ro.ref_end, ro.query_end, d0, d1, d2, d3, d4, d5, ws[RW_MIS].as<uint32_t>());
+    ZSW_HIP(ctx, hipGetLastError());
+    if (host) {
+        uint32_t* outs[5] = {out_score, out_rs, out_re, out_qs, out_qe};
+        uint32_t* devs[5] = {d0, d1, d2, d3, d4};
+        for (int k = 0; k < 5; ++k) ZSW_HIP(ctx, hipMemcpyAsync(outs[k], devs[k], (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        ZSW_HIP(ctx, hipMemcpyAsync(out_status, d5, n, hipMemcpyDeviceToHost, stream));
+        ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    }
+    return ZSW_OK;
+}
 
 enum { WS_SCORE = 0, WS_STATUS, WS_TIER, WS_REND, WS_ITEMS, WS_RING, WS_CIG, WS_ALN, WS_CIGSTART, WS_CIGRAW, WS_BSUMS, WS_TOTAL,
        WS_FBLIST, WS_FBCOUNT, WS_OINC, WS_OOP, WS_CIG2, WS_RING2 };
@@ -577,6 +680,7 @@ void zsw_destroy(zsw_context* ctx) {
                       &ctx->s_bases, &ctx->s_offsets, &ctx->s_score, &ctx->s_status, &ctx->s_tier, &ctx->s_rend, &ctx->s_qend};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->a_ws) b.release();
+    for (DevBuf& b : ctx->r_ws) b.release();
     ctx->timer.destroy();
     delete ctx;
 }
@@ -652,6 +756,16 @@ zsw_error zsw_score_ends_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int
     ResultRule rule;
     if (!rule_direct(int_type, ctx->bias, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "bad int_type");
     return run_score(ctx, reads, rule, true, out_score, out_status, nullptr, out_ref_end, out_query_end, stream);
+}
+
+zsw_error zsw_score_ranges_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes,
+                                 uint32_t* out_score, uint32_t* out_ref_start, uint32_t* out_ref_end,
+                                 uint32_t* out_query_start, uint32_t* out_query_end, uint8_t* out_status, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!valid_lanes(lanes)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "lanes must be a power of two in 2..64");
+    ResultRule rule;
+    if (!rule_direct(int_type, ctx->bias, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "bad int_type");
+    return run_ranges(ctx, reads, rule, out_score, out_ref_start, out_ref_end, out_query_start, out_query_end, out_status, stream);
 }
 
 zsw_error zsw_synth_reads(zsw_context* ctx, uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint8_t* out_device,

@@ -81,6 +81,12 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
                         const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
                         const ScoreWorkspace& ws, hipStream_t stream, KernelTimer* timer,
                         int mode /* 0 score, 1 +ref_end, 2 +both ends */);
+// Reverse pass of sw_simd_score_ranges: per read, SW of reverse(read[..query_end]) against reverse(reference[..ref_end]);
+// out.ref_end / out.query_end receive the inclusive starts. d_gtab: ref_len uint2 entries of scratch.
+hipError_t launch_score_rev(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
+                            const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
+                            const ScoreWorkspace& ws, const uint32_t* d_fwd_ref_end, const uint32_t* d_fwd_query_end,
+                            uint2* d_gtab, hipStream_t stream);
 bool score_config_for(uint32_t max_len, int* G, int* C);
 
 }  // namespace zsw

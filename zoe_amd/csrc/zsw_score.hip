@@ -51,6 +51,10 @@ struct ScoreArgs {
     uint32_t go2, ge2, bias2;
     ResultRule rule;
     ScoreOut out;
+    // reverse pass of sw_simd_score_ranges (REV kernels): per read, the forward ends and the per-row table in HBM
+    const uint32_t* rev_ref_end;
+    const uint32_t* rev_query_end;
+    const uint2* gtab;
 };
 
 // Waves per SIMD the register allocator must leave room for: H, E and the selectors take 3*C VGPRs
@@ -63,7 +67,11 @@ constexpr int min_waves(int C, int MODE) {
 }
 
 // MODE 0: score; 1: score + ref_end; 2: score + ref_end + query_end
-template <int G, int C, bool FAST, int MODE>
+// REV (with MODE 2): the second pass of sw_simd_score_ranges (striped.rs:355-388) — sw_simd_score_ends_reverse on
+// `reference[..ref_end]` with the profile of `reverse(read[..query_end])` (profile.rs:314-350). Every read has its own
+// reference prefix, so a lane carries ONE read (high half idle), takes its row table from HBM/L2 (gtab[ref_end-1-row])
+// and each wave runs only as many steps as its longest prefix needs. Outputs: ref_end/query_end receive the STARTS.
+template <int G, int C, bool FAST, int MODE, bool REV = false>
 __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreArgs a) {
     __shared__ uint2 rp[CH + G];
     __shared__ uint2 swt[9];
@@ -73,8 +81,8 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
     const int tid = threadIdx.x;
     const int g = tid & (G - 1);
     const uint32_t group = blockIdx.x * (BLOCK / G) + tid / G;
-    const uint32_t itemA = 2 * group, itemB = 2 * group + 1;
-    const bool validA = itemA < a.b.n_items, validB = itemB < a.b.n_items;
+    const uint32_t itemA = REV ? group : 2 * group, itemB = 2 * group + 1;
+    const bool validA = itemA < a.b.n_items, validB = !REV && itemB < a.b.n_items;
     const uint32_t idA = validA ? (a.b.items ? a.b.items[itemA] : itemA) : 0;
     const uint32_t idB = validB ? (a.b.items ? a.b.items[itemB] : itemB) : 0;
 
@@ -102,6 +110,12 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
             lenB = a.b.fixed_len;
         }
     }
+    int rev_re = 0;  // REV: this read's reference prefix length (forward ref_end) and query prefix length
+    if (REV) {
+        const uint32_t qe = validA ? a.rev_query_end[idA] : 0;
+        lenA = qe <= lenA ? qe : lenA;
+        rev_re = validA && lenA ? (int)a.rev_ref_end[idA] : 0;
+    }
 
     // per-column selectors: which table bytes v_perm picks for read A (low half) and read B (high half)
     uint32_t sel[C];
@@ -109,7 +123,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
     for (int c = 0; c < C; ++c) {
         const uint32_t q = (uint32_t)(g * C + c);
         uint32_t kA = PAD_K, kB = PAD_K;
-        if (q < lenA) kA = lut[a.b.bases[offA + q]];
+        if (q < lenA) kA = lut[a.b.bases[REV ? offA + (lenA - 1 - q) : offA + q]];
         if (q < lenB) kB = lut[a.b.bases[offB + q]];
         uint32_t sA, sB;
         if (FAST) {  // table = W[r][0..3] as i16; residue >= 4 (an all-zero matrix column) and padding -> 0
@@ -140,66 +154,88 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
     const int R = (int)a.ref_len;
     const int T = R + G - 1;
 
-    for (int base = 0; base < T; base += CH) {
-        __syncthreads();
-        for (int j = tid; j < CH + G - 1; j += BLOCK) {
-            const int row = base - (G - 1) + j;
-            int idx = NEUTRAL;
-            if (row >= 0 && row < R) idx = lut[a.ref[row]];
-            rp[j] = swt[idx];
+    // one DP row of this lane's strip; `w` = the row's table entry, `row` = its index (for the end tracking)
+    auto step = [&](const uint2 w, const int row) {
+        uint32_t Fin = (uint32_t)__shfl_up((int)Fout, 1, G);
+        uint32_t Hin = (uint32_t)__shfl_up((int)Hlast, 1, G);
+        if (g == 0) {
+            Fin = MIN2;
+            Hin = MIN2;
         }
-        __syncthreads();
-        const int tend = (T < base + CH) ? T : base + CH;
-        const int joff = (G - 1 - g) - base;
-        uint2 w = rp[base + joff];
+        // hd = H(r-1,c-1) + W(r,c) is formed one column ahead, so the previous row's H[c] is dead
+        // before this row's H[c] is written (same register, no copy in the loop).
+        uint32_t hd = pk_adds(Hin_prev, __builtin_amdgcn_perm(w.y, w.x, sel[0]));
+        if (!FAST) hd = pk_subs(hd, bias2);
+        Hin_prev = Hin;
+        uint32_t F = Fin;
+        uint32_t rmax = MIN2;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            uint32_t hd_next = 0;
+            if (c + 1 < C) {
+                hd_next = pk_adds(H[c], __builtin_amdgcn_perm(w.y, w.x, sel[c + 1 < C ? c + 1 : c]));
+                if (!FAST) hd_next = pk_subs(hd_next, bias2);
+            }
+            if (MODE == 0) best = pk_max(best, hd);  // E, F never exceed an H already folded into best
+            uint32_t h = pk_max(hd, E[c]);
+            h = pk_max(h, F);
+            if (MODE != 0) rmax = pk_max(rmax, h);
+            H[c] = h;
+            const uint32_t hg = pk_subs(h, go2);
+            E[c] = pk_max(pk_subs(E[c], ge2), hg);
+            F = pk_max(pk_subs(F, ge2), hg);
+            hd = hd_next;
+        }
+        Fout = F;
+        Hlast = H[C - 1];
+        if (MODE != 0) {
+            const uint32_t nb = pk_max(best, rmax);
+            const uint32_t ch = nb ^ best;  // a non-zero half = that read's maximum rose in this row
+            best = nb;
+            if (ch & 0xffffu) rA = row;
+            if (ch >> 16) rB = row;
+            if (MODE == 2) {
+                const uint32_t m = ((ch & 0xffffu) ? 0xffffu : 0u) | ((ch >> 16) ? 0xffff0000u : 0u);
+#pragma unroll
+                for (int c = 0; c < C; ++c) snap[MODE == 2 ? c : 0] = (H[c] & m) | (snap[MODE == 2 ? c : 0] & ~m);
+            }
+        }
+    };
+    if (!REV) {
+        for (int base = 0; base < T; base += CH) {
+            __syncthreads();
+            for (int j = tid; j < CH + G - 1; j += BLOCK) {
+                const int row = base - (G - 1) + j;
+                int idx = NEUTRAL;
+                if (row >= 0 && row < R) idx = lut[a.ref[row]];
+                rp[j] = swt[idx];
+            }
+            __syncthreads();
+            const int tend = (T < base + CH) ? T : base + CH;
+            const int joff = (G - 1 - g) - base;
+            uint2 w = rp[base + joff];
 #pragma unroll 1
-        for (int t = base; t < tend; ++t) {
-            const uint2 wn = rp[t + 1 + joff];
-            uint32_t Fin = (uint32_t)__shfl_up((int)Fout, 1, G);
-            uint32_t Hin = (uint32_t)__shfl_up((int)Hlast, 1, G);
-            if (g == 0) {
-                Fin = MIN2;
-                Hin = MIN2;
+            for (int t = base; t < tend; ++t) {
+                const uint2 wn = rp[t + 1 + joff];
+                step(w, t - g);
+                w = wn;
             }
-            // hd = H(r-1,c-1) + W(r,c) is formed one column ahead, so the previous row's H[c] is dead
-            // before this row's H[c] is written (same register, no copy in the loop).
-            uint32_t hd = pk_adds(Hin_prev, __builtin_amdgcn_perm(w.y, w.x, sel[0]));
-            if (!FAST) hd = pk_subs(hd, bias2);
-            Hin_prev = Hin;
-            uint32_t F = Fin;
-            uint32_t rmax = MIN2;
+        }
+    } else {
+        int tw = rev_re;
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                uint32_t hd_next = 0;
-                if (c + 1 < C) {
-                    hd_next = pk_adds(H[c], __builtin_amdgcn_perm(w.y, w.x, sel[c + 1 < C ? c + 1 : c]));
-                    if (!FAST) hd_next = pk_subs(hd_next, bias2);
-                }
-                if (MODE == 0) best = pk_max(best, hd);  // E, F never exceed an H already folded into best
-                uint32_t h = pk_max(hd, E[c]);
-                h = pk_max(h, F);
-                if (MODE != 0) rmax = pk_max(rmax, h);
-                H[c] = h;
-                const uint32_t hg = pk_subs(h, go2);
-                E[c] = pk_max(pk_subs(E[c], ge2), hg);
-                F = pk_max(pk_subs(F, ge2), hg);
-                hd = hd_next;
-            }
-            Fout = F;
-            Hlast = H[C - 1];
-            if (MODE != 0) {
-                const uint32_t nb = pk_max(best, rmax);
-                const uint32_t ch = nb ^ best;  // a non-zero half = that read's maximum rose in this row
-                best = nb;
-                const int row = t - g;
-                if (ch & 0xffffu) rA = row;
-                if (ch >> 16) rB = row;
-                if (MODE == 2) {
-                    const uint32_t m = ((ch & 0xffffu) ? 0xffffu : 0u) | ((ch >> 16) ? 0xffff0000u : 0u);
-#pragma unroll
-                    for (int c = 0; c < C; ++c) snap[MODE == 2 ? c : 0] = (H[c] & m) | (snap[MODE == 2 ? c : 0] & ~m);
-                }
-            }
+        for (int d = 32; d >= 1; d >>= 1) tw = max(tw, __shfl_xor(tw, d, 64));
+        tw = tw ? tw + G - 1 : 0;  // steps of this wave: its longest reference prefix plus the strip skew
+        const uint2 neutral = swt[NEUTRAL];
+        auto row_entry = [&](int row) {
+            const int rr = rev_re - 1 - row;
+            return (row >= 0 && rr >= 0) ? a.gtab[rr] : neutral;
+        };
+        uint2 w = row_entry(-g);
+#pragma unroll 1
+        for (int t = 0; t < tw; ++t) {
+            const uint2 wn = row_entry(t + 1 - g);
+            step(w, t - g);
             w = wn;
         }
     }
@@ -244,9 +280,9 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
 
     // ---- outputs: regroup so that lane l of the wave owns the wave's l-th read (coalesced stores) ----
     const int lane = tid & 63;
-    constexpr int RW = 2 * (64 / G);          // reads per wave
-    const int src = (lane >> 1) * G;          // first lane of the group that holds read `lane`
-    const bool hi = lane & 1;
+    constexpr int RW = REV ? 64 / G : 2 * (64 / G);  // reads per wave
+    const int src = REV ? lane * G : (lane >> 1) * G;  // first lane of the group that holds read `lane`
+    const bool hi = !REV && (lane & 1);
     // both shuffles run with every lane active (a lane that sits out a divergent branch cannot be a shuffle source)
     auto pick = [&](int va, int vb) {
         const int xa = __shfl(va, src, 64), xb = __shfl(vb, src, 64);
@@ -278,8 +314,13 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
             a.out.status[o_id] = status;
             if (a.out.tier) a.out.tier[o_id] = tier;
             const bool some = status == ZSW_STATUS_SOME;
-            if (MODE != 0 && a.out.ref_end) a.out.ref_end[o_id] = some ? o_re : 0;
-            if (MODE == 2 && a.out.query_end) a.out.query_end[o_id] = some ? o_qe : 0;
+            if (REV) {  // inclusive 0-based starts (striped.rs:326-328): prefix length minus the exclusive end found here
+                a.out.ref_end[o_id] = some ? a.rev_ref_end[o_id] - o_re : 0;
+                a.out.query_end[o_id] = some ? o_len - o_qe : 0;
+            } else {
+                if (MODE != 0 && a.out.ref_end) a.out.ref_end[o_id] = some ? o_re : 0;
+                if (MODE == 2 && a.out.query_end) a.out.query_end[o_id] = some ? o_qe : 0;
+            }
         }
     }
 }
@@ -561,7 +602,8 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
 __global__ __launch_bounds__(64) void exact32_kernel(BatchDev b, const uint32_t* list, const uint32_t* list_count,
                                                      const uint8_t* ref, uint32_t ref_len, const ScoringDev* sc,
                                                      ResultRule rule, ScoreOut out, int32_t* scratch, uint32_t slots,
-                                                     uint32_t scratch_len) {
+                                                     uint32_t scratch_len, const uint32_t* rev_ref_end,
+                                                     const uint32_t* rev_query_end) {
     __shared__ uint8_t lut[256];
     __shared__ int32_t w[MAX_S * MAX_S];
     for (int i = threadIdx.x; i < 256; i += 64) lut[i] = sc->index_map[i];
@@ -584,6 +626,11 @@ __global__ __launch_bounds__(64) void exact32_kernel(BatchDev b, const uint32_t*
             off = (uint64_t)id * b.fixed_len;
             len = b.fixed_len;
         }
+        uint32_t rows = ref_len;
+        if (rev_ref_end) {  // reverse pass of sw_simd_score_ranges: reversed prefixes of both sequences
+            len = rev_query_end[id] <= len ? rev_query_end[id] : len;
+            rows = len ? rev_ref_end[id] : 0;
+        }
         if (len == 0 || len > scratch_len) {
             out.score[id] = 0;
             out.status[id] = len == 0 ? ZSW_STATUS_EMPTY : ZSW_STATUS_OVERFLOWED;
@@ -598,13 +645,13 @@ __global__ __launch_bounds__(64) void exact32_kernel(BatchDev b, const uint32_t*
         }
         int64_t best = 0;
         uint32_t r_end = 0, c_end = 0;
-        for (uint32_t r = 0; r < ref_len; ++r) {
-            const int32_t* wr = &w[lut[ref[r]] * S];
+        for (uint32_t r = 0; r < rows; ++r) {
+            const int32_t* wr = &w[lut[ref[rev_ref_end ? rows - 1 - r : r]] * S];
             int32_t f = 0, diag = 0;
             for (uint32_t c = 0; c < len; ++c) {
                 const int32_t up = Hrow[(size_t)c * slots];
                 int32_t e = Erow[(size_t)c * slots];
-                int32_t h = diag + wr[lut[b.bases[off + c]]];
+                int32_t h = diag + wr[lut[b.bases[rev_ref_end ? off + (len - 1 - c) : off + c]]];
                 h = max(max(h, e), max(f, 0));
                 if (h > best) {
                     best = h;
@@ -625,8 +672,13 @@ __global__ __launch_bounds__(64) void exact32_kernel(BatchDev b, const uint32_t*
         out.status[id] = status;
         if (out.tier) out.tier[id] = tier;
         const bool some = status == ZSW_STATUS_SOME;
-        if (out.ref_end) out.ref_end[id] = some ? r_end + 1 : 0;
-        if (out.query_end) out.query_end[id] = some ? c_end + 1 : 0;
+        if (rev_ref_end) {  // inclusive starts
+            out.ref_end[id] = some ? rows - (r_end + 1) : 0;
+            out.query_end[id] = some ? len - (c_end + 1) : 0;
+        } else {
+            if (out.ref_end) out.ref_end[id] = some ? r_end + 1 : 0;
+            if (out.query_end) out.query_end[id] = some ? c_end + 1 : 0;
+        }
     }
 }
 
@@ -846,6 +898,9 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     a.sc = d_sc;
     a.rule = rule;
     a.out = out;
+    a.rev_ref_end = nullptr;
+    a.rev_query_end = nullptr;
+    a.gtab = nullptr;
     const bool fast = fast_ok(h_sc);
     if (table_ok) build_tables(h_sc, fast, &a);
     const bool use_v2 = table_ok && v2_ok(h_sc);
@@ -866,7 +921,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     };
     auto exact_all = [&](const BatchDev& bb) {
         hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, bb, (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr, d_ref, ref_len, d_sc, rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len);
+                           (const uint32_t*)nullptr, d_ref, ref_len, d_sc, rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
         return hipGetLastError();
     };
     if (!table_ok) {  // alphabet outside the table kernels: exact kernel over the whole batch
@@ -925,7 +980,79 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     }
     // reads that saturated i16: exact pass over the device-side worklist (usually empty)
     hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, b, out.fb_list, out.fb_count, d_ref, ref_len, d_sc,
-                       rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len);
+                       rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    return hipGetLastError();
+}
+
+// ---- reverse pass of sw_simd_score_ranges -------------------------------------------------------------------
+__global__ void gtab_kernel(const uint8_t* ref, uint32_t n, const ScoringDev* sc, ScoreArgs a, uint2* gtab) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int idx = sc->index_map[ref[i]];
+        gtab[i] = make_uint2(a.wtab[idx][0], a.wtab[idx][1]);
+    }
+}
+
+template <int G, int C>
+static hipError_t launch_cfg_rev(const ScoreArgs& a, bool fast, hipStream_t stream) {
+    const uint32_t reads_per_block = BLOCK / G;
+    const uint32_t grid = (a.b.n_items + reads_per_block - 1) / reads_per_block;
+    if (grid == 0) return hipSuccess;
+    if (fast) hipLaunchKernelGGL((score_kernel<G, C, true, 2, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((score_kernel<G, C, false, 2, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_score_rev(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
+                            const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
+                            const ScoreWorkspace& ws, const uint32_t* d_fwd_ref_end, const uint32_t* d_fwd_query_end,
+                            uint2* d_gtab, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(out.fb_count, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const uint32_t exact_grid = (uint32_t)(ws.slots / 64);
+    int G = 0, C = 0;
+    const bool table_ok = (h_sc.S <= 7 || fast_ok(h_sc)) && score_config_for(max_len, &G, &C);
+    if (!table_ok) {
+        hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, b, (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, d_ref, ref_len, d_sc, rule, out, ws.scratch, (uint32_t)ws.slots,
+                           ws.scratch_len, d_fwd_ref_end, d_fwd_query_end);
+        return hipGetLastError();
+    }
+    ScoreArgs a;
+    a.b = b;
+    a.ref = d_ref;
+    a.ref_len = ref_len;
+    a.sc = d_sc;
+    a.rule = rule;
+    a.out = out;
+    a.rev_ref_end = d_fwd_ref_end;
+    a.rev_query_end = d_fwd_query_end;
+    a.gtab = d_gtab;
+    const bool fast = fast_ok(h_sc);
+    build_tables(h_sc, fast, &a);
+    if (ref_len) hipLaunchKernelGGL(gtab_kernel, dim3((ref_len + 255) / 256), dim3(256), 0, stream, d_ref, ref_len, d_sc, a, d_gtab);
+    switch (G * 100 + C) {
+#define ZSW_CASE(GV, CV) \
+    case GV * 100 + CV: e = launch_cfg_rev<GV, CV>(a, fast, stream); break;
+        ZSW_CASE(4, 19)
+        ZSW_CASE(4, 25)
+        ZSW_CASE(4, 32)
+        ZSW_CASE(4, 38)
+        ZSW_CASE(8, 19)
+        ZSW_CASE(8, 25)
+        ZSW_CASE(8, 32)
+        ZSW_CASE(8, 38)
+        ZSW_CASE(16, 25)
+        ZSW_CASE(16, 32)
+        ZSW_CASE(16, 38)
+        ZSW_CASE(64, 19)
+        ZSW_CASE(64, 38)
+#undef ZSW_CASE
+        default: e = hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, b, out.fb_list, out.fb_count, d_ref, ref_len, d_sc,
+                       rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len, d_fwd_ref_end, d_fwd_query_end);
     return hipGetLastError();
 }
 
