@@ -63,5 +63,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_driver() -> str:
+    """The C++ host driver (examples/zsw_driver.cpp over include/zoe_sw.hpp), linked against the in-tree library."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "examples", "zsw_driver.cpp")
+    out = os.path.join(root, "examples", "zsw_driver")
+    deps = [src, os.path.join(root, "include", "zoe_sw.hpp"), os.path.join(root, "include", "zoe_sw.h"), LIB]
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(root, "include"), src, "-o", out, "-L" + HERE,
+                    "-lzoe_sw_hip", "-Wl,-rpath,$ORIGIN/../zoe_amd", "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
