@@ -82,12 +82,26 @@ def cpu_baseline(reference: bytes, target_s: float):
     probe = synth.reads_host(reference, 0, 1000 * cores, READ_LEN)
     t0 = time.perf_counter()
     oracle.batch_score_w256(8, sc, probe, reference, fixed_len=READ_LEN, threads=cores)
-    rate = probe.shape[0] / (time.perf_counter() - t0)
-    n = int(max(probe.shape[0], min(rate * target_s, 8_000_000)))
+    probe_rate = probe.shape[0] / (time.perf_counter() - t0)
+    n = int(max(probe.shape[0], min(probe_rate * target_s, 8_000_000)))
     reads = synth.reads_host(reference, 0, n, READ_LEN)
     t0 = time.perf_counter()
     oracle.batch_score_w256(8, sc, reads, reference, fixed_len=READ_LEN, threads=cores)
     dt = time.perf_counter() - t0
+    # short side samples: one thread, i16-direct, and one shared reference-side profile
+    def rate(fn, k):
+        t = time.perf_counter()
+        fn(reads[:k])
+        return k / (time.perf_counter() - t)
+
+    k1 = max(2000, min(n, int(rate_guess_1t(rate, cores) * 3)))
+    variants = {
+        "from_i8_fresh_profile_1_thread": rate(lambda r: oracle.batch_score_w256(8, sc, r, reference, fixed_len=READ_LEN, threads=1), k1),
+        "from_i16_fresh_profile_all_threads": rate(
+            lambda r: oracle.batch_score_w256(16, sc, r, reference, fixed_len=READ_LEN, threads=cores), min(n, int(probe_rate * 3))),
+        "from_i8_shared_reference_profile_all_threads": rate(
+            lambda r: oracle.batch_score_shared_w256(8, sc, r, reference, fixed_len=READ_LEN, threads=cores), min(n, int(probe_rate * 3))),
+    }
     return {
         "value": n / dt,
         "unit": "read-alignments/s",
@@ -95,7 +109,21 @@ def cpu_baseline(reference: bytes, target_s: float):
         "kind": "port",
         "sample": f"{n} of the same synthetic 150 bp reads vs the 2 kb reference, sw_score_from_i8 (i8x32 -> i16x16, "
                   f"fresh profile per read), restated Zoe CPU path (AVX2), {cores} threads, {dt:.1f} s",
+        "variants_reads_per_s": variants,
     }
+
+
+def rate_guess_1t(rate_fn, cores):
+    """Reads/s of one thread, estimated on a tiny probe so the 1-thread sample lasts about 3 s."""
+    from oracle import oracle
+    from zoe_amd import synth
+
+    ref = synth.reference_host(REF_LEN)
+    probe = synth.reads_host(ref, 0, 1000, READ_LEN)
+    sc = oracle.dna_scoring(2, -5, b"N", -10, -1)
+    t = time.perf_counter()
+    oracle.batch_score_w256(8, sc, probe, ref, fixed_len=READ_LEN, threads=1)
+    return 1000 / (time.perf_counter() - t)
 
 
 def main():

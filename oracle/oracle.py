@@ -291,5 +291,26 @@ def batch_score_w256(from_width: int, sc: Scoring, reads: np.ndarray, reference,
     return score, status, tier
 
 
+def batch_score_shared_w256(from_width: int, sc: Scoring, reads: np.ndarray, profile_seq, offsets: Optional[np.ndarray] = None,
+                            fixed_len: int = 0, threads: int = 1):
+    """SharedProfiles usage (sw/mod.rs:73-78): one profile built from `profile_seq` (the long sequence), every read
+    passed as `reference`. Returns (score u32[n], status u8[n])."""
+    w, im, a = _sc_args(sc)
+    reads = np.ascontiguousarray(reads, dtype=np.uint8).reshape(-1)
+    ps = _u8(profile_seq)
+    if offsets is not None:
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        offp = _p(offsets, C.c_uint64)
+    else:
+        n = reads.size // fixed_len
+        offp = None
+    score = np.zeros(n, dtype=np.uint32)
+    status = np.zeros(n, dtype=np.uint8)
+    rc = lib().zor_batch_score_shared_w256(from_width, *a, _p(reads), offp, C.c_size_t(fixed_len), C.c_size_t(n), _p(ps), C.c_size_t(len(ps)), threads, _p(score, C.c_uint32), _p(status))
+    _check(rc)
+    return score, status
+
+
 def hardware_threads() -> int:
     return int(lib().zor_hardware_threads())

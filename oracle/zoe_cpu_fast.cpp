@@ -79,25 +79,42 @@ struct Scratch {
     std::vector<__m256i> profile, load, store, e;
 };
 
-// StripedProfile::new_unchecked (profile.rs:270-306) + sw_simd_score (striped.rs:65-142), signed T
+// StripedProfile::new_unchecked (profile.rs:270-306), signed T
 template <typename K>
-Status score_one(const Scoring& sc, const uint8_t* read, size_t len, const uint8_t* reference, size_t ref_len,
-                 Scratch& s, uint32_t* score) {
+size_t build_profile(const Scoring& sc, const uint8_t* seq, size_t len, std::vector<__m256i>& profile) {
     using T = typename K::T;
     constexpr int N = K::N;
     const size_t nv = (len + N - 1) / N;
-    s.profile.resize(size_t(sc.S) * nv);
-    {
-        alignas(32) T lanes[N];
-        for (size_t v = 0; v < nv; ++v)
-            for (int ri = 0; ri < sc.S; ++ri) {
-                for (int i = 0; i < N; ++i) {
-                    size_t q = v + size_t(i) * nv;
-                    lanes[i] = q < len ? T(sc.w[ri][sc.index_map[read[q]]]) : T(0);
-                }
-                s.profile[size_t(ri) * nv + v] = _mm256_load_si256((const __m256i*)lanes);
+    profile.resize(size_t(sc.S) * nv);
+    alignas(32) T lanes[N];
+    for (size_t v = 0; v < nv; ++v)
+        for (int ri = 0; ri < sc.S; ++ri) {
+            for (int i = 0; i < N; ++i) {
+                size_t q = v + size_t(i) * nv;
+                lanes[i] = q < len ? T(sc.w[ri][sc.index_map[seq[q]]]) : T(0);
             }
-    }
+            profile[size_t(ri) * nv + v] = _mm256_load_si256((const __m256i*)lanes);
+        }
+    return nv;
+}
+
+template <typename K>
+Status run_profile(const Scoring& sc, const std::vector<__m256i>& profile, size_t nv, const uint8_t* reference, size_t ref_len,
+                   Scratch& s, uint32_t* score);
+
+// fresh profile per call + sw_simd_score (striped.rs:65-142)
+template <typename K>
+Status score_one(const Scoring& sc, const uint8_t* read, size_t len, const uint8_t* reference, size_t ref_len,
+                 Scratch& s, uint32_t* score) {
+    const size_t nv = build_profile<K>(sc, read, len, s.profile);
+    return run_profile<K>(sc, s.profile, nv, reference, ref_len, s, score);
+}
+
+// sw_simd_score (striped.rs:65-142) against a prebuilt profile
+template <typename K>
+Status run_profile(const Scoring& sc, const std::vector<__m256i>& profile, size_t nv, const uint8_t* reference, size_t ref_len,
+                   Scratch& s, uint32_t* score) {
+    using T = typename K::T;
     const __m256i minimums = K::splat(Int<T>::MIN);
     const __m256i go = K::splat(-sc.gap_open), ge = K::splat(-sc.gap_extend);
     s.load.assign(nv, minimums);
@@ -112,7 +129,7 @@ Status score_one(const Scoring& sc, const uint8_t* read, size_t len, const uint8
         __m256i F = minimums;
         __m256i H = K::shr1(store[nv - 1]);
         std::swap(load, store);
-        const __m256i* scores_vec = &s.profile[ref_index * nv];
+        const __m256i* scores_vec = &profile[ref_index * nv];
         for (size_t j = 0; j < nv; ++j) {
             __m256i E = es[j];
             H = K::adds(H, scores_vec[j]);
@@ -226,6 +243,54 @@ int zor_batch_score_w256(int from_width, int S, const int8_t* weights, const uin
     worker();
     for (auto& t : pool) t.join();
     return err.load();
+}
+
+// The other way Zoe is meant to be used for many reads vs one reference (SharedProfiles, sw/mod.rs:73-78): ONE profile
+// built from the long sequence, every read passed as the `reference` argument of sw_simd_score. Scores are role-symmetric
+// for symmetric matrices (profile.rs:443-445). i8x32 -> i16x16 -> i32 cascade, w256.
+int zor_batch_score_shared_w256(int from_width, int S, const int8_t* weights, const uint8_t* index_map, int gap_open,
+                                int gap_extend, const uint8_t* reads, const uint64_t* offsets, size_t fixed_len, size_t n_reads,
+                                const uint8_t* profile_seq, size_t profile_len, int threads, uint32_t* out_score,
+                                uint8_t* out_status) {
+    if (S > MAX_S) return -2;
+    Scoring sc;
+    sc.S = S;
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) sc.w[i][j] = weights[j * S + i];  // the profile sequence plays the query role: transpose
+    std::memcpy(sc.index_map, index_map, 256);
+    sc.gap_open = gap_open;
+    sc.gap_extend = gap_extend;
+    int e = validate_profile_args(profile_len, gap_open, gap_extend);
+    if (e) return e;
+    std::vector<__m256i> p8, p16;
+    const size_t nv8 = build_profile<I8>(sc, profile_seq, profile_len, p8);
+    const size_t nv16 = build_profile<I16>(sc, profile_seq, profile_len, p16);
+    if (threads < 1) threads = 1;
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        Scratch s;
+        for (;;) {
+            size_t b = next.fetch_add(256);
+            if (b >= n_reads) break;
+            size_t eidx = std::min(n_reads, b + 256);
+            for (size_t i = b; i < eidx; ++i) {
+                size_t off = offsets ? size_t(offsets[i]) : i * fixed_len;
+                size_t len = offsets ? size_t(offsets[i + 1] - offsets[i]) : fixed_len;
+                uint32_t score = 0;
+                Status st = OVERFLOWED;
+                if (from_width <= 8) st = run_profile<I8>(sc, p8, nv8, reads + off, len, s, &score);
+                if (st == OVERFLOWED) st = run_profile<I16>(sc, p16, nv16, reads + off, len, s, &score);
+                if (st == OVERFLOWED) st = score_i32(sc, profile_seq, profile_len, reads + off, len, &score);
+                out_status[i] = uint8_t(st);
+                out_score[i] = st == SOME ? score : 0;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    return 0;
 }
 
 int zor_hardware_threads() { return int(std::thread::hardware_concurrency()); }

@@ -50,6 +50,11 @@ struct AlignArgs {
     int debug;  // ZSW_ALIGN_DEBUG experiments: 1 = skip traceback, 2 = skip ring stores
 };
 
+// max(a - b, 0) for non-negative a, b: one v_sub_u32 with clamp
+__device__ __forceinline__ int32_t subsat(int32_t a, int32_t b) {
+    return (int32_t)__builtin_elementwise_sub_sat((uint32_t)a, (uint32_t)b);
+}
+
 __device__ __forceinline__ uint32_t read_len(const BatchDev& b, uint32_t id, uint64_t* off) {
     if (b.offsets) {
         *off = b.offsets[id];
@@ -365,9 +370,9 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
                             const bool stopped = h == 0;
                             H[v] = h;
                             if (v == nv - 1) Hlast = h;
-                            const int32_t hg = max(h - go, 0);
-                            const int32_t En = max(max(Eo - ge, 0), hg);
-                            F = max(max(F - ge, 0), hg);
+                            const int32_t hg = subsat(h, go);
+                            const int32_t En = max(subsat(Eo, ge), hg);
+                            F = max(subsat(F, ge), hg);
                             E[v] = En;
                             fl |= (En > hg ? (uint32_t)BT_UP_EXT : 0u) | (F > hg ? (uint32_t)BT_LEFT_EXT : 0u);
                             if (stopped) fl = BT_STOP;
@@ -377,8 +382,10 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
                     }
                 }
             }
-            // lazy-F pass (striped.rs:528-553)
-            bool done = !act;
+            // lazy-F pass (striped.rs:528-553). A read that has left its loop (or is past its last row) carries F = 0:
+            // with F = 0 a step changes neither H nor the flags (H = max(H,0); F == H only where H == 0, which stays STOP),
+            // so finished reads need no predication while other reads of the wave keep iterating.
+            if (!act) F = 0;
             for (int it = 0; it < N; ++it) {
                 F = __shfl_up(F, 1, N);
                 if (li == 0) F = 0;
@@ -387,25 +394,21 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
                 for (int v = 0; v < NVMAX; ++v) {
                     if (!stop_all && v < nv) {
                         const int32_t h0 = H[v];
-                        const bool cond = !done && F > max(h0 - go, 0);
-                        const unsigned long long bal = __ballot(cond);
-                        if ((bal & gmask) == 0) done = true;
+                        const unsigned long long bal = __ballot(F > subsat(h0, go));
+                        if ((bal & gmask) == 0) F = 0;  // this read breaks out of 'lazy_f here
                         if (bal == 0) {
                             stop_all = true;  // every read of the wave has left its lazy-F loop
                         } else {
                             const int32_t h = max(h0, F);
                             uint32_t fl = flg[v];
                             if (F == h) fl = (fl & BT_UP_EXT) | BT_LEFT;  // simd_correct_and_set_left
-                            const int32_t hg = max(h - go, 0);
-                            const int32_t Fn = max(F - ge, 0);
-                            if (Fn > hg) fl |= BT_LEFT_EXT;
+                            const int32_t hg = subsat(h, go);
+                            F = subsat(F, ge);
+                            if (F > hg) fl |= BT_LEFT_EXT;
                             if (h == 0) fl = BT_STOP;
-                            if (!done) {
-                                H[v] = h;
-                                flg[v] = fl;
-                                F = Fn;
-                                if (v == nv - 1) Hlast = h;
-                            }
+                            H[v] = h;
+                            flg[v] = fl;
+                            if (v == nv - 1) Hlast = h;
                         }
                     }
                 }
