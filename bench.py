@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=2048, help="reads checked against the oracle after the timed region")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
+                    "multi-rank path on a one-GPU box together with --single-device)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -142,10 +145,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback path)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     import zoe_amd
     from zoe_amd import synth
@@ -162,11 +170,19 @@ def main():
         all_scores = torch.empty(world * n_local, dtype=torch.int32, device=dev)
         all_status = torch.empty(world * n_local, dtype=torch.uint8, device=dev)
 
+    gather_on_host = world > 1 and args.backend != "nccl"
+    if gather_on_host:
+        all_scores, all_status = all_scores.cpu(), all_status.cpu()
+
     def step():
         r = profiles.sw_score_from_i8(reference)
         if world > 1:
-            dist.all_gather_into_tensor(all_scores, r.score)
-            dist.all_gather_into_tensor(all_status, r.status)
+            if gather_on_host:  # rehearsal path only
+                dist.all_gather_into_tensor(all_scores, r.score.cpu())
+                dist.all_gather_into_tensor(all_status, r.status.cpu())
+            else:
+                dist.all_gather_into_tensor(all_scores, r.score)
+                dist.all_gather_into_tensor(all_status, r.status)
         return r
 
     def fence():
@@ -188,9 +204,13 @@ def main():
     kern_s, launches = ctx.timing_read()
     ctx.timing_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if gather_on_host else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the gathered array must be every rank's shard in read order
+        if rank == 0:
+            mine = last.score.cpu() if gather_on_host else last.score
+            assert torch.equal(all_scores[:n_local].to(mine.device), mine), "all-gather order"
 
     # parity spot check outside the timed region (rank 0): a slice of the batch against the oracle
     verified = None
