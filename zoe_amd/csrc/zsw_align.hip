@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "zsw_align.hpp"
@@ -343,7 +344,14 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) rmax = max(rmax, __shfl_xor(rmax, d, 64));
 
-        for (int r = 0; r <= rmax; ++r) {
+        // Rows that can no longer fall inside any read's retained window (r <= min r_end - W) only have to carry the DP
+        // state forward exactly; their flag arithmetic and ring stores are skipped (FLAGS = false).
+        int rmin = active ? rend : 0x7fffffff;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) rmin = min(rmin, __shfl_xor(rmin, d, 64));
+
+        auto do_row = [&](const int r, auto flags_tag) {
+            constexpr bool FLAGS = decltype(flags_tag)::value;
             const bool act = r <= rend;
             const int ri = lut[a.ref[r]];
             const uint32_t* prow = prof4 + (size_t)ri * nvq * 64 + lane;
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
             int32_t F = 0;
             int32_t Hd = __shfl_up(Hlast, 1, N);
             if (li == 0) Hd = 0;
-            uint32_t flg[NVMAX];  // one flag byte per vector, packed four per dword only when the row is stored
+            uint32_t flg[FLAGS ? NVMAX : 1];  // one flag byte per vector, packed four per dword only when the row is stored
 #pragma unroll
             for (int vq = 0; vq < NVQMAX; ++vq) {
                 if (vq < nvq) {
@@ -359,24 +367,26 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int v = 4 * vq + j;
-                        flg[v] = 0;
+                        if (FLAGS) flg[FLAGS ? v : 0] = 0;
                         if (v < nv) {
                             const int32_t s = __builtin_amdgcn_sbfe((int)p4, 8 * j, 8);
                             const int32_t Eo = E[v];
                             const int32_t hold = H[v];
                             int32_t h = max(Hd + s, 0);
                             h = max(h, max(Eo, F));
-                            uint32_t fl = (Eo == h ? (uint32_t)BT_UP : 0u) | (F == h ? (uint32_t)BT_LEFT : 0u);
-                            const bool stopped = h == 0;
+                            uint32_t fl = 0;
+                            if (FLAGS) fl = (Eo == h ? (uint32_t)BT_UP : 0u) | (F == h ? (uint32_t)BT_LEFT : 0u);
                             H[v] = h;
                             if (v == nv - 1) Hlast = h;
                             const int32_t hg = subsat(h, go);
                             const int32_t En = max(subsat(Eo, ge), hg);
                             F = max(subsat(F, ge), hg);
                             E[v] = En;
-                            fl |= (En > hg ? (uint32_t)BT_UP_EXT : 0u) | (F > hg ? (uint32_t)BT_LEFT_EXT : 0u);
-                            if (stopped) fl = BT_STOP;
-                            flg[v] = fl;
+                            if (FLAGS) {
+                                fl |= (En > hg ? (uint32_t)BT_UP_EXT : 0u) | (F > hg ? (uint32_t)BT_LEFT_EXT : 0u);
+                                if (h == 0) fl = BT_STOP;
+                                flg[FLAGS ? v : 0] = fl;
+                            }
                             Hd = hold;
                         }
                     }
@@ -400,14 +410,15 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
                             stop_all = true;  // every read of the wave has left its lazy-F loop
                         } else {
                             const int32_t h = max(h0, F);
-                            uint32_t fl = flg[v];
-                            if (F == h) fl = (fl & BT_UP_EXT) | BT_LEFT;  // simd_correct_and_set_left
-                            const int32_t hg = subsat(h, go);
+                            if (FLAGS) {
+                                uint32_t fl = flg[FLAGS ? v : 0];
+                                if (F == h) fl = (fl & BT_UP_EXT) | BT_LEFT;  // simd_correct_and_set_left
+                                if (subsat(F, ge) > subsat(h, go)) fl |= BT_LEFT_EXT;
+                                if (h == 0) fl = BT_STOP;
+                                flg[FLAGS ? v : 0] = fl;
+                            }
                             F = subsat(F, ge);
-                            if (F > hg) fl |= BT_LEFT_EXT;
-                            if (h == 0) fl = BT_STOP;
                             H[v] = h;
-                            flg[v] = fl;
                             if (v == nv - 1) Hlast = h;
                         }
                     }
@@ -415,11 +426,15 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
                 if (stop_all) break;
             }
             // keep the last W rows of flags of every read still running
-            if (act && r + W > rend && !(a.debug & 2)) {
-                uint32_t* dst = reinterpret_cast<uint32_t*>(ring + (size_t)(r % W) * row_bytes) + (size_t)li * nvq;
+            if (FLAGS) {
+                if (act && r + W > rend && !(a.debug & 2)) {
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(ring + (size_t)(r % W) * row_bytes) + (size_t)li * nvq;
 #pragma unroll
-                for (int vq = 0; vq < NVQMAX; ++vq)
-                    if (vq < nvq) dst[vq] = flg[4 * vq] | (flg[4 * vq + 1] << 8) | (flg[4 * vq + 2] << 16) | (flg[4 * vq + 3] << 24);
+                    for (int vq = 0; vq < NVQMAX; ++vq)
+                        if (vq < nvq)
+                            dst[vq] = flg[FLAGS ? 4 * vq : 0] | (flg[FLAGS ? 4 * vq + 1 : 0] << 8) | (flg[FLAGS ? 4 * vq + 2 : 0] << 16) |
+                                      (flg[FLAGS ? 4 * vq + 3 : 0] << 24);
+                }
             }
             // c_end at the read's last row: first query position whose H equals the best score (striped.rs:571-583)
             if (__ballot(r == rend) != 0) {
@@ -433,6 +448,10 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
                     }
                 }
             }
+        };
+        for (int r = 0; r <= rmax; ++r) {
+            if (r + W > rmin) do_row(r, std::true_type{});
+            else do_row(r, std::false_type{});
         }
 #pragma unroll
         for (int d = 1; d < N; d <<= 1) cend = min(cend, __shfl_xor(cend, d, N));
