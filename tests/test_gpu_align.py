@@ -223,3 +223,22 @@ def test_overflow_unmapped_and_ragged(za, oracle):
     for i, rd in enumerate(reads):
         want, tier = oracle.cascade_align(8, 512, sc, rd, ref)
         assert got.key(i) == okey(want), i
+
+
+def test_align_degenerate_batches(za, oracle):
+    """Nothing to align: empty reference (striped.rs:455-457), all-N reads, a single 1-base read, zero reads."""
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    a = za.StripedProfileBatch([b"ACGT", b"GG"], dna, -10, -1, "i16", 16).sw_align(za.SeqSrc.Reference(b""))
+    assert list(a.status) == [U_, U_] and len(a.inc) == 0
+    a = za.StripedProfileBatch([b"NNNN", b"nnnnnn"], dna, -10, -1, "i8", 32).sw_align(za.SeqSrc.Reference(b"ACGTACGT"))
+    assert list(a.status) == [U_, U_]
+    a = za.into_local_profile([b"A"], dna, -10, -1).sw_align_from_i8(za.SeqSrc.Reference(b"CCCACCC"))
+    want, tier = oracle.cascade_align(8, 256, osc(oracle, dna, -10, -1), b"A", b"CCCACCC")
+    assert a.key(0) == okey(want) and a.cigar(0) == "1M"
+    import torch
+
+    rb = za.ReadBatch(torch.zeros(1, dtype=torch.uint8, device="cuda"), 0, fixed_len=10, min_len=10)
+    a = za.StripedProfileBatch(rb, dna, -10, -1, "i16", 16).sw_align(za.SeqSrc.Reference(b"ACGT"))
+    assert len(a.status) == 0 and len(a.inc) == 0
+    s = za.StripedProfileBatch(rb, dna, -10, -1, "i16", 16).sw_score(b"ACGT")
+    assert s.score.numel() == 0
