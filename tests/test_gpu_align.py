@@ -242,3 +242,53 @@ def test_align_degenerate_batches(za, oracle):
     assert len(a.status) == 0 and len(a.inc) == 0
     s = za.StripedProfileBatch(rb, dna, -10, -1, "i16", 16).sw_score(b"ACGT")
     assert s.score.numel() == 0
+
+
+def test_config3_large_batch_properties(za, oracle):
+    """BASELINE.json configs[2] shape at 2 M reads, through size-independent properties: every CIGAR consumes exactly the
+    read and its reference range, scores and ends agree with the (independent) score+ends kernel for every read, and a
+    random sample is bit-identical to the oracle and re-scores to its own score."""
+    import torch
+
+    from zoe_amd import synth
+
+    ctx = za.SwContext.get(0)
+    ref = synth.reference_host(2000)
+    n = 2_000_000
+    rb = synth.reads_device(ctx, ref, 1_000_000, n, 150)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    a = za.into_local_profile(rb, dna, -10, -1).sw_align_from_i8(za.SeqSrc.Reference(ref))
+    rec, st = a.records, a.status
+    some = st == S_
+    ends = za.StripedProfileBatch(rb, dna, -10, -1, "i16", 16).sw_score_ends(za.SeqSrc.Reference(ref))
+    assert np.array_equal(st, ends.status.cpu().numpy())
+    assert np.array_equal(rec["score"][some], ends.score.cpu().numpy()[some].view(np.uint32))
+    assert np.array_equal(rec["ref_end"][some], ends.ref_end.cpu().numpy()[some].view(np.uint32))
+    assert np.array_equal(rec["query_end"][some], ends.query_end.cpu().numpy()[some].view(np.uint32))
+    # ciglets are packed back to back in read order
+    nc = rec["n_ciglets"].astype(np.int64)
+    off = rec["ciglet_offset"].astype(np.int64)
+    assert np.array_equal(off[some], (np.cumsum(nc) - nc)[some]) and int(nc.sum()) == len(a.inc)
+    # per-read consumption: M+I+S = query_len, M+D = ref span, M+I = query span; no zero increments; no equal neighbours
+    inc = a.inc.astype(np.int64)
+    op = a.op
+    owner = np.repeat(np.arange(n), nc)
+    q_cons = np.bincount(owner, weights=inc * np.isin(op, (ord("M"), ord("I"), ord("S"))), minlength=n).astype(np.int64)
+    r_cons = np.bincount(owner, weights=inc * np.isin(op, (ord("M"), ord("D"))), minlength=n).astype(np.int64)
+    qa_cons = np.bincount(owner, weights=inc * np.isin(op, (ord("M"), ord("I"))), minlength=n).astype(np.int64)
+    assert (q_cons[some] == 150).all()
+    assert np.array_equal(r_cons[some], (rec["ref_end"].astype(np.int64) - rec["ref_start"])[some])
+    assert np.array_equal(qa_cons[some], (rec["query_end"].astype(np.int64) - rec["query_start"])[some])
+    assert (inc > 0).all() and set(np.unique(op)) <= set(b"MIDS")
+    same_owner = owner[1:] == owner[:-1]
+    assert not (same_owner & (op[1:] == op[:-1])).any()
+    # sample vs oracle + sw_score_from_path
+    sc = osc(oracle, dna, -10, -1)
+    rng = np.random.default_rng(4)
+    idx = np.sort(rng.choice(n, 1500, replace=False))
+    host = rb.bases.view(n, 150)[torch.from_numpy(idx).cuda()].cpu().numpy()
+    for k, i in enumerate(idx):
+        want, tier = oracle.cascade_align(8, 256, sc, host[k], ref)
+        assert a.key(int(i)) == okey(want), i
+        if want.status == S_:
+            assert oracle.score_from_path(sc, host[k], ref[want.ref_range[0] : want.ref_range[1]], a.cigar(int(i))) == want.score

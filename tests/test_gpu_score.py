@@ -348,3 +348,42 @@ def test_score_ranges_vs_oracle(za, oracle, dna):
         assert int(got.status[i]) == st, i
         if st == S_:
             assert (int(got.score[i]), (int(got.query_start[i]), int(got.query_end[i])), (int(got.ref_start[i]), int(got.ref_end[i]))) == (s, rr, qr), i
+
+
+def test_full_size_10m_reads_properties(za, oracle, dna, monkeypatch):
+    """BASELINE.json configs[1] at full size (10 M x 150 bp vs 2 kb), checked through size-independent properties:
+    the two independent kernels (v1 saturating-i16, v2 drifted/max3) agree on every read, a second run is identical,
+    shard-wise generation equals whole-batch generation, bounds hold, and a random sample equals the oracle."""
+    import torch
+
+    from zoe_amd import synth
+
+    ctx = za.SwContext.get(0)
+    ref = synth.reference_host(2000)
+    n = 10_000_000
+    rb = synth.reads_device(ctx, ref, 0, n, 150)
+    prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
+    monkeypatch.delenv("ZSW_SCORE_V1", raising=False)
+    a = prof.sw_score_from_i8(ref)
+    s2, st2, t2 = a.score.clone(), a.status.clone(), a.tier.clone()
+    b = prof.sw_score_from_i8(ref)
+    assert torch.equal(b.score, s2) and torch.equal(b.status, st2)  # deterministic
+    monkeypatch.setenv("ZSW_SCORE_V1", "1")
+    c = prof.sw_score_from_i8(ref)
+    assert torch.equal(c.score, s2) and torch.equal(c.status, st2) and torch.equal(c.tier, t2)  # v1 == v2 on all 10 M reads
+    monkeypatch.delenv("ZSW_SCORE_V1", raising=False)
+    # bounds: 0 <= score <= 2 * L; status Some <=> score > 0; tier 8 <=> score < 255
+    assert int(s2.max()) <= 300 and int(s2.min()) >= 0
+    assert torch.equal(st2 == 0, s2 > 0) and torch.equal(t2 == 8, s2 < 255)
+    # a shard regenerated on its own (counter-based generator) scores like the same reads inside the big batch
+    first, cnt = 7_654_321, 50_000
+    shard = synth.reads_device(ctx, ref, first, cnt, 150)
+    d = za.LocalProfilesBatch.new_with_w256(shard, dna, -10, -1).sw_score_from_i8(ref)
+    assert torch.equal(d.score, s2[first : first + cnt])
+    # random sample against the oracle
+    rng = np.random.default_rng(1)
+    idx = np.sort(rng.choice(n, 3000, replace=False))
+    host = rb.bases.view(n, 150)[torch.from_numpy(idx).cuda()].cpu().numpy()
+    ws, wst, wt = oracle.batch_score_w256(8, osc(oracle, dna, -10, -1), host, ref, fixed_len=150, threads=16)
+    assert np.array_equal(s2.cpu().numpy()[idx].view(np.uint32), ws) and np.array_equal(st2.cpu().numpy()[idx], wst)
+    assert np.array_equal(t2.cpu().numpy()[idx], wt)
