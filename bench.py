@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=2048, help="reads checked against the oracle after the timed region")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short config-3 / config-5 measurements")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on a one-GPU box together with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -130,6 +131,44 @@ def rate_guess_1t(rate_fn, cores):
     t = time.perf_counter()
     oracle.batch_score_w256(8, sc, probe, ref, fixed_len=READ_LEN, threads=1)
     return 1000 / (time.perf_counter() - t)
+
+
+def secondary_configs(zoe_amd, synth, ctx, matrix):
+    """Short measurements of the other BASELINE.json configs on this GPU (after the timed region; not part of `value`):
+    configs[2] full traceback and configs[4] mixed lengths vs a 30 kb reference, 1 M reads each."""
+    import torch
+
+    out = {}
+    ref2k = synth.reference_host(REF_LEN)
+    rb = synth.reads_device(ctx, ref2k, 0, 1_000_000, READ_LEN)
+    prof = zoe_amd.into_local_profile(rb, matrix, -10, -1, device=ctx.device)
+    prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref2k))
+    ctx.timing_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    a = prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref2k))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ks, _ = ctx.timing_read()
+    out["align_full_traceback_1M_x_150bp_vs_2kb"] = {
+        "reads_per_s_end_to_end_incl_d2h": 1_000_000 / dt, "pass2_kernel_ms": ks * 1e3, "ciglets": int(len(a.inc)),
+        "call": "into_local_profile(..).sw_align_from_i8(SeqSrc::Reference(ref)) (CIGAR of the i16x16 / i8x32 tier)"}
+    ref30k = synth.reference_host(30000)
+    rr = synth.reads_ragged_device(ctx, ref30k, 0, 1_000_000, 75, 400)
+    pm = zoe_amd.into_local_profile(rr, matrix, -10, -1, device=ctx.device)
+    pm.sw_score_from_i8(ref30k)
+    torch.cuda.synchronize()
+    ctx.timing_read()  # drop the warm-up launch from the kernel timer
+    t0 = time.perf_counter()
+    pm.sw_score_from_i8(ref30k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ks, _ = ctx.timing_read()
+    ctx.timing_enable(False)
+    cells = float(rr.offsets[-1]) * 30000
+    out["score_mixed_1M_x_75_400bp_vs_30kb"] = {"reads_per_s": 1_000_000 / dt, "gcups": cells / dt / 1e9, "kernel_ms": ks * 1e3,
+                                                "call": "sw_score_from_i8, reads bucketed by strip configuration on the device"}
+    return out
 
 
 def main():
@@ -280,6 +319,10 @@ def main():
             },
             "parity_checked_reads": args.verify if verified else 0,
         }
+        if not args.no_secondary and world == 1:
+            del reads, profiles, last
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_configs(zoe_amd, synth, ctx, matrix)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(reference, args.cpu_seconds)
         print(json.dumps(out), flush=True)
