@@ -17,4 +17,10 @@ hipError_t align_finalize(zsw_alignment* d_aln, const uint8_t* d_status, uint32_
                           uint64_t* d_total, const uint64_t* d_cig_start, const uint32_t* d_cig_raw, int invert,
                           uint32_t* out_inc, uint8_t* out_op, uint64_t cap, bool count_only, hipStream_t stream);
 
+// Device-side grouping (zsw_group.hip): read ids sorted by (N, nv, ref_end) + the table of group starts.
+size_t group_temp_bytes(uint32_t n);
+hipError_t group_reads(const BatchDev& b, const uint8_t* d_status, const uint8_t* d_tier, const uint32_t* d_ref_end, int lanes_w8,
+                       int lanes_w16, int lanes_w32, uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* items_out,
+                       void* temp, size_t temp_bytes, uint32_t* table, uint32_t* table_count, uint32_t cap, hipStream_t stream);
+
 }  // namespace zsw

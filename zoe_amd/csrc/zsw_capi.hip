@@ -51,7 +51,7 @@ struct zsw_context {
     // staging for host-memory batches
     DevBuf s_bases, s_offsets, s_score, s_status, s_tier, s_rend, s_qend;
     // alignment workspace (zsw_align.hip)
-    DevBuf a_ws[20];
+    DevBuf a_ws[28];
     // score_ranges workspace
     DevBuf r_ws[20];
     KernelTimer timer;
@@ -385,9 +385,23 @@ zsw_error run_ranges(zsw_context* ctx, const zsw_batch* reads, const ResultRule&
 }
 
 enum { WS_SCORE = 0, WS_STATUS, WS_TIER, WS_REND, WS_ITEMS, WS_RING, WS_CIG, WS_ALN, WS_CIGSTART, WS_CIGRAW, WS_BSUMS, WS_TOTAL,
-       WS_FBLIST, WS_FBCOUNT, WS_OINC, WS_OOP, WS_CIG2, WS_RING2 };
+       WS_FBLIST, WS_FBCOUNT, WS_OINC, WS_OOP, WS_CIG2, WS_RING2, WS_KEYS_IN, WS_KEYS_OUT, WS_VALS_IN, WS_SORT_TMP, WS_GTABLE, WS_FBMETA,
+       WS_ITEMS2 };
 
-typedef std::map<std::pair<int, uint32_t>, std::vector<uint32_t>> Groups;  // <N lanes, nv vectors> -> read ids
+__global__ void count_some_kernel(const uint8_t* status, uint32_t n, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long b = __ballot(i < n && status[i] == ZSW_STATUS_SOME);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (uint32_t)__popcll(b));
+}
+
+// (tier, length) of the listed reads
+__global__ void gather_meta_kernel(BatchDev b, const uint8_t* tier, const uint32_t* ids, uint32_t n_ids, uint32_t* meta) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_ids) return;
+    const uint32_t id = ids[k];
+    meta[2 * k] = tier[id];
+    meta[2 * k + 1] = b.offsets ? (uint32_t)(b.offsets[id + 1] - b.offsets[id]) : b.fixed_len;
+}
 
 // lanes_w*: lane count of the profile whose width answered (direct call: the caller's N for its one width).
 zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, int lanes_w8, int lanes_w16, int lanes_w32,
@@ -426,50 +440,55 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
                                 (uint32_t)ctx->ref_len, rule, so, score_ws(ctx), stream, nullptr, 1);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align pass 1", e);
 
-    // group the reads that have an alignment by the <N, nv> of the instantiation that answered
-    std::vector<uint8_t> h_status(n), h_tier(n);
-    std::vector<uint32_t> h_rend(n);
-    ZSW_HIP(ctx, hipMemcpyAsync(h_rend.data(), so.ref_end, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-    ZSW_HIP(ctx, hipMemcpyAsync(h_status.data(), so.status, n, hipMemcpyDeviceToHost, stream));
-    ZSW_HIP(ctx, hipMemcpyAsync(h_tier.data(), so.tier, n, hipMemcpyDeviceToHost, stream));
-    std::vector<uint64_t> h_off;
-    const uint64_t* offs = nullptr;
-    if (reads->offsets) {
-        if (host) {
-            offs = reads->offsets;
-        } else {
-            h_off.resize((size_t)n + 1);
-            ZSW_HIP(ctx, hipMemcpyAsync(h_off.data(), reads->offsets, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, stream));
-            offs = h_off.data();
-        }
-    }
-    ZSW_HIP(ctx, hipStreamSynchronize(stream));
-    auto key_of = [&](uint32_t i) {
-        const int N = h_tier[i] == 8 ? lanes_w8 : h_tier[i] == 16 ? lanes_w16 : lanes_w32;
-        const uint32_t len = offs ? (uint32_t)(offs[i + 1] - offs[i]) : reads->fixed_len;
-        return std::make_pair(N, (len + (uint32_t)N - 1) / (uint32_t)N);
+    // Group the reads that have an alignment by the <N, nv> of the instantiation that answered and order each group by its
+    // reference end row — on the device (zsw_group.hip); only the table of group starts comes back to the host.
+    // Reads that share a wavefront walk the reference rows together: ordering by r_end makes their high-scoring rows (where
+    // Zoe's lazy-F loop runs long) coincide and bounds the rows a wave computes by nearly the same r_end for all its reads.
+    struct GroupRun {
+        int N;
+        uint32_t nv, start, count;
     };
-    Groups groups;
-    for (uint32_t i = 0; i < n; ++i)
-        if (h_status[i] == ZSW_STATUS_SOME) groups[key_of(i)].push_back(i);
-    // Reads that share a wavefront walk the reference rows together; ordering each group by its reference end row
-    // makes their high-scoring rows (where Zoe's lazy-F loop runs long) coincide and bounds the rows a wave computes
-    // by nearly the same r_end for all of its reads. Counting sort, O(n + R).
+    const uint32_t TABLE_CAP = 1u << 16;
+    ZSW_HIP(ctx, ws[WS_ITEMS].ensure((size_t)n * 4 + 4));
+    ZSW_HIP(ctx, ws[WS_KEYS_IN].ensure((size_t)n * 8 + 8));
+    ZSW_HIP(ctx, ws[WS_KEYS_OUT].ensure((size_t)n * 8 + 8));
+    ZSW_HIP(ctx, ws[WS_VALS_IN].ensure((size_t)n * 4 + 4));
+    const size_t sort_bytes = group_temp_bytes(n);
+    ZSW_HIP(ctx, ws[WS_SORT_TMP].ensure(sort_bytes + 256));
+    ZSW_HIP(ctx, ws[WS_GTABLE].ensure((size_t)TABLE_CAP * 8 + 8));
+    e = group_reads(st.b, so.status, so.tier, so.ref_end, lanes_w8, lanes_w16, lanes_w32, ws[WS_KEYS_IN].as<uint64_t>(),
+                    ws[WS_KEYS_OUT].as<uint64_t>(), ws[WS_VALS_IN].as<uint32_t>(), ws[WS_ITEMS].as<uint32_t>(), ws[WS_SORT_TMP].p,
+                    sort_bytes, ws[WS_GTABLE].as<uint32_t>() + 2, ws[WS_GTABLE].as<uint32_t>(), TABLE_CAP - 1, stream);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align grouping", e);
+    uint32_t n_groups = 0;
+    ZSW_HIP(ctx, hipMemcpyAsync(&n_groups, ws[WS_GTABLE].p, 4, hipMemcpyDeviceToHost, stream));
+    ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    if (n_groups > TABLE_CAP - 1) return fail(ctx, ZSW_ERR_UNSUPPORTED, "more than 65535 distinct <lanes, vectors> groups in one call");
+    std::vector<uint32_t> h_table((size_t)n_groups * 2 + 2);
+    uint32_t n_some = 0;
+    if (n_groups) ZSW_HIP(ctx, hipMemcpy(h_table.data(), ws[WS_GTABLE].as<uint32_t>() + 2, (size_t)n_groups * 8, hipMemcpyDeviceToHost));
+    std::vector<GroupRun> groups;
     {
-        std::vector<uint32_t> cnt, tmp;
-        for (auto& g : groups) {
-            std::vector<uint32_t>& ids = g.second;
-            cnt.assign(ctx->ref_len + 2, 0);
-            for (uint32_t id : ids) ++cnt[std::min<size_t>(h_rend[id], ctx->ref_len) + 1];
-            for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
-            tmp.resize(ids.size());
-            for (uint32_t id : ids) tmp[cnt[std::min<size_t>(h_rend[id], ctx->ref_len)]++] = id;
-            ids.swap(tmp);
+        // sort the table by start (atomic slots are unordered) and derive the counts; the last group ends where the reads
+        // without an alignment (key ~0) begin, i.e. at the number of SOME statuses (counted on the device)
+        std::vector<std::pair<uint32_t, uint32_t>> t;  // (start, N<<24|nv)
+        for (uint32_t k = 0; k < n_groups; ++k) t.emplace_back(h_table[2 * k + 1], h_table[2 * k]);
+        std::sort(t.begin(), t.end());
+        if (!t.empty()) {
+            ZSW_HIP(ctx, ws[WS_FBCOUNT].ensure(4));
+            ZSW_HIP(ctx, hipMemsetAsync(ws[WS_FBCOUNT].p, 0, 4, stream));
+            hipLaunchKernelGGL(count_some_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, so.status, n, ws[WS_FBCOUNT].as<uint32_t>());
+            ZSW_HIP(ctx, hipMemcpyAsync(&n_some, ws[WS_FBCOUNT].p, 4, hipMemcpyDeviceToHost, stream));
+            ZSW_HIP(ctx, hipStreamSynchronize(stream));
+        }
+        for (size_t k = 0; k < t.size(); ++k) {
+            const uint32_t end = k + 1 < t.size() ? t[k + 1].first : n_some;
+            groups.push_back(GroupRun{(int)(t[k].second >> 24), t[k].second & 0xffffffu, t[k].first, end - t[k].first});
         }
     }
     const int S = ctx->h_sc.S;
     for (auto& g : groups)
-        if (align_lds_need(g.first.second, S) + 4352 + 64 > 160 * 1024)
+        if (align_lds_need(g.nv, S) + 4352 + 64 > 160 * 1024)
             return fail(ctx, ZSW_ERR_UNSUPPORTED, "read too long for the alignment kernel's LDS-resident profile");
 
     const uint32_t MAXC = 32;
@@ -478,67 +497,50 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     ZSW_HIP(ctx, ws[WS_CIGRAW].ensure((size_t)n * 4));
     ZSW_HIP(ctx, ws[WS_FBLIST].ensure((size_t)n * 4 + 4));
     ZSW_HIP(ctx, ws[WS_FBCOUNT].ensure(4));
-    ZSW_HIP(ctx, ws[WS_ITEMS].ensure((size_t)n * 4 + 4));
     ZSW_HIP(ctx, ws[WS_CIG].ensure((size_t)n * MAXC * 4));
     ZSW_HIP(ctx, hipMemsetAsync(ws[WS_FBCOUNT].p, 0, 4, stream));
 
-    auto run_groups = [&](Groups& gs, bool full, DevBuf& ringbuf, DevBuf& cigbuf) -> zsw_error {
-        std::vector<uint32_t> all;
-        for (auto& g : gs) all.insert(all.end(), g.second.begin(), g.second.end());
-        if (all.empty()) return ZSW_OK;
-        ZSW_HIP(ctx, hipMemcpyAsync(ws[WS_ITEMS].p, all.data(), all.size() * 4, hipMemcpyHostToDevice, stream));
-        ZSW_HIP(ctx, hipStreamSynchronize(stream));  // `all` is a temporary
-        if (full) {
-            uint64_t need = 0;
-            for (auto& g : gs) need += (uint64_t)g.second.size() * ((uint64_t)g.first.first * g.first.second + ctx->ref_len + 4);
-            ZSW_HIP(ctx, cigbuf.ensure(need * 4));
+    auto window_of = [&](const GroupRun& g, bool full) {
+        const uint32_t lpad = g.nv * (uint32_t)g.N;
+        uint32_t W = full ? (uint32_t)ctx->ref_len : std::min<uint32_t>((uint32_t)ctx->ref_len, lpad + std::max<uint32_t>(32, lpad / 4));
+        return W ? W : 1u;
+    };
+    auto grid_of = [&](const GroupRun& g, bool full) {
+        const uint32_t rpw = 64 / (uint32_t)g.N;
+        uint32_t grid = std::min<uint32_t>((g.count + rpw - 1) / rpw, full ? 256u : 4096u);
+        while (grid > 1 && align_ring_bytes(g.N, g.nv, window_of(g, full), grid) > (size_t(3) << 30)) grid /= 2;
+        return grid;
+    };
+    // one ring per pass, shared by its launches (they run in order on one stream): size it for the largest group up front
+    auto run_groups = [&](const std::vector<GroupRun>& gs, const uint32_t* d_items, bool full, DevBuf& ringbuf, DevBuf& cigbuf) -> zsw_error {
+        if (gs.empty()) return ZSW_OK;
+        size_t ring_need = 0;
+        uint64_t pool_need = 0;
+        for (auto& g : gs) {
+            ring_need = std::max(ring_need, align_ring_bytes(g.N, g.nv, window_of(g, full), grid_of(g, full)));
+            pool_need += (uint64_t)g.count * ((uint64_t)g.N * g.nv + ctx->ref_len + 4);
         }
-        size_t pos = 0;
+        ZSW_HIP(ctx, ringbuf.ensure(ring_need + 64));
+        if (full) ZSW_HIP(ctx, cigbuf.ensure(pool_need * 4));
         uint64_t pool = 0;
         for (auto& g : gs) {
-            const int N = g.first.first;
-            const uint32_t nv = g.first.second;
-            const uint32_t cnt = (uint32_t)g.second.size();
-            const uint32_t rpw = 64 / (uint32_t)N;
-            const uint32_t lpad = nv * (uint32_t)N;
-            uint32_t W = full ? (uint32_t)ctx->ref_len : std::min<uint32_t>((uint32_t)ctx->ref_len, lpad + std::max<uint32_t>(32, lpad / 4));
-            if (W == 0) W = 1;
-            const uint32_t maxc = full ? lpad + (uint32_t)ctx->ref_len + 4 : MAXC;
-            uint32_t grid = std::min<uint32_t>((cnt + rpw - 1) / rpw, full ? 256u : 4096u);
-            while (grid > 1 && align_ring_bytes(N, nv, W, grid) > (size_t(3) << 30)) grid /= 2;
-            // one ring per launch; launches on one stream run in order, so the buffer can be shared but must be
-            // large enough for the biggest group: size it before the first launch
-            ZSW_HIP(ctx, ringbuf.ensure(align_ring_bytes(N, nv, W, grid)));
+            const uint32_t W = window_of(g, full);
+            const uint32_t maxc = full ? g.nv * (uint32_t)g.N + (uint32_t)ctx->ref_len + 4 : MAXC;
             BatchDev b = st.b;
-            b.items = ws[WS_ITEMS].as<uint32_t>() + pos;
-            b.n_items = cnt;
-            hipError_t he = align_pass2(N, nv, b, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len, ctx->d_sc.as<ScoringDev>(), S,
-                                        so.score, so.ref_end, so.status, W, maxc, ringbuf.as<uint8_t>(), grid,
+            b.items = d_items + g.start;
+            b.n_items = g.count;
+            hipError_t he = align_pass2(g.N, g.nv, b, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len, ctx->d_sc.as<ScoringDev>(), S,
+                                        so.score, so.ref_end, so.status, W, maxc, ringbuf.as<uint8_t>(), grid_of(g, full),
                                         cigbuf.as<uint32_t>(), pool, full ? 1 : 0, ws[WS_CIGSTART].as<uint64_t>(),
                                         ws[WS_CIGRAW].as<uint32_t>(), ws[WS_ALN].as<zsw_alignment>(),
                                         ws[WS_FBLIST].as<uint32_t>(), ws[WS_FBCOUNT].as<uint32_t>(), invert, stream);
             if (he != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align pass 2", he);
-            if (full) pool += (uint64_t)cnt * maxc;
-            pos += cnt;
+            if (full) pool += (uint64_t)g.count * maxc;
         }
         return ZSW_OK;
     };
-    // DevBuf::ensure frees and reallocates: size the shared ring for the largest group up front
-    {
-        size_t ring_need = 0;
-        for (auto& g : groups) {
-            const int N = g.first.first;
-            const uint32_t nv = g.first.second, rpw = 64 / (uint32_t)N, lpad = nv * (uint32_t)N;
-            uint32_t W = std::min<uint32_t>((uint32_t)ctx->ref_len, lpad + std::max<uint32_t>(32, lpad / 4));
-            if (W == 0) W = 1;
-            uint32_t grid = std::min<uint32_t>(((uint32_t)g.second.size() + rpw - 1) / rpw, 4096u);
-            while (grid > 1 && align_ring_bytes(N, nv, W, grid) > (size_t(3) << 30)) grid /= 2;
-            ring_need = std::max(ring_need, align_ring_bytes(N, nv, W, grid));
-        }
-        ZSW_HIP(ctx, ws[WS_RING].ensure(ring_need + 64));
-    }
     ctx->timer.begin(stream);
-    zsw_error ze = run_groups(groups, false, ws[WS_RING], ws[WS_CIG]);
+    zsw_error ze = run_groups(groups, ws[WS_ITEMS].as<uint32_t>(), false, ws[WS_RING], ws[WS_CIG]);
     ctx->timer.end(stream);
     if (ze != ZSW_OK) return ze;
     // reads whose traceback left the retained window (or overflowed their ciglet slots): rerun keeping every row
@@ -546,22 +548,29 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     ZSW_HIP(ctx, hipMemcpyAsync(&n_fb, ws[WS_FBCOUNT].p, 4, hipMemcpyDeviceToHost, stream));
     ZSW_HIP(ctx, hipStreamSynchronize(stream));
     if (n_fb) {
-        std::vector<uint32_t> fb(n_fb);
-        ZSW_HIP(ctx, hipMemcpy(fb.data(), ws[WS_FBLIST].p, (size_t)n_fb * 4, hipMemcpyDeviceToHost));
-        Groups g2;
-        for (uint32_t id : fb) g2[key_of(id)].push_back(id);
-        ZSW_HIP(ctx, hipMemsetAsync(ws[WS_FBCOUNT].p, 0, 4, stream));
-        size_t ring_need = 0;
-        for (auto& g : g2) {
-            const int N = g.first.first;
-            const uint32_t nv = g.first.second, rpw = 64 / (uint32_t)N;
-            uint32_t W = std::max<uint32_t>(1, (uint32_t)ctx->ref_len);
-            uint32_t grid = std::min<uint32_t>(((uint32_t)g.second.size() + rpw - 1) / rpw, 256u);
-            while (grid > 1 && align_ring_bytes(N, nv, W, grid) > (size_t(3) << 30)) grid /= 2;
-            ring_need = std::max(ring_need, align_ring_bytes(N, nv, W, grid));
+        // few reads: fetch their (tier, length) and group them on the host
+        ZSW_HIP(ctx, ws[WS_FBMETA].ensure((size_t)n_fb * 8));
+        hipLaunchKernelGGL(gather_meta_kernel, dim3((n_fb + 255) / 256), dim3(256), 0, stream, st.b, so.tier, ws[WS_FBLIST].as<uint32_t>(),
+                           n_fb, ws[WS_FBMETA].as<uint32_t>());
+        std::vector<uint32_t> fb(n_fb), meta((size_t)n_fb * 2);
+        ZSW_HIP(ctx, hipMemcpyAsync(fb.data(), ws[WS_FBLIST].p, (size_t)n_fb * 4, hipMemcpyDeviceToHost, stream));
+        ZSW_HIP(ctx, hipMemcpyAsync(meta.data(), ws[WS_FBMETA].p, (size_t)n_fb * 8, hipMemcpyDeviceToHost, stream));
+        ZSW_HIP(ctx, hipStreamSynchronize(stream));
+        std::map<std::pair<int, uint32_t>, std::vector<uint32_t>> g2;
+        for (uint32_t k = 0; k < n_fb; ++k) {
+            const int N = meta[2 * k] == 8 ? lanes_w8 : meta[2 * k] == 16 ? lanes_w16 : lanes_w32;
+            g2[std::make_pair(N, (meta[2 * k + 1] + (uint32_t)N - 1) / (uint32_t)N)].push_back(fb[k]);
         }
-        ZSW_HIP(ctx, ws[WS_RING2].ensure(ring_need + 64));
-        ze = run_groups(g2, true, ws[WS_RING2], ws[WS_CIG2]);
+        std::vector<uint32_t> ids;
+        std::vector<GroupRun> runs;
+        for (auto& g : g2) {
+            runs.push_back(GroupRun{g.first.first, g.first.second, (uint32_t)ids.size(), (uint32_t)g.second.size()});
+            ids.insert(ids.end(), g.second.begin(), g.second.end());
+        }
+        ZSW_HIP(ctx, ws[WS_ITEMS2].ensure(ids.size() * 4 + 4));
+        ZSW_HIP(ctx, hipMemcpy(ws[WS_ITEMS2].p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+        ZSW_HIP(ctx, hipMemsetAsync(ws[WS_FBCOUNT].p, 0, 4, stream));
+        ze = run_groups(runs, ws[WS_ITEMS2].as<uint32_t>(), true, ws[WS_RING2], ws[WS_CIG2]);
         if (ze != ZSW_OK) return ze;
         uint32_t again = 0;
         ZSW_HIP(ctx, hipMemcpyAsync(&again, ws[WS_FBCOUNT].p, 4, hipMemcpyDeviceToHost, stream));
