@@ -244,6 +244,41 @@ def cascade_align(from_width: int, preset: int, sc: Scoring, prof_seq, other, ot
     return _aln(st.value, f, buf), tier.value
 
 
+def banded_align(sc: Scoring, prof_seq, other, band_width: int) -> Aln:
+    w, im, a = _sc_args(sc)
+    ps, ot = _u8(prof_seq), _u8(other)
+    st = C.c_uint32(0)
+    f = (C.c_uint64 * 8)()
+    cap = 16 * (len(ps) + len(ot)) + 64
+    buf = C.create_string_buffer(cap)
+    _check(lib().zor_banded_align(*a, _p(ps), C.c_size_t(len(ps)), _p(ot), C.c_size_t(len(ot)), C.c_size_t(band_width), C.byref(st), f, buf, C.c_size_t(cap)))
+    return _aln(st.value, f, buf)
+
+
+def align_3pass(T: str, lanes: int, sc: Scoring, prof_seq, other, other_is_query=False):
+    """profile.sw_align_3pass(SeqSrc::Reference(other), ..) → (Aln, how) with how 0 = no-gaps shortcut, 1 = banded, 2 = scalar."""
+    w, im, a = _sc_args(sc)
+    ps, ot = _u8(prof_seq), _u8(other)
+    st, how = C.c_uint32(0), C.c_int(-1)
+    f = (C.c_uint64 * 8)()
+    cap = 16 * (len(ps) + len(ot)) + 64
+    buf = C.create_string_buffer(cap)
+    _check(lib().zor_align_3pass(TCODE[T], lanes, *a, _p(ps), C.c_size_t(len(ps)), _p(ot), C.c_size_t(len(ot)), int(other_is_query), C.byref(st), f, buf, C.c_size_t(cap), C.byref(how)))
+    return _aln(st.value, f, buf), how.value
+
+
+def cascade_align_3pass(from_width: int, preset: int, sc: Scoring, prof_seq, other, other_is_query=False):
+    """LocalProfiles::new_with_w{preset}(prof_seq).sw_align_from_i{from_width}_3pass(..) → (Aln, tier, how)."""
+    w, im, a = _sc_args(sc)
+    ps, ot = _u8(prof_seq), _u8(other)
+    st, tier, how = C.c_uint32(0), C.c_int(0), C.c_int(-1)
+    f = (C.c_uint64 * 8)()
+    cap = 16 * (len(ps) + len(ot)) + 64
+    buf = C.create_string_buffer(cap)
+    _check(lib().zor_cascade_align_3pass(from_width, preset, *a, _p(ps), C.c_size_t(len(ps)), _p(ot), C.c_size_t(len(ot)), int(other_is_query), C.byref(st), f, buf, C.c_size_t(cap), C.byref(tier), C.byref(how)))
+    return _aln(st.value, f, buf), tier.value, how.value
+
+
 def profile_dump(T: str, lanes: int, sc: Scoring, seq, rev_end: int = 0) -> np.ndarray:
     """StripedProfile::new(seq) (or .reverse_from_forward(rev_end)) as int64 [S, nv, lanes]."""
     w, im, a = _sc_args(sc)

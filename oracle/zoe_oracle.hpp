@@ -801,6 +801,174 @@ inline Maybe<Alignment> sw_scalar_align(const uint8_t* reference, size_t ref_len
     return out;
 }
 
+// ---- AlignmentStates helpers used by the 3-pass path (state.rs:156-166, 201-208, 244-246) ----
+inline void prepend_ciglet(AlignmentStates& st, Ciglet g) {
+    if (g.inc > 0) {
+        if (!st.c.empty() && st.c.front().op == g.op)
+            st.c.front().inc += g.inc;
+        else
+            st.c.insert(st.c.begin(), g);
+    }
+}
+inline AlignmentStates new_no_gaps(size_t start, size_t end, size_t query_len) {
+    AlignmentStates st;
+    st.soft_clip(start);
+    st.add_ciglet({end - start, 'M'});
+    st.soft_clip(query_len - end);
+    return st;
+}
+
+// ---- sw_banded_align (sw/banded.rs:40-133) with BandedBacktrackMatrix (types/backtrack.rs:541-635) ----
+// Returns UNMAPPED when the reference would panic on an out-of-band traceback index (never a result there).
+inline Maybe<Alignment> sw_banded_align(const uint8_t* reference, size_t ref_len, const ScalarProfile& q, size_t band_width) {
+    Maybe<Alignment> out;
+    if (ref_len == 0) {
+        out.status = UNMAPPED;
+        return out;
+    }
+    int32_t best_score = 0;
+    size_t r_end = 0, c_end = 0;
+    const size_t q_len = q.len;
+    std::vector<int32_t> h_row(q_len, 0), e_row(q_len, q.gap_open);
+    const size_t full = 2 * band_width + 1;
+    std::vector<uint8_t> bt(ref_len * full, 0);
+    auto cursor_of = [&](size_t r, size_t c, bool* ok) -> size_t {  // BandedBacktrackMatrix::move_to (:629-634)
+        const size_t skipped = r > band_width ? r - band_width : 0;
+        if (c < skipped) {
+            *ok = false;  // usize underflow: the reference panics
+            return 0;
+        }
+        const size_t cur = r * full + (c - skipped);
+        if (cur >= bt.size()) *ok = false;
+        return cur;
+    };
+    int32_t h_store = 0;
+    for (size_t r = 0; r < ref_len; ++r) {
+        int32_t f = q.gap_open;
+        int32_t h = h_store;
+        const size_t start_col = r > band_width ? r - band_width : 0;
+        const size_t end_col = std::min(r + band_width + 1, q_len);
+        if (start_col >= end_col) break;
+        if (start_col + band_width == r) {
+            const int32_t match_score = q.weight(reference[r], q.seq[start_col]);
+            const int32_t e = e_row[start_col];
+            h_store = std::max(std::max(h + match_score, e), 0);
+        }
+        for (size_t c = start_col; c < end_col; ++c) {
+            bool ok = true;
+            uint8_t& cell = bt[cursor_of(r, c, &ok)];
+            h += q.weight(reference[r], q.seq[c]);
+            int32_t e = e_row[c];
+            h = std::max(std::max(std::max(h, e), f), 0);
+            if (h > best_score) {
+                best_score = h;
+                r_end = r;
+                c_end = c;
+            }
+            if (e == h) cell |= BT_UP;
+            if (f == h) cell |= BT_LEFT;
+            if (h == 0) cell = BT_STOP;
+            const int32_t next_diag = h_row[c];
+            h_row[c] = h;
+            h += q.gap_open;
+            e = std::max(e + q.gap_extend, h);
+            f = std::max(f + q.gap_extend, h);
+            if (h != q.gap_open) {
+                if (e > h) cell |= BT_UP_EXTENDING;
+                if (f > h) cell |= BT_LEFT_EXTENDING;
+            }
+            h = next_diag;
+            e_row[c] = e;
+        }
+    }
+    if (best_score == 0) {
+        out.status = UNMAPPED;
+        return out;
+    }
+    bool ok = true;
+    auto cell = [&](size_t r, size_t c) -> uint8_t {
+        const size_t cur = cursor_of(r, c, &ok);
+        return ok ? bt[cur] : BT_STOP;
+    };
+    out.value = to_alignment(cell, uint32_t(best_score), r_end, c_end, ref_len, q_len);
+    out.status = ok ? SOME : UNMAPPED;
+    return out;
+}
+
+// ---- sw_align_3pass (sw/three_pass.rs:21-104) ----
+template <typename T, int N>
+Maybe<Alignment> sw_align_3pass(const uint8_t* reference, size_t ref_len, const StripedProfile<T, N>& query_profile,
+                                const uint8_t* query, size_t query_len, const WeightMatrixI8& matrix, const ByteIndexMap& map,
+                                int gap_open, int gap_extend, int* how = nullptr) {
+    Maybe<Alignment> out;
+    auto sr = sw_simd_score_ranges<T, N>(reference, ref_len, query_profile);
+    if (sr.status != SOME) {
+        out.status = sr.status;
+        return out;
+    }
+    const uint32_t score = sr.value.score;
+    const size_t rs = sr.value.ref_start, re = sr.value.ref_end, qs = sr.value.query_start, qe = sr.value.query_end;
+    if (qs >= qe) {
+        out.status = UNMAPPED;
+        return out;
+    }
+    ScalarProfile whole{query, query_len, &matrix, &map, gap_open, gap_extend};
+    if (qe - qs == re - rs) {
+        int64_t sum = 0;
+        for (size_t k = 0; k < qe - qs; ++k) sum += whole.weight(reference[rs + k], query[qs + k]);
+        const uint32_t usum = sum < 0 ? 0u : uint32_t(sum);  // try_into().unwrap_or(0)
+        if (usum == score) {
+            out.status = SOME;
+            out.value.score = score;
+            out.value.ref_start = rs;
+            out.value.ref_end = re;
+            out.value.query_start = qs;
+            out.value.query_end = qe;
+            out.value.states = new_no_gaps(qs, qe, query_len);
+            out.value.ref_len = ref_len;
+            out.value.query_len = query_len;
+            if (how) *how = 0;
+            return out;
+        }
+    }
+    ScalarProfile query_new{query + qs, qe - qs, &matrix, &map, gap_open, gap_extend};
+    const uint8_t* reference_new = reference + rs;
+    const size_t rlen = re - rs, qlen = qe - qs;
+    size_t band_width = (rlen > qlen ? rlen - qlen : qlen - rlen) + 1;
+    const size_t max_bandwidth = (qlen - 1) / 2;
+    Maybe<Alignment> inner;
+    bool have = false;
+    while (band_width <= max_bandwidth) {
+        Maybe<Alignment> b = sw_banded_align(reference_new, rlen, query_new, band_width);
+        if (b.status == SOME && b.value.score == score) {
+            inner = b;
+            have = true;
+            if (how) *how = 1;
+            break;
+        }
+        band_width *= 2;
+    }
+    if (!have) {
+        inner = sw_scalar_align(reference_new, rlen, query_new);
+        if (how) *how = 2;
+    }
+    Alignment a = inner.value;
+    const size_t aq_start = a.query_start + qs, aq_end = a.query_end + qs;
+    const size_t ar_start = a.ref_start + rs, ar_end = a.ref_end + rs;
+    prepend_ciglet(a.states, {aq_start, 'S'});         // prepend_soft_clip (state.rs:244-246)
+    a.states.soft_clip(query_len - aq_end);
+    out.status = SOME;
+    out.value.score = score;
+    out.value.ref_start = ar_start;
+    out.value.ref_end = ar_end;
+    out.value.query_start = aq_start;
+    out.value.query_end = aq_end;
+    out.value.states = a.states;
+    out.value.ref_len = ref_len;
+    out.value.query_len = query_len;
+    return out;
+}
+
 // ---- sw_score_from_path (sw/mod.rs:399-454); returns -1 on any ScoringError ----
 inline int64_t sw_score_from_path(const std::vector<Ciglet>& ciglets, const uint8_t* ref_in_alignment, size_t ref_n,
                                   const ScalarProfile& q) {

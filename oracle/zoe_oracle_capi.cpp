@@ -294,6 +294,59 @@ int zor_cascade_align(int from_width, int preset, int S, const int8_t* weights, 
     return 0;
 }
 
+// sw_banded_align (banded.rs:40-133) with a ScalarProfile built from prof_seq
+int zor_banded_align(int S, const int8_t* weights, const uint8_t* index_map, int gap_open, int gap_extend, const uint8_t* prof_seq,
+                     size_t prof_len, const uint8_t* other, size_t other_len, size_t band_width, uint32_t* out_status,
+                     uint64_t* out_fields, char* cigar_buf, size_t cigar_cap) {
+    int e = validate_profile_args(prof_len, gap_open, gap_extend);
+    if (e) return e;
+    Ctx c = make_ctx(S, weights, index_map);
+    ScalarProfile q{prof_seq, prof_len, &c.wm, &c.map, gap_open, gap_extend};
+    auto m = sw_banded_align(other, other_len, q, band_width);
+    put_alignment(m, false, out_status, out_fields, cigar_buf, cigar_cap);
+    return 0;
+}
+
+// StripedProfile::<T,N,S>::new(prof_seq).sw_align_3pass(SeqSrc::Reference(other) | Query, prof_seq, matrix, go, ge)
+// (profile.rs:546-552 → three_pass.rs:21-104). out_how: 0 no-gaps shortcut, 1 banded, 2 scalar fallback.
+int zor_align_3pass(int tcode, int lanes, int S, const int8_t* weights, const uint8_t* index_map, int gap_open, int gap_extend,
+                    const uint8_t* prof_seq, size_t prof_len, const uint8_t* other, size_t other_len, int other_is_query,
+                    uint32_t* out_status, uint64_t* out_fields, char* cigar_buf, size_t cigar_cap, int* out_how) {
+    int e = validate_profile_args(prof_len, gap_open, gap_extend);
+    if (e) return e;
+    Ctx c = make_ctx(S, weights, index_map);
+    return dispatch(tcode, lanes, [&](auto t, auto n) -> int {
+        using T = decltype(t);
+        constexpr int N = decltype(n)::value;
+        ProfileWeights pw = ProfileWeights::from(c.wm, Int<T>::SIGNED);
+        auto p = StripedProfile<T, N>::make(prof_seq, prof_len, pw, c.map, gap_open, gap_extend);
+        int how = -1;
+        auto m = sw_align_3pass<T, N>(other, other_len, p, prof_seq, prof_len, c.wm, c.map, gap_open, gap_extend, &how);
+        if (out_how) *out_how = how;
+        put_alignment(m, other_is_query != 0, out_status, out_fields, cigar_buf, cigar_cap);
+        return 0;
+    });
+}
+
+// ProfileSets::sw_align_from_i{8,16,32}_3pass (profile_set.rs:212-283)
+int zor_cascade_align_3pass(int from_width, int preset, int S, const int8_t* weights, const uint8_t* index_map, int gap_open,
+                            int gap_extend, const uint8_t* prof_seq, size_t prof_len, const uint8_t* other, size_t other_len,
+                            int other_is_query, uint32_t* out_status, uint64_t* out_fields, char* cigar_buf, size_t cigar_cap,
+                            int* out_tier, int* out_how) {
+    int e = validate_profile_args(prof_len, gap_open, gap_extend);
+    if (e) return e;
+    const int widths[3] = {8, 16, 32};
+    for (int k = 0; k < 3; ++k) {
+        if (widths[k] < from_width) continue;
+        int rc = zor_align_3pass(k, preset / widths[k], S, weights, index_map, gap_open, gap_extend, prof_seq, prof_len, other,
+                                 other_len, other_is_query, out_status, out_fields, cigar_buf, cigar_cap, out_how);
+        if (rc) return rc;
+        *out_tier = widths[k];
+        if (*out_status != OVERFLOWED) break;
+    }
+    return 0;
+}
+
 // sw_score_from_path over a CIGAR string; -1 on any ScoringError
 long long zor_score_from_path(int S, const int8_t* weights, const uint8_t* index_map, int gap_open, int gap_extend,
                               const uint8_t* query, size_t query_len, const uint8_t* ref_in_alignment, size_t ref_n,

@@ -124,3 +124,24 @@ def test_config0_10k_reads_cpu(oracle):
     for i in range(0, 10000, 500):
         assert oracle.scalar_score(sc, reads[i], ref) == (int(st8[i]), int(s8[i]))
         assert oracle.score("i16", 16, sc, reads[i], ref) == (int(st8[i]), int(s8[i]))
+
+
+@pytest.mark.parametrize("scheme", [(2, -5, -10, -1), (4, -2, -3, -1), (3, -1, -4, -1)])
+def test_three_pass_is_a_valid_optimal_alignment(oracle, scheme):
+    """sw_align_3pass (three_pass.rs:21-104): same score as the striped path, a CIGAR that re-scores to it, all three
+    routes exercised (no-gaps shortcut, banded, scalar fallback)."""
+    ma, mi, go, ge = scheme
+    sc = oracle.dna_scoring(ma, mi, b"N", go, ge)
+    rng = np.random.default_rng(abs(hash(scheme)) % (2**32))
+    hows = set()
+    for read, ref in rand_pairs(rng, 150, ref_len=(60, 200), read_len=(12, 70)):
+        a, how = oracle.align_3pass("i16", 16, sc, read, ref)
+        st, s = oracle.score("i16", 16, sc, read, ref)
+        assert a.status == st
+        if st == S_:
+            hows.add(how)
+            assert a.score == s
+            assert oracle.score_from_path(sc, read, ref[a.ref_range[0] : a.ref_range[1]], a.cigar) == s
+            if how == 0:
+                assert "D" not in a.cigar and "I" not in a.cigar
+    assert 0 in hows and (1 in hows or 2 in hows)

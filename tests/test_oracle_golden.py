@@ -266,3 +266,21 @@ def test_score_from_path(oracle):
     reference, q = b"ATTCCTTTTGCCGGG", b"ATTGCGCCCGG"
     a = oracle.scalar_align(sc, q, reference)
     assert oracle.score_from_path(sc, q, reference[a.ref_range[0] : a.ref_range[1]], a.cigar) == a.score
+
+
+def test_three_pass_and_banded_vectors(oracle):
+    # src/alignment/profile_set.rs:183-209 (sw_align_from_i8_3pass doctest): score 26
+    sc = dna(oracle, 4, -2, -3, -1)
+    a, tier, how = oracle.cascade_align_3pass(8, 256, sc, QRY_A, REF_A)
+    assert (a.status, a.score, tier) == (S_, 26, 8)
+    assert oracle.score_from_path(sc, QRY_A, REF_A[a.ref_range[0] : a.ref_range[1]], a.cigar) == 26
+    # src/alignment/sw/test.rs:364-381 (test_banded_sw_align_simple): score 10; :383-392 empty sequences
+    sc2 = dna(oracle, 2, -1, -2, -1)
+    b = oracle.banded_align(sc2, b"AACCGG", b"AAACCCGGG", 3)
+    assert (b.status, b.score) == (S_, 10) and b.ref_range[1] > b.ref_range[0] and b.query_range[1] > b.query_range[0]
+    assert oracle.banded_align(sc2, b"ACGT", b"", 3).status == U_
+    with pytest.raises(oracle.ProfileError):
+        oracle.banded_align(sc2, b"", b"ACGT", 3)
+    # a band as wide as both sequences reproduces the scalar alignment (sw/test.rs:313-345 compares them loosely)
+    sc3 = dna(oracle, 4, -2, -3, -1)
+    assert oracle.banded_align(sc3, b"CTCAGATTG", b"GGCCACAGGATTGAG", 15).key() == oracle.scalar_align(sc3, b"CTCAGATTG", b"GGCCACAGGATTGAG").key()
