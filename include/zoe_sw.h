@@ -143,6 +143,19 @@ zsw_error zsw_align_batch_from(zsw_context* ctx, const zsw_batch* reads, int fro
                                zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
                                uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream);
 
+/* ---- 3-pass alignment ---------------------------------------------------------------------- */
+/* sw_align_3pass (src/alignment/sw/three_pass.rs:21-104; profile.rs:546-552): score ranges first, then the no-gaps shortcut,
+ * a doubling banded alignment (sw/banded.rs:40-133) or the scalar alignment (sw/scalar.rs:173-271) inside the bounding box.
+ * Same outputs as zsw_align_batch; like in the reference the CIGAR may differ from sw_simd_align's where several optimal
+ * alignments exist (the score and validity do not). */
+zsw_error zsw_align_3pass_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, int invert,
+                                zsw_alignment* out_aln, uint8_t* out_status, uint32_t* out_inc, uint8_t* out_op,
+                                uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream);
+/* ProfileSets::sw_align_from_i{8,16,32}_3pass (src/alignment/profile_set.rs:212-283) */
+zsw_error zsw_align_3pass_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, int invert,
+                                     zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
+                                     uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream);
+
 /* ---- bench/test utilities (not part of the reference surface) ------------------------------ */
 /* Counter-based synthetic reads: read i depends only on (seed, i, reference), so any
  * shard regenerates its own slice. Writes reads [first, first+n) of length `len` into out (device). */

@@ -369,7 +369,7 @@ class _ProfileBatchBase:
         self.ctx.set_scoring(self.matrix, self.gap_open, self.gap_extend)
         self.ctx.set_reference(reference)
 
-    def _align(self, seq: SeqSrc, direct, from_width=None, preset=None) -> AlignmentBatch:
+    def _align(self, seq: SeqSrc, direct, from_width=None, preset=None, three_pass: bool = False) -> AlignmentBatch:
         torch = _torch()
         self._prep(seq.seq)
         n = self.reads.n_reads
@@ -383,11 +383,13 @@ class _ProfileBatchBase:
         while True:
             inc = torch.zeros(cap, dtype=torch.int32, device=dev)
             op = torch.zeros(cap, dtype=torch.uint8, device=dev)
+            fn_direct = self.ctx.lib.zsw_align_3pass_batch if three_pass else self.ctx.lib.zsw_align_batch
+            fn_from = self.ctx.lib.zsw_align_3pass_batch_from if three_pass else self.ctx.lib.zsw_align_batch_from
             if direct is not None:
-                rc = self.ctx.lib.zsw_align_batch(self.ctx.h, C.byref(b), direct[0], direct[1], int(seq.is_query), aln.data_ptr(),
+                rc = fn_direct(self.ctx.h, C.byref(b), direct[0], direct[1], int(seq.is_query), aln.data_ptr(),
                                                   status.data_ptr(), inc.data_ptr(), op.data_ptr(), cap, C.byref(total), self.ctx.stream())
             else:
-                rc = self.ctx.lib.zsw_align_batch_from(self.ctx.h, C.byref(b), from_width, preset, int(seq.is_query), aln.data_ptr(),
+                rc = fn_from(self.ctx.h, C.byref(b), from_width, preset, int(seq.is_query), aln.data_ptr(),
                                                        status.data_ptr(), tier.data_ptr(), inc.data_ptr(), op.data_ptr(), cap,
                                                        C.byref(total), self.ctx.stream())
             if rc == -1 and total.value > cap:
@@ -470,6 +472,10 @@ class StripedProfileBatch(_ProfileBatchBase):
         """profile.rs:515-519 → sw_simd_align (striped.rs:449-598)"""
         return self._align(seq, (_lib.INT_TYPES[self.T], self.N))
 
+    def sw_align_3pass(self, seq: SeqSrc) -> AlignmentBatch:
+        """profile.rs:546-552 → sw_align_3pass (three_pass.rs:21-104)"""
+        return self._align(seq, (_lib.INT_TYPES[self.T], self.N), three_pass=True)
+
 
 class LocalProfilesBatch(_ProfileBatchBase):
     """`LocalProfiles::new_with_w{128,256,512}(read_i, &matrix, gap_open, gap_extend)` for every read."""
@@ -521,6 +527,16 @@ class LocalProfilesBatch(_ProfileBatchBase):
 
     def sw_align_from_i16(self, seq: SeqSrc) -> AlignmentBatch:
         return self._align(seq, None, 16, self.preset)
+
+    def sw_align_from_i8_3pass(self, seq: SeqSrc) -> AlignmentBatch:
+        """profile_set.rs:212-229 → sw_align_3pass (three_pass.rs:21-104)"""
+        return self._align(seq, None, 8, self.preset, three_pass=True)
+
+    def sw_align_from_i16_3pass(self, seq: SeqSrc) -> AlignmentBatch:
+        return self._align(seq, None, 16, self.preset, three_pass=True)
+
+    def sw_align_from_i32_3pass(self, seq: SeqSrc) -> AlignmentBatch:
+        return self._align(seq, None, 32, self.preset, three_pass=True)
 
     def sw_align_from_i32(self, seq: SeqSrc) -> AlignmentBatch:
         return self._align(seq, None, 32, self.preset)

@@ -23,4 +23,36 @@ hipError_t group_reads(const BatchDev& b, const uint8_t* d_status, const uint8_t
                        int lanes_w16, int lanes_w32, uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* items_out,
                        void* temp, size_t temp_bytes, uint32_t* table, uint32_t* table_count, uint32_t cap, hipStream_t stream);
 
+// Third pass of sw_align_3pass (zsw_threepass.hip). list == null: classify pass over all reads (resolves the no-gaps
+// shortcut, queues the rest in dp_list); otherwise the DP pass over `list`.
+struct ThreePassArgs {
+    BatchDev b;
+    const uint8_t* ref;
+    uint32_t ref_len;
+    const ScoringDev* sc;
+    const uint32_t* score;  // ranges results, indexed by read id
+    const uint32_t *rs, *re, *qs, *qe;
+    const uint8_t* status;
+    const uint32_t* list;  // read ids that need the DP (class 2), or null: classify pass over all reads
+    const uint32_t* list_count;
+    uint32_t* dp_list;     // classify pass: reads that need the DP
+    uint32_t* dp_count;
+    uint32_t* dp_need_max;  // classify pass: largest slot need (bytes) among them
+    uint8_t* scratch;       // DP pass: slots * slot_bytes
+    uint32_t slots;
+    uint64_t slot_bytes;
+    uint32_t* cig;          // ciglet pool (traceback order), maxc per read
+    uint32_t maxc;
+    uint64_t pool_base;
+    int by_item;
+    uint64_t* cig_start;
+    uint32_t* cig_raw;
+    zsw_alignment* aln;
+    uint32_t* fb_list;      // ciglet overflow / slot too small -> rerun with larger resources
+    uint32_t* fb_count;
+    int invert;
+};
+
+hipError_t launch_threepass(const ThreePassArgs& a, uint32_t grid, hipStream_t stream);
+
 }  // namespace zsw

@@ -309,38 +309,30 @@ __global__ void ranges_combine_kernel(uint32_t n, const uint32_t* fscore, const 
 }
 
 enum { RW_FSCORE = 0, RW_FSTATUS, RW_FREND, RW_FQEND, RW_RSCORE, RW_RSTATUS, RW_RRS, RW_RQS, RW_QEM, RW_GTAB, RW_MIS, RW_O0, RW_O1,
-       RW_O2, RW_O3, RW_O4, RW_O5 };
+       RW_O2, RW_O3, RW_O4, RW_O5, RW_FTIER };
 
-zsw_error run_ranges(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, uint32_t* out_score, uint32_t* out_rs,
-                     uint32_t* out_re, uint32_t* out_qs, uint32_t* out_qe, uint8_t* out_status, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
-    if (!reads || !out_score || !out_rs || !out_re || !out_qs || !out_qe || !out_status)
-        return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
-    const uint32_t n = (uint32_t)reads->n_reads;
-    Staged st;
-    {
-        uint32_t dummy_score = 0;
-        uint8_t dummy_status = 0;
-        zsw_error ze = stage(ctx, reads, stream, false, false, &dummy_score, &dummy_status, nullptr, nullptr, nullptr, &st);
-        if (ze != ZSW_OK) return ze;
-    }
-    if (n == 0) return ZSW_OK;
-    const bool host = reads->mem == ZSW_MEM_HOST;
+struct RangesDev {  // device arrays of sw_simd_score_ranges for every read (library workspace)
+    uint32_t *score, *rs, *re, *qs, *qe;
+    uint8_t *status, *tier;
+};
+
+// forward score+ends (MODE 2), reverse pass on the prefixes, combine; everything stays on the device
+zsw_error ranges_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, hipStream_t stream, RangesDev* out) {
+    const uint32_t n = st.b.n_reads;
     DevBuf* ws = ctx->r_ws;
-    for (int k : {RW_FSCORE, RW_FREND, RW_FQEND, RW_RSCORE, RW_RRS, RW_RQS, RW_QEM}) ZSW_HIP(ctx, ws[k].ensure((size_t)n * 4 + 4));
-    for (int k : {RW_FSTATUS, RW_RSTATUS}) ZSW_HIP(ctx, ws[k].ensure((size_t)n + 4));
+    for (int k : {RW_FSCORE, RW_FREND, RW_FQEND, RW_RSCORE, RW_RRS, RW_RQS, RW_QEM, RW_O0, RW_O1, RW_O2, RW_O3, RW_O4})
+        ZSW_HIP(ctx, ws[k].ensure((size_t)n * 4 + 4));
+    for (int k : {RW_FSTATUS, RW_RSTATUS, RW_O5, RW_FTIER}) ZSW_HIP(ctx, ws[k].ensure((size_t)n + 4));
     ZSW_HIP(ctx, ws[RW_GTAB].ensure(ctx->ref_len * 8 + 8));
     ZSW_HIP(ctx, ws[RW_MIS].ensure(4));
     ScoreOut fo;
     fo.score = ws[RW_FSCORE].as<uint32_t>();
     fo.status = ws[RW_FSTATUS].as<uint8_t>();
-    fo.tier = nullptr;
+    fo.tier = ws[RW_FTIER].as<uint8_t>();
     fo.ref_end = ws[RW_FREND].as<uint32_t>();
     fo.query_end = ws[RW_FQEND].as<uint32_t>();
     fo.fb_list = ctx->d_fb_list.as<uint32_t>();
     fo.fb_count = ctx->d_fb_count.as<uint32_t>();
-    ctx->timer.begin(stream);
     hipError_t e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(),
                                 (uint32_t)ctx->ref_len, rule, fo, score_ws(ctx), stream, nullptr, 2);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "ranges forward pass", e);
@@ -357,30 +349,47 @@ zsw_error run_ranges(zsw_context* ctx, const zsw_batch* reads, const ResultRule&
     e = launch_score_rev(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len,
                          rule, ro, score_ws(ctx), fo.ref_end, ws[RW_QEM].as<uint32_t>(), ws[RW_GTAB].as<uint2>(), stream);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "ranges reverse pass", e);
-    ctx->timer.end(stream);
-    uint32_t *d0 = out_score, *d1 = out_rs, *d2 = out_re, *d3 = out_qs, *d4 = out_qe;
-    uint8_t* d5 = out_status;
-    if (host) {
-        for (int k : {RW_O0, RW_O1, RW_O2, RW_O3, RW_O4}) ZSW_HIP(ctx, ws[k].ensure((size_t)n * 4 + 4));
-        ZSW_HIP(ctx, ws[RW_O5].ensure((size_t)n + 4));
-        d0 = ws[RW_O0].as<uint32_t>();
-        d1 = ws[RW_O1].as<uint32_t>();
-        d2 = ws[RW_O2].as<uint32_t>();
-        d3 = ws[RW_O3].as<uint32_t>();
-        d4 = ws[RW_O4].as<uint32_t>();
-        d5 = ws[RW_O5].as<uint8_t>();
-    }
+    out->score = ws[RW_O0].as<uint32_t>();
+    out->rs = ws[RW_O1].as<uint32_t>();
+    out->re = ws[RW_O2].as<uint32_t>();
+    out->qs = ws[RW_O3].as<uint32_t>();
+    out->qe = ws[RW_O4].as<uint32_t>();
+    out->status = ws[RW_O5].as<uint8_t>();
+    out->tier = fo.tier;
     ZSW_HIP(ctx, hipMemsetAsync(ws[RW_MIS].p, 0, 4, stream));
     hipLaunchKernelGGL(ranges_combine_kernel, dim3(g256), dim3(256), 0, stream, n, fo.score, fo.status, fo.ref_end, fo.query_end,
-                       ro.score, ro.status, ro.ref_end, ro.query_end, d0, d1, d2, d3, d4, d5, ws[RW_MIS].as<uint32_t>());
+                       ro.score, ro.status, ro.ref_end, ro.query_end, out->score, out->rs, out->re, out->qs, out->qe, out->status,
+                       ws[RW_MIS].as<uint32_t>());
     ZSW_HIP(ctx, hipGetLastError());
-    if (host) {
-        uint32_t* outs[5] = {out_score, out_rs, out_re, out_qs, out_qe};
-        uint32_t* devs[5] = {d0, d1, d2, d3, d4};
-        for (int k = 0; k < 5; ++k) ZSW_HIP(ctx, hipMemcpyAsync(outs[k], devs[k], (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-        ZSW_HIP(ctx, hipMemcpyAsync(out_status, d5, n, hipMemcpyDeviceToHost, stream));
-        ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    return ZSW_OK;
+}
+
+zsw_error run_ranges(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, uint32_t* out_score, uint32_t* out_rs,
+                     uint32_t* out_re, uint32_t* out_qs, uint32_t* out_qe, uint8_t* out_status, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!reads || !out_score || !out_rs || !out_re || !out_qs || !out_qe || !out_status)
+        return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
+    const uint32_t n = (uint32_t)reads->n_reads;
+    Staged st;
+    {
+        uint32_t dummy_score = 0;
+        uint8_t dummy_status = 0;
+        zsw_error ze = stage(ctx, reads, stream, false, false, &dummy_score, &dummy_status, nullptr, nullptr, nullptr, &st);
+        if (ze != ZSW_OK) return ze;
     }
+    if (n == 0) return ZSW_OK;
+    RangesDev rd;
+    ctx->timer.begin(stream);
+    zsw_error ze = ranges_device(ctx, st, rule, stream, &rd);
+    ctx->timer.end(stream);
+    if (ze != ZSW_OK) return ze;
+    const hipMemcpyKind kind = reads->mem == ZSW_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    uint32_t* outs[5] = {out_score, out_rs, out_re, out_qs, out_qe};
+    uint32_t* devs[5] = {rd.score, rd.rs, rd.re, rd.qs, rd.qe};
+    for (int k = 0; k < 5; ++k) ZSW_HIP(ctx, hipMemcpyAsync(outs[k], devs[k], (size_t)n * 4, kind, stream));
+    ZSW_HIP(ctx, hipMemcpyAsync(out_status, rd.status, n, kind, stream));
+    if (reads->mem == ZSW_MEM_HOST) ZSW_HIP(ctx, hipStreamSynchronize(stream));
     return ZSW_OK;
 }
 
@@ -401,6 +410,45 @@ __global__ void gather_meta_kernel(BatchDev b, const uint8_t* tier, const uint32
     const uint32_t id = ids[k];
     meta[2 * k] = tier[id];
     meta[2 * k + 1] = b.offsets ? (uint32_t)(b.offsets[id + 1] - b.offsets[id]) : b.fixed_len;
+}
+
+// Shared tail of the alignment entry points: count + scan + packed write of the ciglets (reversal and SeqSrc::Query
+// inversion happen in the writer), then the records/statuses to the caller's arrays.
+zsw_error finish_alignments(zsw_context* ctx, DevBuf* ws, uint32_t n, bool host, const uint8_t* d_status, const uint8_t* d_tier,
+                            int invert, zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
+                            uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, hipStream_t stream) {
+    const uint32_t nblocks = (n + 1023) / 1024;
+    ZSW_HIP(ctx, ws[WS_BSUMS].ensure((size_t)nblocks * 8 + 8));
+    ZSW_HIP(ctx, ws[WS_TOTAL].ensure(8));
+    hipError_t e = align_finalize(ws[WS_ALN].as<zsw_alignment>(), d_status, n, ws[WS_BSUMS].as<uint64_t>(), ws[WS_TOTAL].as<uint64_t>(),
+                                  ws[WS_CIGSTART].as<uint64_t>(), ws[WS_CIGRAW].as<uint32_t>(), invert, nullptr, nullptr, 0, true, stream);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align count", e);
+    uint64_t total = 0;
+    ZSW_HIP(ctx, hipMemcpyAsync(&total, ws[WS_TOTAL].p, 8, hipMemcpyDeviceToHost, stream));
+    ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    *out_n_ciglets = total;
+    if (total > ciglet_cap) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "ciglet capacity too small; required size returned");
+    uint32_t* d_inc = out_inc;
+    uint8_t* d_op = out_op;
+    if (host) {
+        ZSW_HIP(ctx, ws[WS_OINC].ensure(total * 4 + 4));
+        ZSW_HIP(ctx, ws[WS_OOP].ensure(total + 4));
+        d_inc = ws[WS_OINC].as<uint32_t>();
+        d_op = ws[WS_OOP].as<uint8_t>();
+    }
+    e = align_finalize(ws[WS_ALN].as<zsw_alignment>(), d_status, n, ws[WS_BSUMS].as<uint64_t>(), ws[WS_TOTAL].as<uint64_t>(),
+                       ws[WS_CIGSTART].as<uint64_t>(), ws[WS_CIGRAW].as<uint32_t>(), invert, d_inc, d_op, ciglet_cap, false, stream);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align write", e);
+    const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    ZSW_HIP(ctx, hipMemcpyAsync(out_aln, ws[WS_ALN].p, (size_t)n * sizeof(zsw_alignment), kind, stream));
+    ZSW_HIP(ctx, hipMemcpyAsync(out_status, d_status, n, kind, stream));
+    if (out_tier && d_tier) ZSW_HIP(ctx, hipMemcpyAsync(out_tier, d_tier, n, kind, stream));
+    if (host && total) {
+        ZSW_HIP(ctx, hipMemcpyAsync(out_inc, d_inc, total * 4, kind, stream));
+        ZSW_HIP(ctx, hipMemcpyAsync(out_op, d_op, total, kind, stream));
+    }
+    ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    return ZSW_OK;
 }
 
 // lanes_w*: lane count of the profile whose width answered (direct call: the caller's N for its one width).
@@ -578,39 +626,128 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
         if (again) return fail(ctx, ZSW_ERR_HIP, "alignment traceback did not complete with the full window");
     }
 
-    // pack the ciglets: count, scan, write (reversal and SeqSrc::Query inversion happen in the writer)
-    const uint32_t nblocks = (n + 1023) / 1024;
-    ZSW_HIP(ctx, ws[WS_BSUMS].ensure((size_t)nblocks * 8 + 8));
-    ZSW_HIP(ctx, ws[WS_TOTAL].ensure(8));
-    e = align_finalize(ws[WS_ALN].as<zsw_alignment>(), so.status, n, ws[WS_BSUMS].as<uint64_t>(), ws[WS_TOTAL].as<uint64_t>(),
-                       ws[WS_CIGSTART].as<uint64_t>(), ws[WS_CIGRAW].as<uint32_t>(), invert, nullptr, nullptr, 0, true, stream);
-    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align count", e);
-    uint64_t total = 0;
-    ZSW_HIP(ctx, hipMemcpyAsync(&total, ws[WS_TOTAL].p, 8, hipMemcpyDeviceToHost, stream));
-    ZSW_HIP(ctx, hipStreamSynchronize(stream));
-    *out_n_ciglets = total;
-    if (total > ciglet_cap) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "ciglet capacity too small; required size returned");
-    uint32_t* d_inc = out_inc;
-    uint8_t* d_op = out_op;
-    if (host) {
-        ZSW_HIP(ctx, ws[WS_OINC].ensure(total * 4 + 4));
-        ZSW_HIP(ctx, ws[WS_OOP].ensure(total + 4));
-        d_inc = ws[WS_OINC].as<uint32_t>();
-        d_op = ws[WS_OOP].as<uint8_t>();
+    return finish_alignments(ctx, ws, n, host, so.status, so.tier, invert, out_aln, out_status, out_tier, out_inc, out_op, ciglet_cap,
+                             out_n_ciglets, stream);
+}
+
+// sw_align_3pass per read (three_pass.rs:21-104): ranges on the device, then the third pass (zsw_threepass.hip)
+zsw_error run_threepass(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, int invert, zsw_alignment* out_aln,
+                        uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap,
+                        uint64_t* out_n_ciglets, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!reads || !out_aln || !out_status || !out_n_ciglets || (ciglet_cap && (!out_inc || !out_op)))
+        return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
+    const uint32_t n = (uint32_t)reads->n_reads;
+    Staged st;
+    {
+        uint32_t dummy_score = 0;
+        uint8_t dummy_status = 0;
+        zsw_error ze = stage(ctx, reads, stream, false, false, &dummy_score, &dummy_status, nullptr, nullptr, nullptr, &st);
+        if (ze != ZSW_OK) return ze;
     }
-    e = align_finalize(ws[WS_ALN].as<zsw_alignment>(), so.status, n, ws[WS_BSUMS].as<uint64_t>(), ws[WS_TOTAL].as<uint64_t>(),
-                       ws[WS_CIGSTART].as<uint64_t>(), ws[WS_CIGRAW].as<uint32_t>(), invert, d_inc, d_op, ciglet_cap, false, stream);
-    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align write", e);
-    const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    ZSW_HIP(ctx, hipMemcpyAsync(out_aln, ws[WS_ALN].p, (size_t)n * sizeof(zsw_alignment), kind, stream));
-    ZSW_HIP(ctx, hipMemcpyAsync(out_status, so.status, n, kind, stream));
-    if (out_tier) ZSW_HIP(ctx, hipMemcpyAsync(out_tier, so.tier, n, kind, stream));
-    if (host && total) {
-        ZSW_HIP(ctx, hipMemcpyAsync(out_inc, d_inc, total * 4, kind, stream));
-        ZSW_HIP(ctx, hipMemcpyAsync(out_op, d_op, total, kind, stream));
-    }
+    *out_n_ciglets = 0;
+    if (n == 0) return ZSW_OK;
+    const bool host = reads->mem == ZSW_MEM_HOST;
+    RangesDev rd;
+    ctx->timer.begin(stream);
+    zsw_error ze = ranges_device(ctx, st, rule, stream, &rd);
+    if (ze != ZSW_OK) return ze;
+    DevBuf* ws = ctx->a_ws;
+    const uint32_t MAXC = 32;
+    ZSW_HIP(ctx, ws[WS_ALN].ensure((size_t)n * sizeof(zsw_alignment)));
+    ZSW_HIP(ctx, ws[WS_CIGSTART].ensure((size_t)n * 8));
+    ZSW_HIP(ctx, ws[WS_CIGRAW].ensure((size_t)n * 4));
+    ZSW_HIP(ctx, ws[WS_FBLIST].ensure((size_t)n * 4 + 4));
+    ZSW_HIP(ctx, ws[WS_ITEMS].ensure((size_t)n * 4 + 4));
+    ZSW_HIP(ctx, ws[WS_FBCOUNT].ensure(16));
+    ZSW_HIP(ctx, ws[WS_CIG].ensure((size_t)n * MAXC * 4));
+    ZSW_HIP(ctx, hipMemsetAsync(ws[WS_FBCOUNT].p, 0, 16, stream));
+    uint32_t* counters = ws[WS_FBCOUNT].as<uint32_t>();  // [0] rerun count, [1] dp count, [2] largest slot need
+    ThreePassArgs a;
+    a.b = st.b;
+    a.ref = ctx->d_ref.as<uint8_t>();
+    a.ref_len = (uint32_t)ctx->ref_len;
+    a.sc = ctx->d_sc.as<ScoringDev>();
+    a.score = rd.score;
+    a.rs = rd.rs;
+    a.re = rd.re;
+    a.qs = rd.qs;
+    a.qe = rd.qe;
+    a.status = rd.status;
+    a.list = nullptr;
+    a.list_count = nullptr;
+    a.dp_list = ws[WS_ITEMS].as<uint32_t>();
+    a.dp_count = counters + 1;
+    a.dp_need_max = counters + 2;
+    a.scratch = nullptr;
+    a.slots = 0;
+    a.slot_bytes = 0;
+    a.cig = ws[WS_CIG].as<uint32_t>();
+    a.maxc = MAXC;
+    a.pool_base = 0;
+    a.by_item = 0;
+    a.cig_start = ws[WS_CIGSTART].as<uint64_t>();
+    a.cig_raw = ws[WS_CIGRAW].as<uint32_t>();
+    a.aln = ws[WS_ALN].as<zsw_alignment>();
+    a.fb_list = ws[WS_FBLIST].as<uint32_t>();
+    a.fb_count = counters;
+    a.invert = invert;
+    hipError_t e = launch_threepass(a, std::min<uint32_t>((n + 63) / 64, 65536u), stream);  // classify + no-gaps shortcut
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "3-pass classify", e);
+    uint32_t h_cnt[3] = {0, 0, 0};
+    ZSW_HIP(ctx, hipMemcpyAsync(h_cnt, counters, 12, hipMemcpyDeviceToHost, stream));
     ZSW_HIP(ctx, hipStreamSynchronize(stream));
-    return ZSW_OK;
+    auto dp_pass = [&](const uint32_t* d_list, uint32_t* d_list_count, uint32_t count, uint64_t slot_bytes, uint32_t maxc, int by_item,
+                       DevBuf& cigbuf, DevBuf& scratchbuf) -> zsw_error {
+        if (!count) return ZSW_OK;
+        slot_bytes = (slot_bytes + 63) & ~63ull;
+        uint64_t budget = 2ull << 30;
+        uint32_t slots = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(budget / slot_bytes, 64), 131072);
+        slots = std::min<uint32_t>(slots, (count + 63) / 64 * 64);
+        slots = std::max<uint32_t>(64, slots / 64 * 64);
+        ZSW_HIP(ctx, scratchbuf.ensure((uint64_t)slots * slot_bytes + 64));
+        if (by_item) ZSW_HIP(ctx, cigbuf.ensure((uint64_t)count * maxc * 4 + 64));
+        ThreePassArgs d = a;
+        d.list = d_list;
+        d.list_count = d_list_count;
+        d.scratch = scratchbuf.as<uint8_t>();
+        d.slots = slots;
+        d.slot_bytes = slot_bytes;
+        d.cig = cigbuf.as<uint32_t>();
+        d.maxc = maxc;
+        d.by_item = by_item;
+        hipError_t he = launch_threepass(d, slots / 64, stream);
+        if (he != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "3-pass DP", he);
+        return ZSW_OK;
+    };
+    const uint64_t SLOT_CAP = 96 * 1024;
+    ze = dp_pass(ws[WS_ITEMS].as<uint32_t>(), counters + 1, h_cnt[1], std::min<uint64_t>(std::max<uint32_t>(h_cnt[2], 64), SLOT_CAP), MAXC, 0,
+                 ws[WS_CIG], ws[WS_RING]);
+    if (ze != ZSW_OK) return ze;
+    ZSW_HIP(ctx, hipMemcpyAsync(h_cnt, counters, 4, hipMemcpyDeviceToHost, stream));
+    ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    if (h_cnt[0]) {
+        // reads whose box is larger than the slot cap or whose CIGAR needs more than 32 ciglets: rerun with full-size resources
+        const uint32_t n_fb = h_cnt[0];
+        if ((uint64_t)h_cnt[2] > (1ull << 31)) return fail(ctx, ZSW_ERR_UNSUPPORTED, "3-pass bounding box too large");
+        ZSW_HIP(ctx, ws[WS_ITEMS2].ensure((size_t)n_fb * 4 + 4));
+        ZSW_HIP(ctx, hipMemcpyAsync(ws[WS_ITEMS2].p, ws[WS_FBLIST].p, (size_t)n_fb * 4, hipMemcpyDeviceToDevice, stream));
+        ZSW_HIP(ctx, ws[WS_FBMETA].ensure(8));
+        ZSW_HIP(ctx, hipMemcpyAsync(ws[WS_FBMETA].p, &n_fb, 4, hipMemcpyHostToDevice, stream));
+        ZSW_HIP(ctx, hipMemsetAsync(counters, 0, 4, stream));
+        const uint32_t maxc_fb = st.max_len + (uint32_t)ctx->ref_len + 4;
+        ze = dp_pass(ws[WS_ITEMS2].as<uint32_t>(), ws[WS_FBMETA].as<uint32_t>(), n_fb, std::max<uint32_t>(h_cnt[2], 64), maxc_fb, 1,
+                     ws[WS_CIG2], ws[WS_RING2]);
+        if (ze != ZSW_OK) return ze;
+        uint32_t again = 0;
+        ZSW_HIP(ctx, hipMemcpyAsync(&again, counters, 4, hipMemcpyDeviceToHost, stream));
+        ZSW_HIP(ctx, hipStreamSynchronize(stream));
+        if (again) return fail(ctx, ZSW_ERR_HIP, "3-pass alignment did not complete with full-size resources");
+    }
+    ctx->timer.end(stream);
+    return finish_alignments(ctx, ws, n, host, rd.status, rd.tier, invert, out_aln, out_status, out_tier, out_inc, out_op, ciglet_cap,
+                             out_n_ciglets, stream);
 }
 
 }  // namespace
@@ -775,6 +912,26 @@ zsw_error zsw_score_ranges_batch(zsw_context* ctx, const zsw_batch* reads, zsw_i
     ResultRule rule;
     if (!rule_direct(int_type, ctx->bias, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "bad int_type");
     return run_ranges(ctx, reads, rule, out_score, out_ref_start, out_ref_end, out_query_start, out_query_end, out_status, stream);
+}
+
+zsw_error zsw_align_3pass_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, int invert,
+                                zsw_alignment* out_aln, uint8_t* out_status, uint32_t* out_inc, uint8_t* out_op,
+                                uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!valid_lanes(lanes)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "lanes must be a power of two in 2..64");
+    ResultRule rule;
+    if (!rule_direct(int_type, ctx->bias, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "bad int_type");
+    return run_threepass(ctx, reads, rule, invert, out_aln, out_status, nullptr, out_inc, out_op, ciglet_cap, out_n_ciglets, stream);
+}
+
+zsw_error zsw_align_3pass_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, int invert,
+                                     zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
+                                     uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (preset_bits != 128 && preset_bits != 256 && preset_bits != 512) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "preset_bits");
+    ResultRule rule;
+    if (!rule_cascade(from_width, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "from_width");
+    return run_threepass(ctx, reads, rule, invert, out_aln, out_status, out_tier, out_inc, out_op, ciglet_cap, out_n_ciglets, stream);
 }
 
 zsw_error zsw_synth_reads(zsw_context* ctx, uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint8_t* out_device,

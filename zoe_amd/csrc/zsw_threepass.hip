@@ -1,0 +1,289 @@
+// zsw_threepass.hip — third pass of sw_align_3pass (src/alignment/sw/three_pass.rs:21-104), batched.
+//
+// Passes 1 and 2 are sw_simd_score_ranges (zsw_score.hip: forward score+ends, reverse pass on the prefixes). What is left
+// per read is small and sequential, so one GPU thread owns one read:
+//   * ranges of equal length whose diagonal weights add up to the score -> `new_no_gaps` (state.rs:201-208);
+//   * else sw_banded_align (banded.rs:40-133) on the bounding box, band |dr - dq| + 1 doubling while <= (q-1)/2, accepted when
+//     it reproduces the score; else sw_scalar_align (scalar.rs:173-271) on the box;
+//   * the outer soft clips are then added exactly as the reference does (prepend_soft_clip / soft_clip merge with the inner
+//     alignment's own clips, three_pass.rs:85-92).
+// Flag bytes and the two DP rows of a read live in a per-thread slot of HBM scratch (a 150 x 160 box is 24 KB).
+#include "zsw_align.hpp"
+
+namespace zsw {
+
+constexpr uint8_t BT_UP = 1, BT_UP_EXT = 2, BT_LEFT = 4, BT_LEFT_EXT = 8, BT_STOP = 16;  // backtrack.rs:18-34
+
+struct CigWriter {  // AlignmentStates::add_ciglet (state.rs:142-152) into the pool, traceback order
+    uint32_t* cig;
+    uint32_t maxc, ncig = 0, cur_op = 0, cur_inc = 0, n_nons = 0;
+    bool overflow = false;
+    __device__ void push(uint32_t inc, uint32_t op) {
+        if (inc == 0) return;
+        if (cur_inc && cur_op == op) {
+            cur_inc += inc;
+            return;
+        }
+        flush();
+        cur_op = op;
+        cur_inc = inc;
+        if (op != 'S') ++n_nons;
+    }
+    __device__ void flush() {
+        if (cur_inc) {
+            if (ncig < maxc) cig[ncig] = (cur_inc << 8) | cur_op;
+            else overflow = true;
+            ++ncig;
+        }
+        cur_inc = 0;
+    }
+};
+
+__device__ __forceinline__ uint32_t tp_read_len(const BatchDev& b, uint32_t id, uint64_t* off) {
+    if (b.offsets) {
+        *off = b.offsets[id];
+        return (uint32_t)(b.offsets[id + 1] - *off);
+    }
+    *off = (uint64_t)id * b.fixed_len;
+    return b.fixed_len;
+}
+
+__device__ __forceinline__ uint64_t slot_need(uint32_t rlen, uint32_t qlen) { return (uint64_t)rlen * qlen + 8ull * qlen + 32; }
+
+// BackTrackable::to_alignment (backtrack.rs:290-342) over a cell functor; emits into `w` in traceback order, including the outer
+// clips of three_pass.rs:85-92. Returns false when the reference would index outside its banded matrix.
+template <typename CellFn>
+__device__ bool tp_traceback(CellFn cell, int r_end, int c_end, uint32_t qlen_box, uint32_t q_off, uint32_t query_len, CigWriter& w,
+                             int* r_out, int* c_out) {
+    bool ok = true;
+    uint32_t f = cell(r_end, c_end, &ok);
+    int r = r_end + 1, c = c_end + 1;
+    // inner 3' clip (query_len_box - c) merged with the outer one (query.len() - adjusted_end)
+    w.push((qlen_box - (uint32_t)c) + (query_len - ((uint32_t)c + q_off)), 'S');
+    uint32_t op = 0;
+    while (ok && !(f & BT_STOP) && r > 0 && c > 0) {
+        if (op == 'D' && (f & BT_UP_EXT)) {
+            r -= 1;
+        } else if (op == 'I' && (f & BT_LEFT_EXT)) {
+            c -= 1;
+        } else if (f & BT_UP) {
+            op = 'D';
+            r -= 1;
+        } else if (f & BT_LEFT) {
+            op = 'I';
+            c -= 1;
+        } else {
+            op = 'M';
+            r -= 1;
+            c -= 1;
+        }
+        w.push(1, op);
+        f = cell(r > 0 ? r - 1 : 0, c > 0 ? c - 1 : 0, &ok);
+    }
+    // inner 5' clip (c) merged with the outer one (adjusted start = c + q_off): the reference adds both (three_pass.rs:91)
+    w.push((uint32_t)c + ((uint32_t)c + q_off), 'S');
+    w.flush();
+    *r_out = r;
+    *c_out = c;
+    return ok;
+}
+
+__global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
+    __shared__ uint8_t lut[256];
+    __shared__ int32_t wsh[MAX_S * MAX_S];
+    for (int i = threadIdx.x; i < 256; i += 64) lut[i] = a.sc->index_map[i];
+    for (int i = threadIdx.x; i < MAX_S * MAX_S; i += 64) wsh[i] = a.sc->w[i];
+    __syncthreads();
+    const int S = a.sc->S;
+    const int go = -a.sc->gap_open, ge = -a.sc->gap_extend;  // negative, as in ScalarProfile (profile.rs:110-115)
+    const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t nthreads = gridDim.x * 64;
+    const uint32_t n = a.list ? *a.list_count : a.b.n_reads;
+    auto wt = [&](uint8_t rb, uint8_t qb) -> int32_t { return wsh[lut[rb] * S + lut[qb]]; };
+
+    for (uint32_t item = tid; item < n; item += nthreads) {
+        const uint32_t id = a.list ? a.list[item] : item;
+        if (a.status[id] != ZSW_STATUS_SOME) continue;
+        uint64_t off = 0;
+        const uint32_t query_len = tp_read_len(a.b, id, &off);
+        const uint8_t* query = a.b.bases + off;
+        const uint32_t score = a.score[id];
+        const uint32_t rs = a.rs[id], re = a.re[id], qs = a.qs[id], qe = a.qe[id];
+        const uint32_t rlen = re - rs, qlen = qe - qs;
+        uint32_t* cig = a.cig + a.pool_base + (uint64_t)(a.by_item ? item : id) * a.maxc;
+        CigWriter w;
+        w.cig = cig;
+        w.maxc = a.maxc;
+        zsw_alignment out;
+        out.score = score;
+        out.ref_len = a.ref_len;
+        out.query_len = query_len;
+        out.ciglet_offset = 0;
+        bool done = false;
+        if (!a.list) {
+            // classify pass: the no-gaps shortcut (three_pass.rs:37-58) is resolved here, the rest is queued for the DP pass
+            if (qlen == rlen) {
+                int64_t sum = 0;
+                for (uint32_t k = 0; k < qlen; ++k) sum += wt(a.ref[rs + k], query[qs + k]);
+                if ((sum < 0 ? 0u : (uint32_t)sum) == score) {
+                    w.push(query_len - qe, 'S');
+                    w.push(qe - qs, 'M');
+                    w.push(qs, 'S');
+                    w.flush();
+                    out.ref_start = rs;
+                    out.ref_end = re;
+                    out.query_start = qs;
+                    out.query_end = qe;
+                    done = true;
+                }
+            }
+            if (!done) {
+                const uint32_t k = atomicAdd(a.dp_count, 1u);
+                a.dp_list[k] = id;
+                const uint64_t need = slot_need(rlen, qlen);
+                atomicMax(a.dp_need_max, (uint32_t)(need > 0xffffffffull ? 0xffffffffull : need));
+                continue;
+            }
+        } else {
+            if (slot_need(rlen, qlen) > a.slot_bytes) {  // does not fit this launch's slots: larger-slot rerun
+                const uint32_t k = atomicAdd(a.fb_count, 1u);
+                a.fb_list[k] = id;
+                continue;
+            }
+            uint8_t* slot = a.scratch + (uint64_t)tid * a.slot_bytes;
+            int32_t* h_row = reinterpret_cast<int32_t*>(slot);
+            int32_t* e_row = h_row + qlen;
+            uint8_t* bt = slot + ((8ull * qlen + 15) & ~15ull);
+            const uint8_t* refb = a.ref + rs;
+            const uint8_t* qb = query + qs;
+            int r_fin = 0, c_fin = 0, r_end = 0, c_end = 0;
+            bool have = false;
+            uint32_t band = (rlen > qlen ? rlen - qlen : qlen - rlen) + 1;
+            const uint32_t max_band = (qlen - 1) / 2;
+            while (!have && band <= max_band) {
+                // sw_banded_align (banded.rs:40-133)
+                const uint32_t full = 2 * band + 1;
+                for (uint32_t c = 0; c < qlen; ++c) {
+                    h_row[c] = 0;
+                    e_row[c] = go;
+                }
+                for (uint64_t k = 0; k < (uint64_t)rlen * full; ++k) bt[k] = 0;
+                int32_t best = 0, h_store = 0;
+                for (uint32_t r = 0; r < rlen; ++r) {
+                    int32_t f = go, h = h_store;
+                    const uint32_t start_col = r > band ? r - band : 0;
+                    const uint32_t end_col = min(r + band + 1, qlen);
+                    if (start_col >= end_col) break;
+                    if (start_col + band == r) h_store = max(max(h + wt(refb[r], qb[start_col]), e_row[start_col]), 0);
+                    for (uint32_t c = start_col; c < end_col; ++c) {
+                        uint8_t cell = 0;
+                        h += wt(refb[r], qb[c]);
+                        int32_t e = e_row[c];
+                        h = max(max(max(h, e), f), 0);
+                        if (h > best) {
+                            best = h;
+                            r_end = (int)r;
+                            c_end = (int)c;
+                        }
+                        if (e == h) cell |= BT_UP;
+                        if (f == h) cell |= BT_LEFT;
+                        if (h == 0) cell = BT_STOP;
+                        const int32_t next_diag = h_row[c];
+                        h_row[c] = h;
+                        h += go;
+                        e = max(e + ge, h);
+                        f = max(f + ge, h);
+                        if (h != go) {
+                            if (e > h) cell |= BT_UP_EXT;
+                            if (f > h) cell |= BT_LEFT_EXT;
+                        }
+                        h = next_diag;
+                        e_row[c] = e;
+                        bt[(uint64_t)r * full + (c - start_col)] = cell;
+                    }
+                }
+                if (best > 0 && (uint32_t)best == score) {
+                    // BandedBacktrackMatrix::move_to (backtrack.rs:629-634)
+                    auto cell = [&](int rr, int cc, bool* ok) -> uint32_t {
+                        const uint32_t skipped = (uint32_t)rr > band ? (uint32_t)rr - band : 0;
+                        if ((uint32_t)cc < skipped) {
+                            *ok = false;
+                            return BT_STOP;
+                        }
+                        const uint64_t cur = (uint64_t)rr * full + ((uint32_t)cc - skipped);
+                        if (cur >= (uint64_t)rlen * full) {
+                            *ok = false;
+                            return BT_STOP;
+                        }
+                        return bt[cur];
+                    };
+                    CigWriter trial = w;
+                    if (tp_traceback(cell, r_end, c_end, qlen, qs, query_len, trial, &r_fin, &c_fin)) {
+                        w = trial;
+                        have = true;
+                    }
+                }
+                if (!have) band *= 2;
+            }
+            if (!have) {
+                // sw_scalar_align on the box (scalar.rs:173-271)
+                for (uint32_t c = 0; c < qlen; ++c) {
+                    h_row[c] = 0;
+                    e_row[c] = go;
+                }
+                int32_t best = 0;
+                for (uint32_t r = 0; r < rlen; ++r) {
+                    int32_t f = go, h = 0;
+                    for (uint32_t c = 0; c < qlen; ++c) {
+                        uint8_t cell = 0;
+                        h += wt(refb[r], qb[c]);
+                        int32_t e = e_row[c];
+                        h = max(max(max(h, e), f), 0);
+                        if (h > best) {
+                            best = h;
+                            r_end = (int)r;
+                            c_end = (int)c;
+                        }
+                        if (e == h) cell |= BT_UP;
+                        if (f == h) cell |= BT_LEFT;
+                        if (h == 0) cell = BT_STOP;
+                        const int32_t next_diag = h_row[c];
+                        h_row[c] = h;
+                        h += go;
+                        e = max(e + ge, h);
+                        f = max(f + ge, h);
+                        if (h != go) {
+                            if (e > h) cell |= BT_UP_EXT;
+                            if (f > h) cell |= BT_LEFT_EXT;
+                        }
+                        h = next_diag;
+                        e_row[c] = e;
+                        bt[(uint64_t)r * qlen + c] = cell;
+                    }
+                }
+                auto cell = [&](int rr, int cc, bool* ok) -> uint32_t { return bt[(uint64_t)rr * qlen + (uint32_t)cc]; };
+                tp_traceback(cell, r_end, c_end, qlen, qs, query_len, w, &r_fin, &c_fin);
+            }
+            out.ref_start = (uint32_t)r_fin + rs;
+            out.ref_end = (uint32_t)(r_end + 1) + rs;
+            out.query_start = (uint32_t)c_fin + qs;
+            out.query_end = (uint32_t)(c_end + 1) + qs;
+        }
+        if (w.overflow) {
+            const uint32_t k = atomicAdd(a.fb_count, 1u);
+            a.fb_list[k] = id;
+            continue;
+        }
+        out.n_ciglets = a.invert ? w.n_nons + (out.ref_start > 0 ? 1u : 0u) + (a.ref_len > out.ref_end ? 1u : 0u) : w.ncig;
+        a.aln[id] = out;
+        a.cig_start[id] = (uint64_t)(uintptr_t)cig;
+        a.cig_raw[id] = w.ncig;
+    }
+}
+
+hipError_t launch_threepass(const ThreePassArgs& a, uint32_t grid, hipStream_t stream) {
+    hipLaunchKernelGGL(threepass_kernel, dim3(grid), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace zsw
