@@ -153,6 +153,18 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     out["align_full_traceback_1M_x_150bp_vs_2kb"] = {
         "reads_per_s_end_to_end_incl_d2h": 1_000_000 / dt, "pass2_kernel_ms": ks * 1e3, "ciglets": int(len(a.inc)),
         "call": "into_local_profile(..).sw_align_from_i8(SeqSrc::Reference(ref)) (CIGAR of the i16x16 / i8x32 tier)"}
+    prof.sw_align_from_i8_3pass(zoe_amd.SeqSrc.Reference(ref2k))
+    torch.cuda.synchronize()
+    ctx.timing_read()
+    t0 = time.perf_counter()
+    a3 = prof.sw_align_from_i8_3pass(zoe_amd.SeqSrc.Reference(ref2k))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ks, _ = ctx.timing_read()
+    out["align_3pass_1M_x_150bp_vs_2kb"] = {
+        "reads_per_s_end_to_end_incl_d2h": 1_000_000 / dt, "kernels_ms": ks * 1e3, "ciglets": int(len(a3.inc)),
+        "call": "into_local_profile(..).sw_align_from_i8_3pass(SeqSrc::Reference(ref)) (three_pass.rs: ranges, then no-gaps / banded / scalar in the box)"}
+    del a, a3
     ref30k = synth.reference_host(30000)
     rr = synth.reads_ragged_device(ctx, ref30k, 0, 1_000_000, 75, 400)
     pm = zoe_amd.into_local_profile(rr, matrix, -10, -1, device=ctx.device)

@@ -7,6 +7,7 @@ from zoe_amd import synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+three = len(sys.argv) > 3 and sys.argv[3] == "3pass"
 ctx = zoe_amd.SwContext.get(0)
 ref = synth.reference_host(2000)
 rb = synth.reads_device(ctx, ref, 0, n, 150)
@@ -16,7 +17,7 @@ for r in range(reps + 1):
     ctx.timing_enable(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    a = prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref))
+    a = (prof.sw_align_from_i8_3pass if three else prof.sw_align_from_i8)(zoe_amd.SeqSrc.Reference(ref))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ks, kl = ctx.timing_read()

@@ -347,7 +347,7 @@ zsw_error ranges_device(zsw_context* ctx, const Staged& st, const ResultRule& ru
     ro.fb_list = ctx->d_fb_list.as<uint32_t>();
     ro.fb_count = ctx->d_fb_count.as<uint32_t>();
     e = launch_score_rev(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len,
-                         rule, ro, score_ws(ctx), fo.ref_end, ws[RW_QEM].as<uint32_t>(), ws[RW_GTAB].as<uint2>(), stream);
+                         rule, ro, score_ws(ctx), fo.ref_end, ws[RW_QEM].as<uint32_t>(), fo.score, ws[RW_GTAB].as<uint2>(), stream);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "ranges reverse pass", e);
     out->score = ws[RW_O0].as<uint32_t>();
     out->rs = ws[RW_O1].as<uint32_t>();

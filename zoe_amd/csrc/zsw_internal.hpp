@@ -86,7 +86,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
 hipError_t launch_score_rev(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
                             const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
                             const ScoreWorkspace& ws, const uint32_t* d_fwd_ref_end, const uint32_t* d_fwd_query_end,
-                            uint2* d_gtab, hipStream_t stream);
+                            const uint32_t* d_fwd_score, uint2* d_gtab, hipStream_t stream);
 bool score_config_for(uint32_t max_len, int* G, int* C);
 
 }  // namespace zsw

@@ -54,6 +54,7 @@ struct ScoreArgs {
     // reverse pass of sw_simd_score_ranges (REV kernels): per read, the forward ends and the per-row table in HBM
     const uint32_t* rev_ref_end;
     const uint32_t* rev_query_end;
+    const uint32_t* rev_score;  // forward score: the reverse pass may stop once it has been reached (see the REV loop)
     const uint2* gtab;
 };
 
@@ -231,12 +232,25 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
             const int rr = rev_re - 1 - row;
             return (row >= 0 && rr >= 0) ? a.gtab[rr] : neutral;
         };
+        // The reverse problem's maximum equals the forward score (the same alignment read backwards), and its tie rule wants
+        // the FIRST row that holds the maximum: once a read's running maximum has reached the forward score, and every lane
+        // of its group has walked past that row (G more steps), nothing later can change its answer. Checked every 8 steps;
+        // the wave leaves when all of its reads are finished — about the alignment's own span instead of the whole prefix.
+        const int target = (validA && lenA) ? (int)a.rev_score[idA] - 32768 : 0x7fffffff;  // stored (offset) domain
+        int t_done = (validA && lenA && rev_re > 0) ? 0x3fffffff : -1000000;
         uint2 w = row_entry(-g);
 #pragma unroll 1
         for (int t = 0; t < tw; ++t) {
             const uint2 wn = row_entry(t + 1 - g);
             step(w, t - g);
             w = wn;
+            if ((t & 7) == 7) {
+                int gm = (int)(int16_t)(best & 0xffffu);
+#pragma unroll
+                for (int d = 1; d < G; d <<= 1) gm = max(gm, __shfl_xor(gm, d, G));
+                if (gm >= target && t_done > t) t_done = t;
+                if (__ballot(t < t_done + G) == 0) break;
+            }
         }
     }
 
@@ -900,6 +914,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     a.out = out;
     a.rev_ref_end = nullptr;
     a.rev_query_end = nullptr;
+    a.rev_score = nullptr;
     a.gtab = nullptr;
     const bool fast = fast_ok(h_sc);
     if (table_ok) build_tables(h_sc, fast, &a);
@@ -1006,7 +1021,7 @@ static hipError_t launch_cfg_rev(const ScoreArgs& a, bool fast, hipStream_t stre
 hipError_t launch_score_rev(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
                             const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
                             const ScoreWorkspace& ws, const uint32_t* d_fwd_ref_end, const uint32_t* d_fwd_query_end,
-                            uint2* d_gtab, hipStream_t stream) {
+                            const uint32_t* d_fwd_score, uint2* d_gtab, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(out.fb_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const uint32_t exact_grid = (uint32_t)(ws.slots / 64);
@@ -1027,6 +1042,7 @@ hipError_t launch_score_rev(const ScoringDev* d_sc, const ScoringDev& h_sc, cons
     a.out = out;
     a.rev_ref_end = d_fwd_ref_end;
     a.rev_query_end = d_fwd_query_end;
+    a.rev_score = d_fwd_score;
     a.gtab = d_gtab;
     const bool fast = fast_ok(h_sc);
     build_tables(h_sc, fast, &a);
