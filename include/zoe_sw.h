@@ -156,6 +156,21 @@ zsw_error zsw_align_3pass_batch_from(zsw_context* ctx, const zsw_batch* reads, i
                                      zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
                                      uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream);
 
+/* ---- pre-alignment filter ------------------------------------------------------------------ */
+/* out_pass[i] = sneaky_snake(&reference[ref_start[i] .. ref_start[i]+ref_len[i]], read_i, threshold)
+ * (src/alignment/sneaky_snake.rs:78-131): the SneakySnake edit-distance filter between a read and a candidate window of the
+ * context's reference; `threshold` is the allowed edits as a fraction of the read length. Bytes are compared raw, as in the
+ * reference (no index map). ref_start / ref_len / out_pass live where `reads->mem` says. A window that leaves the reference
+ * is ZSW_ERR_INVALID_ARGUMENT for host arrays and ZSW_FILTER_BAD_WINDOW in out_pass for device arrays. */
+typedef enum zsw_filter_result {
+    ZSW_FILTER_REJECT = 0,      /* Some(false) */
+    ZSW_FILTER_PASS = 1,        /* Some(true)  */
+    ZSW_FILTER_NONE = 2,        /* None: threshold outside [0,1] or |len difference| > allowed edits */
+    ZSW_FILTER_BAD_WINDOW = 255
+} zsw_filter_result;
+zsw_error zsw_sneaky_snake_batch(zsw_context* ctx, const zsw_batch* reads, const uint32_t* ref_start, const uint32_t* ref_len,
+                                 float threshold, uint8_t* out_pass, void* stream);
+
 /* ---- bench/test utilities (not part of the reference surface) ------------------------------ */
 /* Counter-based synthetic reads: read i depends only on (seed, i, reference), so any
  * shard regenerates its own slice. Writes reads [first, first+n) of length `len` into out (device). */

@@ -160,6 +160,34 @@ class LocalProfilesBatch {
     std::vector<MaybeAligned<uint32_t>> sw_score_from_i16(const std::string& reference) { return score_from(reference, 16); }
     // ProfileSets::sw_align_from_i8 with SeqSrc::Reference (profile_set.rs:124-135)
     std::vector<MaybeAligned<Alignment>> sw_align_from_i8(const std::string& reference, bool seq_is_query = false) {
+        return align_from(reference, seq_is_query, zsw_align_batch_from);
+    }
+    // ProfileSets::sw_align_from_i8_3pass (profile_set.rs:212-235)
+    std::vector<MaybeAligned<Alignment>> sw_align_from_i8_3pass(const std::string& reference, bool seq_is_query = false) {
+        return align_from(reference, seq_is_query, zsw_align_3pass_batch_from);
+    }
+    // alignment::sneaky_snake(&reference[ref_start[i]..][..ref_len[i]], read_i, threshold) (sneaky_snake.rs:78-131):
+    // true / false per read, Status::Unmapped standing in for `None`.
+    std::vector<MaybeAligned<bool>> sneaky_snake(const std::string& reference, const std::vector<uint32_t>& ref_start,
+                                                 const std::vector<uint32_t>& ref_len, float threshold) {
+        const size_t n = offsets_.size() - 1;
+        if (ref_start.size() != n || ref_len.size() != n) throw GpuError(ZSW_ERR_INVALID_ARGUMENT, "one window per read");
+        ctx_.check(zsw_set_reference(ctx_.raw(), (const uint8_t*)reference.data(), reference.size(), ZSW_MEM_HOST));
+        zsw_batch b = batch();
+        std::vector<uint8_t> pass(n);
+        ctx_.check(zsw_sneaky_snake_batch(ctx_.raw(), &b, ref_start.data(), ref_len.data(), threshold, pass.data(), nullptr));
+        std::vector<MaybeAligned<bool>> out(n);
+        for (size_t i = 0; i < n; ++i) {
+            out[i].status = pass[i] == ZSW_FILTER_NONE ? Status::Unmapped : Status::Some;
+            out[i].value = pass[i] == ZSW_FILTER_PASS;
+        }
+        return out;
+    }
+
+  private:
+    using AlignFn = zsw_error (*)(zsw_context*, const zsw_batch*, int, int, int, zsw_alignment*, uint8_t*, uint8_t*, uint32_t*,
+                                  uint8_t*, uint64_t, uint64_t*, void*);
+    std::vector<MaybeAligned<Alignment>> align_from(const std::string& reference, bool seq_is_query, AlignFn fn) {
         const size_t n = offsets_.size() - 1;
         ctx_.check(zsw_set_reference(ctx_.raw(), (const uint8_t*)reference.data(), reference.size(), ZSW_MEM_HOST));
         zsw_batch b = batch();
@@ -168,13 +196,13 @@ class LocalProfilesBatch {
         std::vector<uint32_t> inc(16 * n + 64);
         std::vector<uint8_t> op(inc.size());
         uint64_t total = 0;
-        zsw_error e = zsw_align_batch_from(ctx_.raw(), &b, 8, preset_, seq_is_query, aln.data(), status.data(), tier.data(), inc.data(),
-                                           op.data(), inc.size(), &total, nullptr);
+        zsw_error e = fn(ctx_.raw(), &b, 8, preset_, seq_is_query, aln.data(), status.data(), tier.data(), inc.data(), op.data(),
+                         inc.size(), &total, nullptr);
         if (e == ZSW_ERR_INVALID_ARGUMENT && total > inc.size()) {
             inc.resize(total);
             op.resize(total);
-            e = zsw_align_batch_from(ctx_.raw(), &b, 8, preset_, seq_is_query, aln.data(), status.data(), tier.data(), inc.data(),
-                                     op.data(), inc.size(), &total, nullptr);
+            e = fn(ctx_.raw(), &b, 8, preset_, seq_is_query, aln.data(), status.data(), tier.data(), inc.data(), op.data(),
+                   inc.size(), &total, nullptr);
         }
         ctx_.check(e);
         std::vector<MaybeAligned<Alignment>> out(n);
@@ -194,8 +222,6 @@ class LocalProfilesBatch {
         }
         return out;
     }
-
-  private:
     zsw_batch batch() const {
         zsw_batch b;
         b.bases = bases_.data();

@@ -279,6 +279,13 @@ def cascade_align_3pass(from_width: int, preset: int, sc: Scoring, prof_seq, oth
     return _aln(st.value, f, buf), tier.value, how.value
 
 
+def sneaky_snake(reference, query, threshold: float):
+    """alignment::sneaky_snake(reference, query, threshold) → True / False / None (sneaky_snake.rs:78-131)."""
+    r, q = _u8(reference), _u8(query)
+    rc = lib().zor_sneaky_snake(_p(r), C.c_size_t(len(r)), _p(q), C.c_size_t(len(q)), C.c_float(threshold))
+    return {0: False, 1: True, 2: None}[rc]
+
+
 def profile_dump(T: str, lanes: int, sc: Scoring, seq, rev_end: int = 0) -> np.ndarray:
     """StripedProfile::new(seq) (or .reverse_from_forward(rev_end)) as int64 [S, nv, lanes]."""
     w, im, a = _sc_args(sc)

@@ -15,6 +15,7 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <limits>
@@ -1003,6 +1004,42 @@ inline int64_t sw_score_from_path(const std::vector<Ciglet>& ciglets, const uint
     }
     if (c != q.len || r != ref_n || score < 0) return -1;
     return score;
+}
+
+// ---- sneaky_snake (alignment/sneaky_snake.rs:78-131) ----
+// Returns 0 = Some(false), 1 = Some(true), 2 = None. Written the way the reference walks it: diagonals ("rows") of the chip
+// maze in order 0..window, each from the current checkpoint to its first obstacle.
+inline int sneaky_snake(const uint8_t* reference, size_t ref_len, const uint8_t* query, size_t query_len, float threshold) {
+    if (!(threshold >= 0.0f && threshold <= 1.0f)) return 2;                       // :79-81 (NaN is outside the range)
+    const size_t edit_thresh = (size_t)std::floor((float)query_len * threshold);   // :83 (f32 product, floor, as usize)
+    const size_t len_diff = ref_len > query_len ? ref_len - query_len : query_len - ref_len;
+    if (len_diff > edit_thresh) return 2;                                          // :86-88
+    if (edit_thresh == query_len) return 1;                                        // :89-91
+    const uint8_t *s1 = reference, *s2 = query;                                    // :94-98 s1 = the shorter one
+    size_t n1 = ref_len, n2 = query_len;
+    if (ref_len > query_len) {
+        s1 = query, n1 = query_len;
+        s2 = reference, n2 = ref_len;
+    }
+    const size_t window = 2 * edit_thresh + 1, diffpad_len = len_diff / 2;
+    size_t obstacles = 0, checkpoint = 0;
+    while (checkpoint < n1 && obstacles <= edit_thresh && n1 - checkpoint > edit_thresh - obstacles) {  // :106
+        size_t last_col = checkpoint;
+        for (size_t row = 0; row < window; ++row) {
+            for (size_t col = checkpoint; col < n1; ++col) {
+                const size_t shifted = col + row + diffpad_len;                    // :113 checked_sub(edit_thresh)
+                if (shifted >= edit_thresh && shifted - edit_thresh < n2 && s2[shifted - edit_thresh] == s1[col]) {
+                    if (col == n1 - 1 || n1 - col - 1 <= edit_thresh - obstacles) return 1;  // :116-118
+                } else {
+                    last_col = std::max(last_col, col);                            // :120-121
+                    break;
+                }
+            }
+        }
+        checkpoint = last_col + 1;                                                 // :126-127
+        ++obstacles;
+    }
+    return obstacles <= edit_thresh ? 1 : 0;                                       // :130
 }
 
 }  // namespace zor

@@ -347,6 +347,11 @@ int zor_cascade_align_3pass(int from_width, int preset, int S, const int8_t* wei
     return 0;
 }
 
+// sneaky_snake (alignment/sneaky_snake.rs:78-131): 0 Some(false), 1 Some(true), 2 None
+int zor_sneaky_snake(const uint8_t* reference, size_t ref_len, const uint8_t* query, size_t query_len, float threshold) {
+    return sneaky_snake(reference, ref_len, query, query_len, threshold);
+}
+
 // sw_score_from_path over a CIGAR string; -1 on any ScoringError
 long long zor_score_from_path(int S, const int8_t* weights, const uint8_t* index_map, int gap_open, int gap_extend,
                               const uint8_t* query, size_t query_len, const uint8_t* ref_in_alignment, size_t ref_n,

@@ -4,6 +4,6 @@ Hand-written HIP kernels behind a C ABI (include/zoe_sw.h), plus a host-side mir
 reference's profile / weight-matrix / sw_* interface (zoe_amd.alignment).
 """
 from .alignment import (  # noqa: F401
-    DNA_PROFILE_MAP, EMPTY, OVERFLOWED, SOME, UNMAPPED, AlignmentBatch, ByteIndexMap, LocalProfilesBatch, ProfileError,
-    ReadBatch, ScoreBatch, SeqSrc, StripedProfileBatch, SwContext, WeightMatrix, into_local_profile, validate_profile_args,
+    DNA_PROFILE_MAP, EMPTY, FILTER_NONE, FILTER_PASS, FILTER_REJECT, OVERFLOWED, SOME, UNMAPPED, AlignmentBatch, ByteIndexMap, LocalProfilesBatch, ProfileError,
+    ReadBatch, ScoreBatch, SeqSrc, StripedProfileBatch, SwContext, WeightMatrix, into_local_profile, sneaky_snake, validate_profile_args,
 )

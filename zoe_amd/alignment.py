@@ -542,6 +542,30 @@ class LocalProfilesBatch(_ProfileBatchBase):
         return self._align(seq, None, 32, self.preset)
 
 
+FILTER_REJECT, FILTER_PASS, FILTER_NONE = 0, 1, 2
+
+
+def sneaky_snake(reference, reads, ref_start, ref_len, threshold: float, device: int = 0):
+    """Batched `alignment::sneaky_snake(&reference[ref_start[i]..][..ref_len[i]], read_i, threshold)`
+    (sneaky_snake.rs:78-131): a uint8 device tensor of FILTER_REJECT = Some(false) / FILTER_PASS = Some(true) /
+    FILTER_NONE = None per read. `ref_start` / `ref_len`: one candidate window of `reference` per read."""
+    torch = _torch()
+    rb = _as_batch(reads, device)
+    ctx = SwContext.get(rb.device_index)
+    ctx.set_reference(reference)
+    dev = rb.bases.device
+    n = rb.n_reads
+    rs = torch.as_tensor(np.asarray(ref_start, dtype=np.int64) if not isinstance(ref_start, torch.Tensor) else ref_start).to(dev, torch.int32).contiguous()
+    rl = torch.as_tensor(np.asarray(ref_len, dtype=np.int64) if not isinstance(ref_len, torch.Tensor) else ref_len).to(dev, torch.int32).contiguous()
+    if rs.numel() != n or rl.numel() != n:
+        raise ValueError("one (ref_start, ref_len) window per read")
+    out = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+    b = rb.c_batch()
+    ctx.check(ctx.lib.zsw_sneaky_snake_batch(ctx.h, C.byref(b), rs.data_ptr(), rl.data_ptr(), C.c_float(threshold), out.data_ptr(),
+                                             ctx.stream()), profile_errors=False)
+    return out[:n]
+
+
 def into_local_profile(reads, matrix: WeightMatrix, gap_open: int, gap_extend: int, device: int = 0) -> LocalProfilesBatch:
     """Nucleotides::into_local_profile (nucleotides/mod.rs:262-266): the w256 preset."""
     return LocalProfilesBatch.new_with_w256(reads, matrix, gap_open, gap_extend, device)

@@ -934,6 +934,57 @@ zsw_error zsw_align_3pass_batch_from(zsw_context* ctx, const zsw_batch* reads, i
     return run_threepass(ctx, reads, rule, invert, out_aln, out_status, out_tier, out_inc, out_op, ciglet_cap, out_n_ciglets, stream);
 }
 
+zsw_error zsw_sneaky_snake_batch(zsw_context* ctx, const zsw_batch* reads, const uint32_t* ref_start, const uint32_t* ref_len,
+                                 float threshold, uint8_t* out_pass, void* stream_) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!ctx->reference_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "reference not set");
+    if (!reads || !ref_start || !ref_len || !out_pass) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
+    if (reads->n_reads > 0x7fffffffull) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "n_reads > 2^31-1 per call");
+    if (reads->n_reads && !reads->bases) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null bases");
+    const uint32_t n = (uint32_t)reads->n_reads;
+    if (n == 0) return ZSW_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    ZSW_HIP(ctx, hipSetDevice(ctx->device));
+    BatchDev b{};
+    b.n_reads = b.n_items = n;
+    b.fixed_len = reads->fixed_len;
+    const uint32_t *d_rs = ref_start, *d_rl = ref_len;
+    uint8_t* d_out = out_pass;
+    if (reads->mem == ZSW_MEM_HOST) {
+        for (uint32_t i = 0; i < n; ++i)
+            if ((uint64_t)ref_start[i] + ref_len[i] > ctx->ref_len) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "window leaves the reference");
+        const size_t total = reads->offsets ? (size_t)reads->offsets[n] : (size_t)n * reads->fixed_len;
+        ZSW_HIP(ctx, ctx->s_bases.ensure(total + 16));
+        ZSW_HIP(ctx, hipMemcpyAsync(ctx->s_bases.p, reads->bases, total, hipMemcpyHostToDevice, stream));
+        b.bases = ctx->s_bases.as<uint8_t>();
+        if (reads->offsets) {
+            ZSW_HIP(ctx, ctx->s_offsets.ensure((size_t)(n + 1) * 8));
+            ZSW_HIP(ctx, hipMemcpyAsync(ctx->s_offsets.p, reads->offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, stream));
+            b.offsets = ctx->s_offsets.as<uint64_t>();
+        }
+        ZSW_HIP(ctx, ctx->s_rend.ensure((size_t)n * 4 + 4));
+        ZSW_HIP(ctx, ctx->s_qend.ensure((size_t)n * 4 + 4));
+        ZSW_HIP(ctx, ctx->s_status.ensure((size_t)n + 4));
+        ZSW_HIP(ctx, hipMemcpyAsync(ctx->s_rend.p, ref_start, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+        ZSW_HIP(ctx, hipMemcpyAsync(ctx->s_qend.p, ref_len, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+        d_rs = ctx->s_rend.as<uint32_t>();
+        d_rl = ctx->s_qend.as<uint32_t>();
+        d_out = ctx->s_status.as<uint8_t>();
+    } else {
+        b.bases = reads->bases;
+        b.offsets = reads->offsets;
+    }
+    ctx->timer.begin(stream);
+    hipError_t e = launch_sneaky(b, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len, d_rs, d_rl, threshold, d_out, stream);
+    ctx->timer.end(stream);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "sneaky_kernel launch", e);
+    if (reads->mem == ZSW_MEM_HOST) {
+        ZSW_HIP(ctx, hipMemcpyAsync(out_pass, d_out, n, hipMemcpyDeviceToHost, stream));
+        ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    }
+    return ZSW_OK;
+}
+
 zsw_error zsw_synth_reads(zsw_context* ctx, uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint8_t* out_device,
                           void* stream) {
     if (!ctx || !out_device || len == 0) return ZSW_ERR_INVALID_ARGUMENT;

@@ -89,4 +89,8 @@ hipError_t launch_score_rev(const ScoringDev* d_sc, const ScoringDev& h_sc, cons
                             const uint32_t* d_fwd_score, uint2* d_gtab, hipStream_t stream);
 bool score_config_for(uint32_t max_len, int* G, int* C);
 
+// zsw_filter.hip: sneaky_snake over (reference window, read) pairs
+hipError_t launch_sneaky(const BatchDev& b, const uint8_t* d_ref, uint32_t R, const uint32_t* d_ref_start,
+                         const uint32_t* d_ref_len, float threshold, uint8_t* d_out, hipStream_t stream);
+
 }  // namespace zsw
