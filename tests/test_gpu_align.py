@@ -292,3 +292,41 @@ def test_config3_large_batch_properties(za, oracle):
         assert a.key(int(i)) == okey(want), i
         if want.status == S_:
             assert oracle.score_from_path(sc, host[k], ref[want.ref_range[0] : want.ref_range[1]], a.cigar(int(i))) == want.score
+
+
+@pytest.mark.parametrize("scheme", [(1, -1, -1, -1), (2, -1, -2, -1), (2, -5, -10, -1), (5, -4, -6, -2), (1, -3, -4, -3)])
+def test_late_start_on_long_references(za, oracle, scheme):
+    """Pass 2 starts L + L*maxw/gap_extend rows before the first retained flag row instead of at row 0 (zsw_align.hip,
+    warmup_rows). Long, repetitive references and cheap gaps are where an alignment path can span the most rows: every
+    result must still equal the oracle, which always starts at row 0."""
+    ma, mi, go, ge = scheme
+    rng = np.random.default_rng(abs(hash(scheme)) % (2**32))
+    m = za.WeightMatrix.new_dna_matrix(ma, mi, b"N")
+    sc = osc(oracle, m, go, ge)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    R = 6000
+    unit = bytes(rng.choice(alpha, 37))
+    ref = bytearray(rng.choice(alpha[:2], R))           # two-letter background: many near-ties
+    for s in range(400, R - 200, 900):                  # repeated unit, so partial alignments exist far upstream
+        ref[s : s + 37] = unit
+    ref = bytes(ref)
+    reads = []
+    for _ in range(60):
+        L = int(rng.integers(20, 110))
+        s = int(rng.integers(0, R - 3 * L))
+        t = rng.random()
+        if t < 0.4:
+            r = bytearray(ref[s : s + L])
+        elif t < 0.7:                                   # long deletion relative to the reference
+            g = int(rng.integers(5, 2 * L))
+            r = bytearray(ref[s : s + L // 2] + ref[s + L // 2 + g : s + L + g])
+        else:
+            r = bytearray(unit + ref[s : s + L])
+        for _ in range(int(rng.integers(0, 3))):
+            r[int(rng.integers(0, len(r)))] = int(rng.choice(alpha))
+        reads.append(bytes(r))
+    for T, N in (("i16", 16), ("i16", 8), ("i8", 32)):
+        got = za.StripedProfileBatch(reads, m, go, ge, T, N).sw_align(za.SeqSrc.Reference(ref))
+        for i, rd in enumerate(reads):
+            want = oracle.align(T, N, sc, rd, ref)
+            assert got.key(i) == okey(want), (T, N, i, rd)

@@ -48,8 +48,22 @@ struct AlignArgs {
     uint32_t* fb_list;
     uint32_t* fb_count;
     int invert;
-    int debug;  // ZSW_ALIGN_DEBUG experiments: 1 = skip traceback, 2 = skip ring stores
+    int debug;  // ZSW_ALIGN_DEBUG experiments: 1 = skip traceback, 2 = skip ring stores, 4 = no late start
 };
+
+// Late start of pass 2. The state after row r (the H and E rows) is a (max,+) function of earlier rows in which every
+// positive term is the score of an alignment path; a path that spans `span` reference rows has at most L diagonal steps and
+// at least span - L vertical gap steps, so its score is <= L*maxw - (span - L)*gap_extend and it is positive only while
+// span < L + L*maxw/gap_extend. Rows older than that bound cannot influence the rows whose flags are kept, so the recompute
+// may start that many rows before the first retained row with a zero state and still be bit-identical (gap_extend = 0: no
+// bound, start at row 0).
+__device__ __forceinline__ int warmup_rows(const int32_t* w, int S, int ge, int l_pad) {
+    if (ge <= 0) return 0x3fffffff;
+    int maxw = 0;
+    for (int i = 0; i < S * S; ++i) maxw = max(maxw, w[i]);
+    const long long b = (long long)l_pad + ((long long)l_pad * maxw) / ge + 2;
+    return b > 0x3fffffff ? 0x3fffffff : (int)b;
+}
 
 // max(a - b, 0) for non-negative a, b: one v_sub_u32 with clamp
 __device__ __forceinline__ int32_t subsat(int32_t a, int32_t b) {
@@ -166,6 +180,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
     for (int i = lane; i < S * S; i += 64) wsh[i] = a.sc->w[i];
     __syncthreads();
     const unsigned long long gmask = (N == 64) ? ~0ull : (((1ull << N) - 1ull) << (grp * N));
+    const long long warm = warmup_rows(wsh, S, ge, (int)nv * N);
     const size_t row_bytes = (size_t)nv * N;
     uint8_t* ring = a.ring + ((size_t)blockIdx.x * RPW + grp) * (size_t)a.W * row_bytes;
 
@@ -188,10 +203,15 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
             Es[v * 64 + lane] = 0;
         }
         int rmax = rend;
+        int rmin = active ? rend : 0x7fffffff;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) rmax = max(rmax, __shfl_xor(rmax, d, 64));
+        for (int d = 32; d >= 1; d >>= 1) {
+            rmax = max(rmax, __shfl_xor(rmax, d, 64));
+            rmin = min(rmin, __shfl_xor(rmin, d, 64));
+        }
+        const int r0 = (a.debug & 4) ? 0 : max(0, (int)min((long long)rmin - (long long)a.W - warm, (long long)rmax));
 
-        for (int r = 0; r <= rmax; ++r) {
+        for (int r = r0; r <= rmax; ++r) {
             const bool act = r <= rend;
             const int ri = lut[a.ref[r]];
             const int8_t* prow = prof + (size_t)ri * nv * 64 + lane;
@@ -302,6 +322,7 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
     for (int i = lane; i < S * S; i += 64) wsh[i] = a.sc->w[i];
     __syncthreads();
     const unsigned long long gmask = (N == 64) ? ~0ull : (((1ull << N) - 1ull) << (grp * N));
+    const long long warm = warmup_rows(wsh, S, ge, nv * N);
     const size_t row_bytes = (size_t)N * nvq * 4;
     uint8_t* ring = a.ring + ((size_t)blockIdx.x * RPW + grp) * (size_t)a.W * row_bytes;
     const int W = (int)a.W;
@@ -449,7 +470,8 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
                 }
             }
         };
-        for (int r = 0; r <= rmax; ++r) {
+        const int r0 = (a.debug & 4) ? 0 : max(0, (int)min((long long)rmin - (long long)W - warm, (long long)rmax));
+        for (int r = r0; r <= rmax; ++r) {
             if (r + W > rmin) do_row(r, std::true_type{});
             else do_row(r, std::false_type{});
         }
