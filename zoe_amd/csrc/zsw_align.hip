@@ -300,32 +300,61 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
     }
 }
 
-// Register-resident form for nv <= NVMAX: H and E rows live in VGPRs (the unrolled vector loop exits at the
-// runtime nv, which is wave-uniform), the profile stays in LDS packed four scores per dword, and each row's
-// flags are assembled four per dword and stored as one run of dwords per lane.
-// Ring row layout: [lane in group][nvq*4 bytes]  (nvq = ceil(nv/4)); cell (r, c) is byte (c % nv) of lane c / nv.
-template <int N, int NVMAX>
-__global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
+// shift_elements_right::<1>(T::MIN) inside groups of N lanes as one DPP move: row_shr:1 shifts within rows of 16 lanes and
+// wave_shr:1 across the whole wavefront; lanes without a source keep `old` = 0, group-leading lanes are zeroed.
+template <int N>
+__device__ __forceinline__ int32_t shr1(int32_t x, bool li0) {
+    if constexpr (N <= 16) {
+        const int32_t y = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+        return (N < 16 && li0) ? 0 : y;
+    } else {
+        const int32_t y = __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false);
+        return (N < 64 && li0) ? 0 : y;
+    }
+}
+
+// Register-resident form specialised on NVQ = ceil(nv/4) (nv <= 32): every vector step except the last group's is
+// compiled without a bounds test, the last group runs `last` = nv - 4*(NVQ-1) steps behind wave-uniform branches.
+// H, E and the row's flags live in VGPRs at static indices; the profile is in LDS packed four scores per dword and the
+// next row's dwords are fetched while the current row computes; the reference bytes of 64 rows are fetched by one load
+// (lane k holds the profile offset of row rb+k, v_readlane hands it to the row). Rows before the first retained flag
+// row only carry the DP state (FLAGS = false).
+// Ring row layout: [lane in group][NVQ*4 bytes]; cell (r, c) is byte (c % nv) of lane c / nv.
+template <int N, int NVQ>
+__global__ __launch_bounds__(64) void align_kernel_x(AlignArgs a) {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ uint8_t lut[256];
     __shared__ int32_t wsh[MAX_S * MAX_S];
     constexpr int RPW = 64 / N;
-    constexpr int NVQMAX = NVMAX / 4;
+    constexpr int NV4 = 4 * NVQ;
     const int lane = threadIdx.x;
     const int li = lane % N, grp = lane / N;
+    const bool li0 = li == 0;
     const int nv = (int)a.nv;
-    const int nvq = (nv + 3) / 4;
+    const int last = nv - 4 * (NVQ - 1);  // 1..4 steps in the last group
     const int S = a.sc->S;
     const int go = a.sc->gap_open, ge = a.sc->gap_extend;
-    uint32_t* prof4 = reinterpret_cast<uint32_t*>(smem);  // [S][nvq][64]
+    uint32_t* prof4 = reinterpret_cast<uint32_t*>(smem);  // [S][NVQ][64]
     for (int i = lane; i < 256; i += 64) lut[i] = a.sc->index_map[i];
     for (int i = lane; i < S * S; i += 64) wsh[i] = a.sc->w[i];
     __syncthreads();
-    const unsigned long long gmask = (N == 64) ? ~0ull : (((1ull << N) - 1ull) << (grp * N));
+    // the ballot bits of this lane's group, split over the two halves of the wavefront
+    uint32_t gsel_lo, gsel_hi;
+    if constexpr (N == 64) {
+        gsel_lo = gsel_hi = ~0u;
+    } else if constexpr (N == 32) {
+        gsel_lo = grp == 0 ? ~0u : 0u;
+        gsel_hi = grp == 1 ? ~0u : 0u;
+    } else {
+        const uint32_t m = ((1u << N) - 1u) << ((grp * N) & 31);
+        gsel_lo = grp * N < 32 ? m : 0u;
+        gsel_hi = grp * N >= 32 ? m : 0u;
+    }
     const long long warm = warmup_rows(wsh, S, ge, nv * N);
-    const size_t row_bytes = (size_t)N * nvq * 4;
+    const size_t row_bytes = (size_t)N * NVQ * 4;
     uint8_t* ring = a.ring + ((size_t)blockIdx.x * RPW + grp) * (size_t)a.W * row_bytes;
     const int W = (int)a.W;
+    const uint32_t* plane = prof4 + lane;
 
     for (uint32_t first = blockIdx.x * RPW; first < a.b.n_items; first += gridDim.x * RPW) {
         const uint32_t item = first + grp;
@@ -338,7 +367,8 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
         const int32_t best = active ? (int32_t)a.score[id] : 0;
 
         // StripedProfile::new_unchecked (profile.rs:270-306), four consecutive vectors per dword
-        for (int vq = 0; vq < nvq; ++vq) {
+#pragma unroll
+        for (int vq = 0; vq < NVQ; ++vq) {
             int k[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -350,130 +380,170 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
                 uint32_t p = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) p |= (uint32_t)(uint8_t)(k[j] < 0 ? 0 : wsh[ri * S + k[j]]) << (8 * j);
-                prof4[((size_t)ri * nvq + vq) * 64 + lane] = p;
+                prof4[((size_t)ri * NVQ + vq) * 64 + lane] = p;
             }
         }
-        int32_t H[NVMAX], E[NVMAX];
+        int32_t H[NV4], E[NV4];
 #pragma unroll
-        for (int v = 0; v < NVMAX; ++v) {
+        for (int v = 0; v < NV4; ++v) {
             H[v] = 0;
             E[v] = 0;
         }
         int32_t Hlast = 0;  // previous row's H of vector nv-1
         int cend = 0x7fffffff;
-        int rmax = rend;
+        int rmax_v = rend, rmin_v = active ? rend : 0x7fffffff;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) rmax = max(rmax, __shfl_xor(rmax, d, 64));
+        for (int d = 32; d >= 1; d >>= 1) {
+            rmax_v = max(rmax_v, __shfl_xor(rmax_v, d, 64));
+            rmin_v = min(rmin_v, __shfl_xor(rmin_v, d, 64));
+        }
+        const int rmax = __builtin_amdgcn_readfirstlane(rmax_v);
+        const int rmin = __builtin_amdgcn_readfirstlane(rmin_v);
+        const int rflag = (int)max(0ll, (long long)rmin - W + 1);  // first row whose flags some read of the wave keeps
+        const int r0 = (a.debug & 4) ? 0 : (int)max(0ll, min((long long)rmin - (long long)W - warm, (long long)rmax));
 
-        // Rows that can no longer fall inside any read's retained window (r <= min r_end - W) only have to carry the DP
-        // state forward exactly; their flag arithmetic and ring stores are skipped (FLAGS = false).
-        int rmin = active ? rend : 0x7fffffff;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) rmin = min(rmin, __shfl_xor(rmin, d, 64));
+        uint32_t pn[NVQ];  // profile dwords of the row about to run
 
-        auto do_row = [&](const int r, auto flags_tag) {
+        auto do_row = [&](const int r, const uint32_t next_off, auto flags_tag) __attribute__((always_inline)) {
             constexpr bool FLAGS = decltype(flags_tag)::value;
             const bool act = r <= rend;
-            const int ri = lut[a.ref[r]];
-            const uint32_t* prow = prof4 + (size_t)ri * nvq * 64 + lane;
+            uint32_t p[NVQ];
+#pragma unroll
+            for (int vq = 0; vq < NVQ; ++vq) p[vq] = pn[vq];
+            {
+                const uint32_t* nrow = plane + next_off;
+#pragma unroll
+                for (int vq = 0; vq < NVQ; ++vq) pn[vq] = nrow[vq * 64];
+            }
             // main pass (striped.rs:481-526)
             int32_t F = 0;
-            int32_t Hd = __shfl_up(Hlast, 1, N);
-            if (li == 0) Hd = 0;
-            uint32_t flg[FLAGS ? NVMAX : 1];  // one flag byte per vector, packed four per dword only when the row is stored
+            int32_t Hd = shr1<N>(Hlast, li0);
+            uint32_t flg[FLAGS ? NV4 : 1];
+            if constexpr (FLAGS) {
 #pragma unroll
-            for (int vq = 0; vq < NVQMAX; ++vq) {
-                if (vq < nvq) {
-                    const uint32_t p4 = prow[vq * 64];
+                for (int v = NV4 - 3; v < NV4; ++v) flg[FLAGS ? v : 0] = 0;
+            }
+            auto step = [&](const int v, const uint32_t p4) __attribute__((always_inline)) {
+                const int32_t s = __builtin_amdgcn_sbfe((int)p4, 8 * (v & 3), 8);
+                const int32_t Eo = E[v];
+                const int32_t hold = H[v];
+                const int32_t h = max(Hd + s, max(Eo, F));  // Eo >= 0 supplies the floor at T::MIN
+                const int32_t hg = subsat(h, go);
+                const int32_t En = max(subsat(Eo, ge), hg);
+                const int32_t Fn = max(subsat(F, ge), hg);
+                if constexpr (FLAGS) {
+                    uint32_t fl = (Eo == h ? (uint32_t)BT_UP : 0u) | (F == h ? (uint32_t)BT_LEFT : 0u) |
+                                  (En > hg ? (uint32_t)BT_UP_EXT : 0u) | (Fn > hg ? (uint32_t)BT_LEFT_EXT : 0u);
+                    if (h == 0) fl = BT_STOP;
+                    flg[FLAGS ? v : 0] = fl;
+                }
+                H[v] = h;
+                E[v] = En;
+                F = Fn;
+                Hd = hold;
+                if (v >= NV4 - 4) Hlast = h;  // the last executed step of the last group wins
+            };
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int v = 4 * vq + j;
-                        if (FLAGS) flg[FLAGS ? v : 0] = 0;
-                        if (v < nv) {
-                            const int32_t s = __builtin_amdgcn_sbfe((int)p4, 8 * j, 8);
-                            const int32_t Eo = E[v];
-                            const int32_t hold = H[v];
-                            int32_t h = max(Hd + s, 0);
-                            h = max(h, max(Eo, F));
-                            uint32_t fl = 0;
-                            if (FLAGS) fl = (Eo == h ? (uint32_t)BT_UP : 0u) | (F == h ? (uint32_t)BT_LEFT : 0u);
-                            H[v] = h;
-                            if (v == nv - 1) Hlast = h;
-                            const int32_t hg = subsat(h, go);
-                            const int32_t En = max(subsat(Eo, ge), hg);
-                            F = max(subsat(F, ge), hg);
-                            E[v] = En;
-                            if (FLAGS) {
-                                fl |= (En > hg ? (uint32_t)BT_UP_EXT : 0u) | (F > hg ? (uint32_t)BT_LEFT_EXT : 0u);
-                                if (h == 0) fl = BT_STOP;
-                                flg[FLAGS ? v : 0] = fl;
-                            }
-                            Hd = hold;
-                        }
-                    }
+            for (int vq = 0; vq < NVQ - 1; ++vq) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) step(4 * vq + j, p[vq]);
+            }
+            step(NV4 - 4, p[NVQ - 1]);
+            if (last > 1) {
+                step(NV4 - 3, p[NVQ - 1]);
+                if (last > 2) {
+                    step(NV4 - 2, p[NVQ - 1]);
+                    if (last > 3) step(NV4 - 1, p[NVQ - 1]);
                 }
             }
             // lazy-F pass (striped.rs:528-553). A read that has left its loop (or is past its last row) carries F = 0:
             // with F = 0 a step changes neither H nor the flags (H = max(H,0); F == H only where H == 0, which stays STOP),
             // so finished reads need no predication while other reads of the wave keep iterating.
             if (!act) F = 0;
-            for (int it = 0; it < N; ++it) {
-                F = __shfl_up(F, 1, N);
-                if (li == 0) F = 0;
-                bool stop_all = false;
+            auto lazy_step = [&](const int v) __attribute__((always_inline)) -> bool {
+                const int32_t h0 = H[v];
+                const unsigned long long bal = __ballot(F > subsat(h0, go));
+                if (bal == 0) return true;  // every read of the wave has left its lazy-F loop
+                if constexpr (FLAGS) {
+                    // this read breaks out here. (Rows without flags skip the test: H is already exact for a read that
+                    // has left its loop, so further steps with its stale F cannot change H; only flags could differ.)
+                    if ((((uint32_t)bal & gsel_lo) | ((uint32_t)(bal >> 32) & gsel_hi)) == 0) F = 0;
+                }
+                const int32_t h = max(h0, F);
+                const int32_t Fn = subsat(F, ge);
+                if constexpr (FLAGS) {
+                    uint32_t fl = flg[FLAGS ? v : 0];
+                    if (F == h) fl = (fl & BT_UP_EXT) | BT_LEFT;  // simd_correct_and_set_left
+                    if (Fn > subsat(h, go)) fl |= BT_LEFT_EXT;
+                    if (h == 0) fl = BT_STOP;
+                    flg[FLAGS ? v : 0] = fl;
+                }
+                F = Fn;
+                H[v] = h;
+                if (v >= NV4 - 4) Hlast = (v - (NV4 - 4) == last - 1) ? h : Hlast;
+                return false;
+            };
+            auto lazy_round = [&]() __attribute__((always_inline)) -> bool {
 #pragma unroll
-                for (int v = 0; v < NVMAX; ++v) {
-                    if (!stop_all && v < nv) {
-                        const int32_t h0 = H[v];
-                        const unsigned long long bal = __ballot(F > subsat(h0, go));
-                        if ((bal & gmask) == 0) F = 0;  // this read breaks out of 'lazy_f here
-                        if (bal == 0) {
-                            stop_all = true;  // every read of the wave has left its lazy-F loop
-                        } else {
-                            const int32_t h = max(h0, F);
-                            if (FLAGS) {
-                                uint32_t fl = flg[FLAGS ? v : 0];
-                                if (F == h) fl = (fl & BT_UP_EXT) | BT_LEFT;  // simd_correct_and_set_left
-                                if (subsat(F, ge) > subsat(h, go)) fl |= BT_LEFT_EXT;
-                                if (h == 0) fl = BT_STOP;
-                                flg[FLAGS ? v : 0] = fl;
-                            }
-                            F = subsat(F, ge);
-                            H[v] = h;
-                            if (v == nv - 1) Hlast = h;
+                for (int v = 0; v < NV4 - 3; ++v)
+                    if (lazy_step(v)) return true;
+                if (last > 1) {
+                    if (lazy_step(NV4 - 3)) return true;
+                    if (last > 2) {
+                        if (lazy_step(NV4 - 2)) return true;
+                        if (last > 3) {
+                            if (lazy_step(NV4 - 1)) return true;
                         }
                     }
                 }
-                if (stop_all) break;
+                return false;
+            };
+#pragma unroll 1
+            for (int it = 0; it < N; ++it) {
+                F = shr1<N>(F, li0);
+                if (lazy_round()) break;
             }
-            // keep the last W rows of flags of every read still running
-            if (FLAGS) {
+            if constexpr (FLAGS) {
+                // keep the last W rows of flags of every read still running
                 if (act && r + W > rend && !(a.debug & 2)) {
-                    uint32_t* dst = reinterpret_cast<uint32_t*>(ring + (size_t)(r % W) * row_bytes) + (size_t)li * nvq;
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(ring + (size_t)(r % W) * row_bytes) + (size_t)li * NVQ;
 #pragma unroll
-                    for (int vq = 0; vq < NVQMAX; ++vq)
-                        if (vq < nvq)
-                            dst[vq] = flg[FLAGS ? 4 * vq : 0] | (flg[FLAGS ? 4 * vq + 1 : 0] << 8) | (flg[FLAGS ? 4 * vq + 2 : 0] << 16) |
-                                      (flg[FLAGS ? 4 * vq + 3 : 0] << 24);
+                    for (int vq = 0; vq < NVQ; ++vq)
+                        dst[vq] = flg[FLAGS ? 4 * vq : 0] | (flg[FLAGS ? 4 * vq + 1 : 0] << 8) | (flg[FLAGS ? 4 * vq + 2 : 0] << 16) |
+                                  (flg[FLAGS ? 4 * vq + 3 : 0] << 24);
                 }
-            }
-            // c_end at the read's last row: first query position whose H equals the best score (striped.rs:571-583)
-            if (__ballot(r == rend) != 0) {
-                if (r == rend) {
+                // c_end at the read's last row: first query position whose H equals the best score (striped.rs:571-583)
+                if (__ballot(r == rend) != 0) {
+                    if (r == rend) {
 #pragma unroll
-                    for (int v = NVMAX - 1; v >= 0; --v) {
-                        if (v < nv) {
-                            const uint32_t ci = (uint32_t)v + (uint32_t)li * (uint32_t)nv;
-                            if (ci < len && H[v] == best) cend = (int)ci;
+                        for (int v = NV4 - 1; v >= 0; --v) {
+                            if (v < nv) {
+                                const uint32_t ci = (uint32_t)v + (uint32_t)li * (uint32_t)nv;
+                                if (ci < len && H[v] == best) cend = (int)ci;
+                            }
                         }
                     }
                 }
             }
         };
-        const int r0 = (a.debug & 4) ? 0 : max(0, (int)min((long long)rmin - (long long)W - warm, (long long)rmax));
-        for (int r = r0; r <= rmax; ++r) {
-            if (r + W > rmin) do_row(r, std::true_type{});
-            else do_row(r, std::false_type{});
+
+#pragma unroll 1
+        for (int rb = r0; rb <= rmax; rb += 64) {
+            const int rr = rb + lane;
+            const uint32_t offs = rr <= rmax ? (uint32_t)lut[a.ref[rr]] * (uint32_t)(NVQ * 64) : 0u;
+            const int n = min(64, rmax - rb + 1);
+            {
+                const uint32_t* row = plane + (uint32_t)__builtin_amdgcn_readlane((int)offs, 0);
+#pragma unroll
+                for (int vq = 0; vq < NVQ; ++vq) pn[vq] = row[vq * 64];
+            }
+#pragma unroll 1
+            for (int k = 0; k < n; ++k) {
+                const int r = rb + k;
+                const uint32_t noff = (uint32_t)__builtin_amdgcn_readlane((int)offs, min(k + 1, 63));
+                if (r >= rflag) do_row(r, noff, std::true_type{});
+                else do_row(r, noff, std::false_type{});
+            }
         }
 #pragma unroll
         for (int d = 1; d < N; d <<= 1) cend = min(cend, __shfl_xor(cend, d, N));
@@ -481,7 +551,7 @@ __global__ __launch_bounds__(64) void align_kernel_reg(AlignArgs a) {
 
         if (active && li == 0 && !(a.debug & 1)) {
             auto cell = [&](int rr, int cc) -> uint32_t {
-                return __hip_atomic_load(ring + (size_t)(rr % W) * row_bytes + (size_t)(cc / nv) * (size_t)nvq * 4 + (size_t)(cc % nv),
+                return __hip_atomic_load(ring + (size_t)(rr % W) * row_bytes + (size_t)(cc / nv) * (size_t)NVQ * 4 + (size_t)(cc % nv),
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
             traceback_emit(a, id, item, len, rend, cend, best, cell);
@@ -606,10 +676,20 @@ static hipError_t launch_with_lds(K kernel, bool* attr_set, const AlignArgs& a, 
 
 template <int N>
 static hipError_t launch_align_n(const AlignArgs& a, int S, uint32_t grid, hipStream_t stream) {
-    static bool set_lds = false, set8 = false, set16 = false, set32 = false;
-    if (a.nv <= 8) return launch_with_lds(&align_kernel_reg<N, 8>, &set8, a, grid, align_lds_bytes_reg(a.nv, S), stream);
-    if (a.nv <= 16) return launch_with_lds(&align_kernel_reg<N, 16>, &set16, a, grid, align_lds_bytes_reg(a.nv, S), stream);
-    if (a.nv <= 32) return launch_with_lds(&align_kernel_reg<N, 32>, &set32, a, grid, align_lds_bytes_reg(a.nv, S), stream);
+    static bool set_lds = false, setx[9] = {};
+    const size_t lds = align_lds_bytes_reg(a.nv, S);
+    if (a.nv <= 32) {
+        switch ((a.nv + 3) / 4) {
+            case 1: return launch_with_lds(&align_kernel_x<N, 1>, &setx[1], a, grid, lds, stream);
+            case 2: return launch_with_lds(&align_kernel_x<N, 2>, &setx[2], a, grid, lds, stream);
+            case 3: return launch_with_lds(&align_kernel_x<N, 3>, &setx[3], a, grid, lds, stream);
+            case 4: return launch_with_lds(&align_kernel_x<N, 4>, &setx[4], a, grid, lds, stream);
+            case 5: return launch_with_lds(&align_kernel_x<N, 5>, &setx[5], a, grid, lds, stream);
+            case 6: return launch_with_lds(&align_kernel_x<N, 6>, &setx[6], a, grid, lds, stream);
+            case 7: return launch_with_lds(&align_kernel_x<N, 7>, &setx[7], a, grid, lds, stream);
+            case 8: return launch_with_lds(&align_kernel_x<N, 8>, &setx[8], a, grid, lds, stream);
+        }
+    }
     return launch_with_lds(&align_kernel<N>, &set_lds, a, grid, align_lds_bytes(a.nv, S), stream);
 }
 
