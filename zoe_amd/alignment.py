@@ -377,12 +377,12 @@ class _ProfileBatchBase:
         aln = torch.zeros(max(n, 1) * ALN_DTYPE.itemsize, dtype=torch.uint8, device=dev)
         status = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
         tier = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
-        cap = max(16 * n, 64)
+        cap = max(8 * n, 64)  # typical reads need 1-3 ciglets; the call reports the exact total when this is too small
         b = self.reads.c_batch()
         total = C.c_uint64(0)
         while True:
-            inc = torch.zeros(cap, dtype=torch.int32, device=dev)
-            op = torch.zeros(cap, dtype=torch.uint8, device=dev)
+            inc = torch.empty(cap, dtype=torch.int32, device=dev)
+            op = torch.empty(cap, dtype=torch.uint8, device=dev)
             fn_direct = self.ctx.lib.zsw_align_3pass_batch if three_pass else self.ctx.lib.zsw_align_batch
             fn_from = self.ctx.lib.zsw_align_3pass_batch_from if three_pass else self.ctx.lib.zsw_align_batch_from
             if direct is not None:
@@ -398,9 +398,10 @@ class _ProfileBatchBase:
             self.ctx.check(rc)
             break
         torch.cuda.synchronize(dev)
-        rec = np.frombuffer(aln.cpu().numpy().tobytes(), dtype=ALN_DTYPE)[:n]
-        return AlignmentBatch(status.cpu().numpy()[:n], rec, inc.cpu().numpy().view(np.uint32)[: total.value],
-                              op.cpu().numpy()[: total.value], tier.cpu().numpy()[:n] if direct is None else None)
+        t = int(total.value)
+        rec = aln[: n * ALN_DTYPE.itemsize].cpu().numpy().view(ALN_DTYPE)
+        return AlignmentBatch(status[:n].cpu().numpy(), rec, inc[:t].cpu().numpy().view(np.uint32), op[:t].cpu().numpy(),
+                              tier[:n].cpu().numpy() if direct is None else None)
 
 
 class StripedProfileBatch(_ProfileBatchBase):
