@@ -165,6 +165,27 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
         "reads_per_s_end_to_end_incl_d2h": 1_000_000 / dt, "kernels_ms": ks * 1e3, "ciglets": int(len(a3.inc)),
         "call": "into_local_profile(..).sw_align_from_i8_3pass(SeqSrc::Reference(ref)) (three_pass.rs: ranges, then no-gaps / banded / scalar in the box)"}
     del a, a3
+    # score + ranges (striped.rs:355-388) and the sneaky_snake filter on the window each read maps to
+    sp = zoe_amd.StripedProfileBatch(rb, matrix, -10, -1, T="i16", N=16, device=ctx.device)
+    sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rg = sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["score_ranges_1M_x_150bp_vs_2kb"] = {"reads_per_s": 1_000_000 / dt,
+                                             "call": "StripedProfile::<i16,16,5>::sw_score_ranges(SeqSrc::Reference(ref))"}
+    st = (rg.ref_start.to(torch.int64) - rg.query_start.to(torch.int64)).clamp(0, REF_LEN - READ_LEN).to(torch.int32)
+    ln = torch.full_like(st, READ_LEN)
+    zoe_amd.sneaky_snake(ref2k, rb, st, ln, 0.05)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    flt = zoe_amd.sneaky_snake(ref2k, rb, st, ln, 0.05)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["sneaky_snake_1M_x_150bp_windows"] = {"pairs_per_s": 1_000_000 / dt, "pass_fraction": float((flt == 1).float().mean()),
+                                              "call": "sneaky_snake(&ref[start..start+150], read, 0.05) per read"}
+    del rg, flt, sp
     ref30k = synth.reference_host(30000)
     rr = synth.reads_ragged_device(ctx, ref30k, 0, 1_000_000, 75, 400)
     pm = zoe_amd.into_local_profile(rr, matrix, -10, -1, device=ctx.device)
