@@ -714,6 +714,26 @@ bool score_config_for(uint32_t max_len, int* G, int* C) {
     return false;
 }
 
+// Same, for a batch of n_items reads: a small batch cannot fill 1024 SIMDs with the narrowest strips (10 k reads of 150 bp are
+// 312 wavefronts at G = 4), so it takes more lanes per read and fewer columns per lane. The score does not depend on the choice.
+// Cost model: a step issues about 7.5*C + 25 instructions; a launch is latency-bound up to ~2 waves per SIMD, throughput-bound above.
+static bool score_config_for_batch(uint32_t max_len, uint32_t n_items, int* G, int* C) {
+    double best = 0;
+    bool found = false;
+    for (const Cfg& c : kCfgs) {
+        if ((uint32_t)(c.G * c.C) < max_len) continue;
+        const double waves = ((double)((n_items + 1) / 2) * c.G) / 64.0;
+        const double cost = (7.5 * c.C + 25.0) * std::max(2048.0, waves);
+        if (!found || cost < best * 0.97) {  // ties go to the narrower configuration
+            best = cost;
+            *G = c.G;
+            *C = c.C;
+            found = true;
+        }
+    }
+    return found;
+}
+
 template <int G, int C>
 static hipError_t launch_cfg(const ScoreArgs& a, bool fast, int mode, hipStream_t stream) {
     const uint32_t reads_per_block = 2 * (BLOCK / G);
@@ -982,7 +1002,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         }
         if (timer) timer->end(stream);
     } else {
-        if (!score_config_for(max_len, &G, &C)) {  // longer than every strip configuration
+        if (!score_config_for_batch(max_len, b.n_items, &G, &C)) {  // longer than every strip configuration
             if (timer) timer->begin(stream);
             e = exact_all(b);
             if (timer) timer->end(stream);
