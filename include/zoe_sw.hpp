@@ -5,6 +5,7 @@
 //   zoe::WeightMatrix                       src/data/matrices/mod.rs:230-546
 //   zoe::ProfileError                       src/alignment/errors.rs:6-15
 //   zoe::MaybeAligned / Alignment           src/alignment/types/output.rs:18-25, 264-279
+//   zoe::StripedProfileBatch                src/alignment/profile.rs:198-552 (one StripedProfile<T,N,S> per read of a batch)
 //   zoe::LocalProfilesBatch                 src/alignment/profile_set.rs:382-483 (one LocalProfiles per read of a batch)
 // Host-memory batches; one zoe::GpuContext per GPU.
 #pragma once
@@ -140,69 +141,59 @@ class GpuContext {
     zsw_context* ctx_ = nullptr;
 };
 
-// `reads[i].into_local_profile(&matrix, gap_open, gap_extend)` for a whole batch (nucleotides/mod.rs:262-266).
-class LocalProfilesBatch {
+// ScoreEnds / ScoreAndRanges (src/alignment/types/output.rs:201-219); ranges are 0-based half-open
+struct ScoreEnds {
+    uint32_t score = 0;
+    size_t ref_end = 0, query_end = 0;
+};
+struct ScoreAndRanges {
+    uint32_t score = 0;
+    size_t ref_start = 0, ref_end = 0, query_start = 0, query_end = 0;
+};
+
+// Reads of a batch (host memory) bound to one scoring scheme; the common part of the two profile mirrors below.
+class ProfileBatchBase {
   public:
-    LocalProfilesBatch(GpuContext& ctx, const std::vector<std::string>& reads, const WeightMatrix& matrix, int8_t gap_open,
-                       int8_t gap_extend, int preset_bits = 256)
-        : ctx_(ctx), preset_(preset_bits) {
+    size_t size() const { return offsets_.size() - 1; }
+
+  protected:
+    ProfileBatchBase(GpuContext& ctx, const std::vector<std::string>& reads, const WeightMatrix& matrix, int8_t gap_open, int8_t gap_extend)
+        : ctx_(ctx) {
         offsets_.reserve(reads.size() + 1);
         offsets_.push_back(0);
         for (auto& r : reads) {
-            if (r.empty()) throw ProfileError(1);
+            if (r.empty()) throw ProfileError(1);  // validate_profile_args (profile.rs:32-44)
             bases_.insert(bases_.end(), r.begin(), r.end());
             offsets_.push_back(bases_.size());
         }
         ctx_.check(zsw_set_scoring(ctx_.raw(), matrix.weights.data(), matrix.S, matrix.mapping->index_map.data(), gap_open, gap_extend));
     }
-    // ProfileSets::sw_score_from_i8 (profile_set.rs:71-78)
-    std::vector<MaybeAligned<uint32_t>> sw_score_from_i8(const std::string& reference) { return score_from(reference, 8); }
-    std::vector<MaybeAligned<uint32_t>> sw_score_from_i16(const std::string& reference) { return score_from(reference, 16); }
-    // ProfileSets::sw_align_from_i8 with SeqSrc::Reference (profile_set.rs:124-135)
-    std::vector<MaybeAligned<Alignment>> sw_align_from_i8(const std::string& reference, bool seq_is_query = false) {
-        return align_from(reference, seq_is_query, zsw_align_batch_from);
+    zsw_batch batch() const {
+        zsw_batch b;
+        b.bases = bases_.data();
+        b.offsets = offsets_.data();
+        b.fixed_len = 0;
+        b.n_reads = offsets_.size() - 1;
+        b.mem = ZSW_MEM_HOST;
+        return b;
     }
-    // ProfileSets::sw_align_from_i8_3pass (profile_set.rs:212-235)
-    std::vector<MaybeAligned<Alignment>> sw_align_from_i8_3pass(const std::string& reference, bool seq_is_query = false) {
-        return align_from(reference, seq_is_query, zsw_align_3pass_batch_from);
-    }
-    // alignment::sneaky_snake(&reference[ref_start[i]..][..ref_len[i]], read_i, threshold) (sneaky_snake.rs:78-131):
-    // true / false per read, Status::Unmapped standing in for `None`.
-    std::vector<MaybeAligned<bool>> sneaky_snake(const std::string& reference, const std::vector<uint32_t>& ref_start,
-                                                 const std::vector<uint32_t>& ref_len, float threshold) {
-        const size_t n = offsets_.size() - 1;
-        if (ref_start.size() != n || ref_len.size() != n) throw GpuError(ZSW_ERR_INVALID_ARGUMENT, "one window per read");
+    void set_reference(const std::string& reference) {
         ctx_.check(zsw_set_reference(ctx_.raw(), (const uint8_t*)reference.data(), reference.size(), ZSW_MEM_HOST));
-        zsw_batch b = batch();
-        std::vector<uint8_t> pass(n);
-        ctx_.check(zsw_sneaky_snake_batch(ctx_.raw(), &b, ref_start.data(), ref_len.data(), threshold, pass.data(), nullptr));
-        std::vector<MaybeAligned<bool>> out(n);
-        for (size_t i = 0; i < n; ++i) {
-            out[i].status = pass[i] == ZSW_FILTER_NONE ? Status::Unmapped : Status::Some;
-            out[i].value = pass[i] == ZSW_FILTER_PASS;
-        }
-        return out;
     }
-
-  private:
-    using AlignFn = zsw_error (*)(zsw_context*, const zsw_batch*, int, int, int, zsw_alignment*, uint8_t*, uint8_t*, uint32_t*,
-                                  uint8_t*, uint64_t, uint64_t*, void*);
-    std::vector<MaybeAligned<Alignment>> align_from(const std::string& reference, bool seq_is_query, AlignFn fn) {
-        const size_t n = offsets_.size() - 1;
-        ctx_.check(zsw_set_reference(ctx_.raw(), (const uint8_t*)reference.data(), reference.size(), ZSW_MEM_HOST));
-        zsw_batch b = batch();
+    // Runs an align-type entry point (growing the ciglet buffers once if the call asks for it) and rebuilds the Alignments.
+    template <typename Call>
+    std::vector<MaybeAligned<Alignment>> collect(Call call) {
+        const size_t n = size();
         std::vector<zsw_alignment> aln(n);
-        std::vector<uint8_t> status(n), tier(n);
+        std::vector<uint8_t> status(n);
         std::vector<uint32_t> inc(16 * n + 64);
         std::vector<uint8_t> op(inc.size());
         uint64_t total = 0;
-        zsw_error e = fn(ctx_.raw(), &b, 8, preset_, seq_is_query, aln.data(), status.data(), tier.data(), inc.data(), op.data(),
-                         inc.size(), &total, nullptr);
+        zsw_error e = call(aln.data(), status.data(), inc.data(), op.data(), (uint64_t)inc.size(), &total);
         if (e == ZSW_ERR_INVALID_ARGUMENT && total > inc.size()) {
             inc.resize(total);
             op.resize(total);
-            e = fn(ctx_.raw(), &b, 8, preset_, seq_is_query, aln.data(), status.data(), tier.data(), inc.data(), op.data(),
-                   inc.size(), &total, nullptr);
+            e = call(aln.data(), status.data(), inc.data(), op.data(), (uint64_t)inc.size(), &total);
         }
         ctx_.check(e);
         std::vector<MaybeAligned<Alignment>> out(n);
@@ -222,33 +213,139 @@ class LocalProfilesBatch {
         }
         return out;
     }
-    zsw_batch batch() const {
-        zsw_batch b;
-        b.bases = bases_.data();
-        b.offsets = offsets_.data();
-        b.fixed_len = 0;
-        b.n_reads = offsets_.size() - 1;
-        b.mem = ZSW_MEM_HOST;
-        return b;
-    }
-    std::vector<MaybeAligned<uint32_t>> score_from(const std::string& reference, int width) {
-        const size_t n = offsets_.size() - 1;
-        ctx_.check(zsw_set_reference(ctx_.raw(), (const uint8_t*)reference.data(), reference.size(), ZSW_MEM_HOST));
+    GpuContext& ctx_;
+    std::vector<uint8_t> bases_;
+    std::vector<uint64_t> offsets_;
+};
+
+// `StripedProfile::<T, N, S>::new(read_i, &matrix, gap_open, gap_extend)` for every read of a batch (profile.rs:239-247).
+// Unsigned T takes the signed matrix too: the library derives the bias the way to_biased_matrix does (matrices/mod.rs:452-491).
+class StripedProfileBatch : public ProfileBatchBase {
+  public:
+    StripedProfileBatch(GpuContext& ctx, const std::vector<std::string>& reads, const WeightMatrix& matrix, int8_t gap_open,
+                        int8_t gap_extend, zsw_int_type T, int N)
+        : ProfileBatchBase(ctx, reads, matrix, gap_open, gap_extend), T_(T), N_(N) {}
+    // profile.rs:440-446 -> sw_simd_score (striped.rs:65-142)
+    std::vector<MaybeAligned<uint32_t>> sw_score(const std::string& reference) {
+        set_reference(reference);
+        const size_t n = size();
         zsw_batch b = batch();
         std::vector<uint32_t> score(n);
-        std::vector<uint8_t> status(n), tier(n);
-        ctx_.check(zsw_score_batch_from(ctx_.raw(), &b, width, preset_, score.data(), status.data(), tier.data(), nullptr));
+        std::vector<uint8_t> status(n);
+        ctx_.check(zsw_score_batch(ctx_.raw(), &b, T_, N_, score.data(), status.data(), nullptr));
         std::vector<MaybeAligned<uint32_t>> out(n);
+        for (size_t i = 0; i < n; ++i) out[i] = {(Status)status[i], score[i]};
+        return out;
+    }
+    // profile.rs:456-460 -> sw_simd_score_ends (striped.rs:153-162)
+    std::vector<MaybeAligned<ScoreEnds>> sw_score_ends(const std::string& reference) {
+        set_reference(reference);
+        const size_t n = size();
+        zsw_batch b = batch();
+        std::vector<uint32_t> score(n), re(n), qe(n);
+        std::vector<uint8_t> status(n);
+        ctx_.check(zsw_score_ends_batch(ctx_.raw(), &b, T_, N_, score.data(), re.data(), qe.data(), status.data(), nullptr));
+        std::vector<MaybeAligned<ScoreEnds>> out(n);
+        for (size_t i = 0; i < n; ++i) out[i] = {(Status)status[i], ScoreEnds{score[i], re[i], qe[i]}};
+        return out;
+    }
+    // profile.rs:529-533 -> sw_simd_score_ranges (striped.rs:355-388)
+    std::vector<MaybeAligned<ScoreAndRanges>> sw_score_ranges(const std::string& reference) {
+        set_reference(reference);
+        const size_t n = size();
+        zsw_batch b = batch();
+        std::vector<uint32_t> score(n), rs(n), re(n), qs(n), qe(n);
+        std::vector<uint8_t> status(n);
+        ctx_.check(zsw_score_ranges_batch(ctx_.raw(), &b, T_, N_, score.data(), rs.data(), re.data(), qs.data(), qe.data(), status.data(), nullptr));
+        std::vector<MaybeAligned<ScoreAndRanges>> out(n);
+        for (size_t i = 0; i < n; ++i) out[i] = {(Status)status[i], ScoreAndRanges{score[i], rs[i], re[i], qs[i], qe[i]}};
+        return out;
+    }
+    // profile.rs:515-519 -> sw_simd_align (striped.rs:449-598); seq_is_query = SeqSrc::Query (alignment/mod.rs:176-190)
+    std::vector<MaybeAligned<Alignment>> sw_align(const std::string& seq, bool seq_is_query = false) {
+        set_reference(seq);
+        zsw_batch b = batch();
+        return collect([&](zsw_alignment* aln, uint8_t* st, uint32_t* inc, uint8_t* op, uint64_t cap, uint64_t* total) {
+            return zsw_align_batch(ctx_.raw(), &b, T_, N_, seq_is_query, aln, st, inc, op, cap, total, nullptr);
+        });
+    }
+    // profile.rs:546-552 -> sw_align_3pass (three_pass.rs:21-104)
+    std::vector<MaybeAligned<Alignment>> sw_align_3pass(const std::string& seq, bool seq_is_query = false) {
+        set_reference(seq);
+        zsw_batch b = batch();
+        return collect([&](zsw_alignment* aln, uint8_t* st, uint32_t* inc, uint8_t* op, uint64_t cap, uint64_t* total) {
+            return zsw_align_3pass_batch(ctx_.raw(), &b, T_, N_, seq_is_query, aln, st, inc, op, cap, total, nullptr);
+        });
+    }
+
+  private:
+    zsw_int_type T_;
+    int N_;
+};
+
+// `reads[i].into_local_profile(&matrix, gap_open, gap_extend)` for a whole batch (nucleotides/mod.rs:262-266):
+// LocalProfiles with the i8 -> i16 -> i32 cascade of ProfileSets (profile_set.rs:71-283), lane presets w128/w256/w512.
+class LocalProfilesBatch : public ProfileBatchBase {
+  public:
+    LocalProfilesBatch(GpuContext& ctx, const std::vector<std::string>& reads, const WeightMatrix& matrix, int8_t gap_open,
+                       int8_t gap_extend, int preset_bits = 256)
+        : ProfileBatchBase(ctx, reads, matrix, gap_open, gap_extend), preset_(preset_bits) {}
+    // ProfileSets::sw_score_from_i{8,16,32} (profile_set.rs:71-107)
+    std::vector<MaybeAligned<uint32_t>> sw_score_from_i8(const std::string& reference) { return score_from(reference, 8); }
+    std::vector<MaybeAligned<uint32_t>> sw_score_from_i16(const std::string& reference) { return score_from(reference, 16); }
+    std::vector<MaybeAligned<uint32_t>> sw_score_from_i32(const std::string& reference) { return score_from(reference, 32); }
+    // ProfileSets::sw_align_from_i{8,16,32} (profile_set.rs:124-179)
+    std::vector<MaybeAligned<Alignment>> sw_align_from_i8(const std::string& seq, bool seq_is_query = false) { return align_from(seq, seq_is_query, 8, false); }
+    std::vector<MaybeAligned<Alignment>> sw_align_from_i16(const std::string& seq, bool seq_is_query = false) { return align_from(seq, seq_is_query, 16, false); }
+    std::vector<MaybeAligned<Alignment>> sw_align_from_i32(const std::string& seq, bool seq_is_query = false) { return align_from(seq, seq_is_query, 32, false); }
+    // ProfileSets::sw_align_from_i{8,16,32}_3pass (profile_set.rs:212-283)
+    std::vector<MaybeAligned<Alignment>> sw_align_from_i8_3pass(const std::string& seq, bool seq_is_query = false) { return align_from(seq, seq_is_query, 8, true); }
+    std::vector<MaybeAligned<Alignment>> sw_align_from_i16_3pass(const std::string& seq, bool seq_is_query = false) { return align_from(seq, seq_is_query, 16, true); }
+    std::vector<MaybeAligned<Alignment>> sw_align_from_i32_3pass(const std::string& seq, bool seq_is_query = false) { return align_from(seq, seq_is_query, 32, true); }
+    // alignment::sneaky_snake(&reference[ref_start[i]..][..ref_len[i]], read_i, threshold) (sneaky_snake.rs:78-131):
+    // true / false per read, Status::Unmapped standing in for `None`.
+    std::vector<MaybeAligned<bool>> sneaky_snake(const std::string& reference, const std::vector<uint32_t>& ref_start,
+                                                 const std::vector<uint32_t>& ref_len, float threshold) {
+        const size_t n = size();
+        if (ref_start.size() != n || ref_len.size() != n) throw GpuError(ZSW_ERR_INVALID_ARGUMENT, "one window per read");
+        set_reference(reference);
+        zsw_batch b = batch();
+        std::vector<uint8_t> pass(n);
+        ctx_.check(zsw_sneaky_snake_batch(ctx_.raw(), &b, ref_start.data(), ref_len.data(), threshold, pass.data(), nullptr));
+        std::vector<MaybeAligned<bool>> out(n);
         for (size_t i = 0; i < n; ++i) {
-            out[i].status = (Status)status[i];
-            out[i].value = score[i];
+            out[i].status = pass[i] == ZSW_FILTER_NONE ? Status::Unmapped : Status::Some;
+            out[i].value = pass[i] == ZSW_FILTER_PASS;
         }
         return out;
     }
-    GpuContext& ctx_;
+    // the width that answered each read of the last cascade call (8, 16 or 32)
+    const std::vector<uint8_t>& last_tiers() const { return tier_; }
+
+  private:
+    std::vector<MaybeAligned<Alignment>> align_from(const std::string& seq, bool seq_is_query, int width, bool three_pass) {
+        set_reference(seq);
+        zsw_batch b = batch();
+        tier_.assign(size(), 0);
+        return collect([&](zsw_alignment* aln, uint8_t* st, uint32_t* inc, uint8_t* op, uint64_t cap, uint64_t* total) {
+            return (three_pass ? zsw_align_3pass_batch_from : zsw_align_batch_from)(ctx_.raw(), &b, width, preset_, seq_is_query, aln, st,
+                                                                                   tier_.data(), inc, op, cap, total, nullptr);
+        });
+    }
+    std::vector<MaybeAligned<uint32_t>> score_from(const std::string& reference, int width) {
+        set_reference(reference);
+        const size_t n = size();
+        zsw_batch b = batch();
+        std::vector<uint32_t> score(n);
+        std::vector<uint8_t> status(n);
+        tier_.assign(n, 0);
+        ctx_.check(zsw_score_batch_from(ctx_.raw(), &b, width, preset_, score.data(), status.data(), tier_.data(), nullptr));
+        std::vector<MaybeAligned<uint32_t>> out(n);
+        for (size_t i = 0; i < n; ++i) out[i] = {(Status)status[i], score[i]};
+        return out;
+    }
     int preset_;
-    std::vector<uint8_t> bases_;
-    std::vector<uint64_t> offsets_;
+    std::vector<uint8_t> tier_;
 };
 
 }  // namespace zoe

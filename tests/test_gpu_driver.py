@@ -40,3 +40,16 @@ def test_driver_fastq_to_sam(tmp_path, oracle):
     for i, line in enumerate(out.stdout.splitlines()):
         st, s, _ = oracle.cascade_score(8, 256, sc, reads[i], ref)
         assert line.split("\t")[1] == (str(s) if st == 0 else "*")
+
+
+def test_cpp_mirror_known_answer_vectors():
+    """examples/zsw_selftest.cpp: the reference's known-answer tests written against the C++ mirror (include/zoe_sw.hpp)."""
+    from zoe_amd import build
+
+    exe = build.build_driver("zsw_selftest")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(__import__("torch").__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ALL PASSED" in out.stdout and "FAIL" not in out.stdout.replace("FAILED", "")
+    assert out.stdout.count("ok ") == 16

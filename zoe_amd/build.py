@@ -63,11 +63,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-def build_driver() -> str:
-    """The C++ host driver (examples/zsw_driver.cpp over include/zoe_sw.hpp), linked against the in-tree library."""
+def build_driver(name: str = "zsw_driver") -> str:
+    """A C++ host program over include/zoe_sw.hpp (examples/zsw_driver.cpp: FASTQ -> SAM; examples/zsw_selftest.cpp: the
+    reference's known-answer vectors), linked against the in-tree library."""
     root = os.path.dirname(HERE)
-    src = os.path.join(root, "examples", "zsw_driver.cpp")
-    out = os.path.join(root, "examples", "zsw_driver")
+    src = os.path.join(root, "examples", name + ".cpp")
+    out = os.path.join(root, "examples", name)
     deps = [src, os.path.join(root, "include", "zoe_sw.hpp"), os.path.join(root, "include", "zoe_sw.h"), LIB]
     if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
