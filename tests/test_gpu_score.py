@@ -202,20 +202,82 @@ def test_generic_matrix_and_i16_saturation(za, oracle):
     assert r.maybe_aligned(0) == ("Overflowed", None)
 
 
-def test_protein_alphabet_exact_kernel(za, oracle):
-    """S = 25-style alphabets fall outside the table kernels and run on the exact 32-bit kernel."""
-    rng = np.random.default_rng(3)
-    keys = b"ARNDCQEGHILKMFPSTWYV"
-    mp = za.ByteIndexMap.new(keys, b"A")
-    w = rng.integers(-4, 8, size=(20, 20)).astype(np.int8)
-    w = ((w + w.T) // 2).astype(np.int8)
-    m = za.WeightMatrix.new_custom(mp, w)
-    ref = bytes(rng.choice(np.frombuffer(keys, dtype=np.uint8), 300))
-    reads = [bytes(rng.choice(np.frombuffer(keys, dtype=np.uint8), int(rng.integers(5, 80)))) for _ in range(60)]
+def _protein_case(za, seed, S=25, lo=-4, hi=12):
+    rng = np.random.default_rng(seed)
+    keys = b"ACDEFGHIKLMNPQRSTVWYBJZX*"[:S] if S <= 25 else bytes(range(65, 65 + S))
+    mp = za.ByteIndexMap.new(keys, keys[-1:])
+    w = rng.integers(lo, 3, size=(S, S))
+    w = np.minimum(w, w.T)
+    np.fill_diagonal(w, rng.integers(4, hi, size=S))
+    w = w.astype(np.int8)
+    return rng, keys, mp, w, za.WeightMatrix.new_custom(mp, w)
+
+
+@pytest.mark.parametrize("wide", [True, False])
+def test_protein_alphabet_wide_and_exact_kernels(za, oracle, monkeypatch, wide):
+    """25-letter alphabets (the reference's BLOSUM matrices are WeightMatrix<i8, 25>, src/data/matrices/aa.rs) run on the
+    WIDE packed kernels (zsw_score_wide.hip); ZSW_SCORE_NO_WIDE forces the exact 32-bit kernel. Both must equal the oracle:
+    score, ends and ranges, fixed-length and ragged batches."""
+    if not wide:
+        monkeypatch.setenv("ZSW_SCORE_NO_WIDE", "1")
+    rng, keys, mp, w, m = _protein_case(za, 3)
+    alpha = np.frombuffer(keys[:20], dtype=np.uint8)
+    ref = bytes(rng.choice(alpha, 700))
     sc = oracle.Scoring(w, mp.index_map, -11, -1)
-    got = za.StripedProfileBatch(reads, m, -11, -1, "i16", 16).sw_score(ref)
+    reads = []
+    for i in range(150):
+        L = int(rng.integers(5, 200))
+        if i % 3 == 0:  # a mutated piece of the reference
+            s0 = int(rng.integers(0, 700 - L))
+            r = np.frombuffer(ref[s0:s0 + L], dtype=np.uint8).copy()
+            for _ in range(L // 8):
+                r[int(rng.integers(0, L))] = rng.choice(alpha)
+            reads.append(r.tobytes())
+        else:
+            reads.append(bytes(rng.choice(np.frombuffer(keys, dtype=np.uint8), L)))
+    reads.append(b"acdxyz??")  # lower case / unknown bytes go to the catch-all
+    p = za.StripedProfileBatch(reads, m, -11, -1, "i16", 16)
+    got = p.sw_score(ref)
+    ends = p.sw_score_ends(za.SeqSrc.Reference(ref))
     for i, rd in enumerate(reads):
         o_st, o_s = oracle.score("i16", 16, sc, rd, ref)
+        assert (int(got.status[i]), int(got.score[i]) if o_st == S_ else 0) == (o_st, o_s if o_st == S_ else 0), i
+        e_st, (e_s, e_r, e_q) = oracle.score_ends("i16", 16, sc, rd, ref)
+        if e_st == S_:
+            assert (int(ends.score[i]), int(ends.ref_end[i]), int(ends.query_end[i])) == (e_s, e_r, e_q), i
+    fixed = [bytes(rng.choice(alpha, 150)) for _ in range(64)] + [ref[100:250], ref[300:450]]
+    lp = za.LocalProfilesBatch.new_with_w256(fixed, m, -11, -1)
+    gf = lp.sw_score_from_i8(ref)
+    tiers = set()
+    for i, rd in enumerate(fixed):
+        o_st, o_s, o_t = oracle.cascade_score(8, 256, sc, rd, ref)
+        assert (int(gf.status[i]), int(gf.score[i]) if o_st == S_ else 0, int(gf.tier[i])) == (o_st, o_s if o_st == S_ else 0, o_t), i
+        tiers.add(o_t)
+    assert tiers == {8, 16}
+    if wide:  # ranges and alignment on top of the wide pass 1
+        rg = p.sw_score_ranges(za.SeqSrc.Reference(ref))
+        al = za.StripedProfileBatch(reads[:40], m, -11, -1, "i16", 16).sw_align(za.SeqSrc.Reference(ref))
+        for i, rd in enumerate(reads[:40]):
+            o_st, o_s, o_rr, o_qr = oracle.score_ranges("i16", 16, sc, rd, ref)
+            if o_st == S_:
+                assert (int(rg.score[i]), (int(rg.ref_start[i]), int(rg.ref_end[i])), (int(rg.query_start[i]), int(rg.query_end[i]))) == (o_s, o_rr, o_qr), i
+            want = oracle.align("i16", 16, sc, rd, ref)
+            assert al.key(i) == (want.key() if want.status == S_ else (want.status, 0, (0, 0), (0, 0), "", 0, 0)), i
+
+
+def test_wide_kernel_32_letters_and_extreme_weights(za, oracle):
+    """The full 32-letter table and scores at the edges of the signed byte (score + gap_extend in [-128, 127])."""
+    rng, keys, mp, w, m = _protein_case(za, 11, S=32, lo=-100, hi=100)
+    w[0, 1] = w[1, 0] = -127
+    w[2, 2] = 120
+    m = za.WeightMatrix.new_custom(mp, w)
+    alpha = np.frombuffer(keys, dtype=np.uint8)
+    ref = bytes(rng.choice(alpha, 400))
+    reads = [bytes(rng.choice(alpha, int(rng.integers(3, 120)))) for _ in range(80)] + [ref[50:120], bytes([keys[2]]) * 90]
+    sc = oracle.Scoring(w, mp.index_map, -20, -1)
+    got = za.LocalProfilesBatch.new_with_w256(reads, m, -20, -1).sw_score_from_i8(ref)
+    for i, rd in enumerate(reads):
+        o_st, o_s, o_t = oracle.cascade_score(8, 256, sc, rd, ref)
         assert (int(got.status[i]), int(got.score[i]) if o_st == S_ else 0) == (o_st, o_s if o_st == S_ else 0), i
 
 

@@ -25,6 +25,7 @@
 #include <algorithm>
 
 #include "zsw_internal.hpp"
+#include "zsw_score_v2.hpp"
 #include "zsw_timer.hpp"
 
 namespace zsw {
@@ -36,11 +37,6 @@ __device__ __forceinline__ uint32_t U(s2 x) { return __builtin_bit_cast(uint32_t
 __device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return U(__builtin_elementwise_add_sat(S2(a), S2(b))); }
 __device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return U(__builtin_elementwise_sub_sat(S2(a), S2(b))); }
 __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return U(__builtin_elementwise_max(S2(a), S2(b))); }
-
-constexpr int BLOCK = 256;
-constexpr int CH = 2048;       // reference rows staged in LDS per chunk
-constexpr int NEUTRAL = 8;     // table row used outside [0, R): scores 0 for every residue
-constexpr int PAD_K = 255;     // residue code of a padded query column
 
 struct ScoreArgs {
     BatchDev b;
@@ -57,15 +53,6 @@ struct ScoreArgs {
     const uint32_t* rev_score;  // forward score: the reverse pass may stop once it has been reached (see the REV loop)
     const uint2* gtab;
 };
-
-// Waves per SIMD the register allocator must leave room for: H, E and the selectors take 3*C VGPRs
-// (4*C with the MODE 2 snapshot row).
-constexpr int min_waves(int C, int MODE) {
-    // state registers (H, E, selectors [+ snapshot row]) plus ~40 temporaries; measured on the 150 bp configuration:
-    // 3 vs 4 waves/SIMD is time-neutral for this VALU-issue-bound loop, register spills are not free
-    const int need = (MODE == 2 ? 4 * C : 3 * C) + (MODE == 2 ? 44 : 36);
-    return need <= 80 ? 6 : need <= 96 ? 5 : need <= 128 ? 4 : need <= 168 ? 3 : 2;
-}
 
 // MODE 0: score; 1: score + ref_end; 2: score + ref_end + query_end
 // REV (with MODE 2): the second pass of sw_simd_score_ranges (striped.rs:355-388) — sw_simd_score_ends_reverse on
@@ -339,275 +326,6 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
     }
 }
 
-// ================================================================================================
-// score_kernel_v2 — the same recurrence in 7.5 packed instructions per two cells instead of 10.
-//
-// (1) Row drift. Every quantity of row r is stored with offset D_r = FLOOR + r*ge (per packed half, u16):
-//     E_{r+1} = max(E_r - ge, H_r - go, 0)  becomes  E~_{r+1} = max3(E~_r, H~_r - (go - ge), D_{r+1}) — the per-column decay
-//     subtraction of E disappears; G~ = F~ + ge turns the F update into max3(F~, H~ - (go - ge), D_{r+1}) with the SAME
-//     two operands, followed by F~ = G~ - ge. The +ge of H~_{r-1} -> row r is folded into the score table (t = s + ge).
-// (2) Exact 3-input max. All stored values are kept inside [0x0400, 0x7BFF], where IEEE binary16 bit patterns are positive
-//     normal numbers ordered exactly like the integers, so v_pk_maximum3_f16 is an exact packed integer max3 (no NaN, no
-//     denormal, no -0 can occur). The zero floor of local alignment is the third operand D (true 0 of the row).
-// (3) The table row holds signed 8-bit entries for A,C,G,T in bytes 1,3,5,7 (v_perm selectors 8..11 sign-extend exactly
-//     those bytes) and non-negative entries (padding, N, ...) in the even bytes.
-// The state is re-based every K rows so D stays small; a read whose true score nears the representable limit goes to the
-// exact 32-bit kernel like in v1. Results are bit-identical to v1 (tests run both).
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) {
-    // nested as max(max(a, b), c): with (E, hg, D) and (F, hg, D) the inner pairs differ, so the compiler cannot
-    // share a max(hg, D) between them (that would cost a third instruction per column)
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b)),
-                                                                       __builtin_bit_cast(h2, c)));
-}
-__device__ __forceinline__ uint32_t pk_addu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)); }
-__device__ __forceinline__ uint32_t pk_subu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b)); }
-__device__ __forceinline__ uint32_t pk_maxu(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
-}
-
-struct ScoreArgsV2 {
-    BatchDev b;
-    const uint8_t* ref;
-    uint32_t ref_len;
-    const ScoringDev* sc;
-    uint32_t wtab[9][2];  // per reference residue: the 8 table bytes (see (3)); row 8 = neutral (all entries = ge)
-    uint32_t ge2, gd2;    // packed ge and (go - ge)
-    uint32_t floor0;      // FLOOR (one half)
-    uint32_t K;           // re-base period in rows (power of two)
-    uint32_t limit;       // true scores >= limit are recomputed by the exact kernel
-    ResultRule rule;
-    ScoreOut out;
-};
-
-template <int G, int C, int MODE>
-__global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(ScoreArgsV2 a) {
-    __shared__ uint2 rp[CH + G];
-    __shared__ uint2 swt[9];
-    __shared__ uint32_t lut32[64];
-    const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut32);
-
-    const int tid = threadIdx.x;
-    const int g = tid & (G - 1);
-    const uint32_t group = blockIdx.x * (BLOCK / G) + tid / G;
-    const uint32_t itemA = 2 * group, itemB = 2 * group + 1;
-    const bool validA = itemA < a.b.n_items, validB = itemB < a.b.n_items;
-    const uint32_t idA = validA ? (a.b.items ? a.b.items[itemA] : itemA) : 0;
-    const uint32_t idB = validB ? (a.b.items ? a.b.items[itemB] : itemB) : 0;
-
-    if (tid < 64) lut32[tid] = reinterpret_cast<const uint32_t*>(a.sc->index_map)[tid];
-    if (tid < 9) swt[tid] = make_uint2(a.wtab[tid][0], a.wtab[tid][1]);
-    __syncthreads();
-
-    uint64_t offA = 0, offB = 0;
-    uint32_t lenA = 0, lenB = 0;
-    if (validA) {
-        if (a.b.offsets) {
-            offA = a.b.offsets[idA];
-            lenA = (uint32_t)(a.b.offsets[idA + 1] - offA);
-        } else {
-            offA = (uint64_t)idA * a.b.fixed_len;
-            lenA = a.b.fixed_len;
-        }
-    }
-    if (validB) {
-        if (a.b.offsets) {
-            offB = a.b.offsets[idB];
-            lenB = (uint32_t)(a.b.offsets[idB + 1] - offB);
-        } else {
-            offB = (uint64_t)idB * a.b.fixed_len;
-            lenB = a.b.fixed_len;
-        }
-    }
-
-    uint32_t sel[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const uint32_t q = (uint32_t)(g * C + c);
-        uint32_t kA = PAD_K, kB = PAD_K;
-        if (q < lenA) kA = lut[a.b.bases[offA + q]];
-        if (q < lenB) kB = lut[a.b.bases[offB + q]];
-        // residue 0..3: signed byte 2k+1, sign-extended by selector 8+k; residue 4..6: byte 2(k-3), zero-extended; pad: byte 0
-        const uint32_t sA = kA < 4 ? (2 * kA + 1) | ((8 + kA) << 8) : (kA == PAD_K ? 0x0c00u : (2 * (kA - 3)) | 0x0c00u);
-        const uint32_t sB = kB < 4 ? (2 * kB + 1) | ((8 + kB) << 8) : (kB == PAD_K ? 0x0c00u : (2 * (kB - 3)) | 0x0c00u);
-        sel[c] = sA | (sB << 16);
-    }
-
-    const uint32_t ge2 = a.ge2, gd2 = a.gd2;
-    const uint32_t ge1 = ge2 & 0xffffu;
-    const uint32_t K = a.K;
-    const uint32_t Kge2 = (K * ge1) * 0x00010001u;
-    // row of this lane at step t is r = t - g; D_r = FLOOR + r*ge with FLOOR >= 1152 + (G-1)*ge, so D_{-g-1} stays a normal f16
-    uint32_t Dr = (a.floor0 - (uint32_t)(g + 1) * ge1) * 0x00010001u;  // D of row r-1 (advanced to D_r at the top of each step)
-    uint32_t H[C], E[C];
-    uint32_t snap[MODE == 2 ? C : 1];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        H[c] = Dr;                   // H~_{r-1} = true 0 of row r-1
-        E[c] = pk_addu(Dr, ge2);     // E~_r = true 0 of row r
-    }
-    if (MODE == 2) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) snap[MODE == 2 ? c : 0] = 0;
-    }
-    uint32_t snapD = 0;
-    uint32_t best = 0;  // true scores (no offset)
-    uint32_t Fout = Dr, Hlast = Dr, Hin_prev = Dr;
-    int rA = 0, rB = 0;
-    const int R = (int)a.ref_len;
-    const int T = R + G - 1;
-
-    for (int base = 0; base < T; base += CH) {
-        __syncthreads();
-        for (int j = tid; j < CH + G - 1; j += BLOCK) {
-            const int row = base - (G - 1) + j;
-            int idx = NEUTRAL;
-            if (row >= 0 && row < R) idx = lut[a.ref[row]];
-            rp[j] = swt[idx];
-        }
-        __syncthreads();
-        const int tend = (T < base + CH) ? T : base + CH;
-        const int joff = (G - 1 - g) - base;
-        uint2 w = rp[base + joff];
-#pragma unroll 1
-        for (int t = base; t < tend; ++t) {
-            const uint2 wn = rp[t + 1 + joff];
-            const int row = t - g;
-            // re-base the lane's state when its row index reaches a multiple of K (uniform branch, rare)
-            const bool rebase = ge1 != 0 && row > 0 && (row & (int)(K - 1)) == 0;
-            if (__ballot(rebase) != 0) {
-                const uint32_t adj = rebase ? Kge2 : 0u;
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    H[c] = pk_subu(H[c], adj);
-                    E[c] = pk_subu(E[c], adj);
-                }
-                Hin_prev = pk_subu(Hin_prev, adj);
-                Dr = pk_subu(Dr, adj);
-            }
-            Dr = pk_addu(Dr, ge2);                 // D_r
-            const uint32_t Dn = pk_addu(Dr, ge2);  // D_{r+1}
-            uint32_t Fin = (uint32_t)__shfl_up((int)Fout, 1, G);
-            uint32_t Hin = (uint32_t)__shfl_up((int)Hlast, 1, G);
-            if (g == 0) {
-                Fin = Dr;
-                Hin = Dr;
-            }
-            uint32_t hd = pk_addu(Hin_prev, __builtin_amdgcn_perm(w.y, w.x, sel[0]));
-            Hin_prev = Hin;
-            uint32_t F = Fin;
-            uint32_t rmax = 0x04000400u;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                uint32_t hd_next = 0;
-                if (c + 1 < C) hd_next = pk_addu(H[c], __builtin_amdgcn_perm(w.y, w.x, sel[c + 1 < C ? c + 1 : c]));
-                const uint32_t h = pk_max3(hd, E[c], F);
-                H[c] = h;
-                const uint32_t hg = pk_subu(h, gd2);
-                E[c] = pk_max3(E[c], hg, Dn);
-                F = pk_subu(pk_max3(F, hg, Dn), ge2);
-                if (c & 1) rmax = pk_max3(rmax, H[c - (c & 1)], h);
-                else if (c == C - 1) rmax = pk_max3(rmax, h, h);
-                hd = hd_next;
-            }
-            Fout = F;
-            Hlast = H[C - 1];
-            const uint32_t tmax = pk_subu(rmax, Dr);  // true row maximum (>= 0: every H~ >= D_r)
-            const uint32_t nb = pk_maxu(best, tmax);
-            if (MODE != 0) {
-                const uint32_t ch = nb ^ best;
-                if (ch & 0xffffu) rA = row;
-                if (ch >> 16) rB = row;
-                if (MODE == 2) {
-                    const uint32_t m = ((ch & 0xffffu) ? 0xffffu : 0u) | ((ch >> 16) ? 0xffff0000u : 0u);
-#pragma unroll
-                    for (int c = 0; c < C; ++c) snap[MODE == 2 ? c : 0] = (H[c] & m) | (snap[MODE == 2 ? c : 0] & ~m);
-                    snapD = (Dr & m) | (snapD & ~m);
-                }
-            }
-            best = nb;
-            w = wn;
-        }
-    }
-
-    // ---- per-read reduction over the G lanes of the group (true scores) ----
-    int bA = (int)(best & 0xffffu), bB = (int)(best >> 16);
-    int gbA = bA, gbB = bB;
-#pragma unroll
-    for (int d = 1; d < G; d <<= 1) {
-        gbA = max(gbA, __shfl_xor(gbA, d, G));
-        gbB = max(gbB, __shfl_xor(gbB, d, G));
-    }
-    uint32_t reA = 0, reB = 0, qeA = 0, qeB = 0;
-    if (MODE != 0) {
-        int kA = (bA == gbA) ? rA : 0x7fffffff, kB = (bB == gbB) ? rB : 0x7fffffff;
-#pragma unroll
-        for (int d = 1; d < G; d <<= 1) {
-            kA = min(kA, __shfl_xor(kA, d, G));
-            kB = min(kB, __shfl_xor(kB, d, G));
-        }
-        reA = (uint32_t)kA + 1;
-        reB = (uint32_t)kB + 1;
-        if (MODE == 2) {
-            int cA = 0x7fffffff, cB = 0x7fffffff;
-            const int dA = (int)(snapD & 0xffffu), dB = (int)(snapD >> 16);
-#pragma unroll
-            for (int c = C - 1; c >= 0; --c) {
-                const uint32_t sv = snap[MODE == 2 ? c : 0];
-                if ((int)(sv & 0xffffu) - dA == gbA) cA = g * C + c;
-                if ((int)(sv >> 16) - dB == gbB) cB = g * C + c;
-            }
-            if (!(bA == gbA && rA == kA)) cA = 0x7fffffff;
-            if (!(bB == gbB && rB == kB)) cB = 0x7fffffff;
-#pragma unroll
-            for (int d = 1; d < G; d <<= 1) {
-                cA = min(cA, __shfl_xor(cA, d, G));
-                cB = min(cB, __shfl_xor(cB, d, G));
-            }
-            qeA = (uint32_t)cA + 1;
-            qeB = (uint32_t)cB + 1;
-        }
-    }
-
-    const int lane = tid & 63;
-    constexpr int RW = 2 * (64 / G);
-    const int src = (lane >> 1) * G;
-    const bool hi = lane & 1;
-    auto pick = [&](int va, int vb) {
-        const int xa = __shfl(va, src, 64), xb = __shfl(vb, src, 64);
-        return hi ? xb : xa;
-    };
-    const uint32_t o_valid = (uint32_t)pick((int)validA, (int)validB);
-    const uint32_t o_id = (uint32_t)pick((int)idA, (int)idB);
-    const uint32_t o_len = (uint32_t)pick((int)lenA, (int)lenB);
-    const int o_true = pick(gbA, gbB);
-    const uint32_t o_re = (uint32_t)pick((int)reA, (int)reB);
-    const uint32_t o_qe = (uint32_t)pick((int)qeA, (int)qeB);
-    if (lane < RW && o_valid) {
-        if (o_len == 0) {
-            a.out.score[o_id] = 0;
-            a.out.status[o_id] = ZSW_STATUS_EMPTY;
-            if (a.out.tier) a.out.tier[o_id] = 0;
-            if (MODE != 0 && a.out.ref_end) a.out.ref_end[o_id] = 0;
-            if (MODE == 2 && a.out.query_end) a.out.query_end[o_id] = 0;
-        } else if ((uint32_t)o_true >= a.limit) {  // near the representable limit: recompute exactly in 32 bits
-            const uint32_t k = atomicAdd(a.out.fb_count, 1u);
-            a.out.fb_list[k] = o_id;
-        } else {
-            uint32_t score;
-            uint8_t status, tier;
-            apply_rule(a.rule, (uint64_t)o_true, &score, &status, &tier);
-            a.out.score[o_id] = score;
-            a.out.status[o_id] = status;
-            if (a.out.tier) a.out.tier[o_id] = tier;
-            const bool some = status == ZSW_STATUS_SOME;
-            if (MODE != 0 && a.out.ref_end) a.out.ref_end[o_id] = some ? o_re : 0;
-            if (MODE == 2 && a.out.query_end) a.out.query_end[o_id] = some ? o_qe : 0;
-        }
-    }
-}
-
 // Exact 32-bit kernel: any alphabet size, any read length, no saturation below 2^31. One thread per
 // read, H/E rows in global scratch ([column][slot], coalesced over threads). Used for reads whose
 // packed-i16 score saturated, for alphabets the table kernels do not cover (S > 7) and for reads
@@ -836,9 +554,24 @@ static bool v2_ok(const ScoringDev& s) {
     return true;
 }
 
-// Fills the v2 tables for strip width G; returns false if the drifted range does not leave room for scores.
-static bool build_tables_v2(const ScoringDev& s, int G, ScoreArgsV2* a) {
+// Drift-domain constants for strip width G; returns false if the drifted range does not leave room for scores.
+static bool v2_range_setup(const ScoringDev& s, int G, ScoreArgsV2* a) {
     const int ge = s.gap_extend, go = s.gap_open;
+    a->ge2 = (uint32_t)ge * 0x00010001u;
+    a->gd2 = (uint32_t)(go - ge) * 0x00010001u;
+    uint32_t K = 2048;
+    while (K > 16 && K * (uint32_t)ge > 8192) K /= 2;
+    a->K = K;
+    a->floor0 = 1152u + (uint32_t)G * (uint32_t)ge + 128u;
+    const uint32_t dmax = a->floor0 + (K + 2) * (uint32_t)ge;
+    if (dmax + 1024 > 0x7C00u - 512u) return false;
+    a->limit = 0x7C00u - 512u - dmax;
+    return true;
+}
+
+// Fills the v2 tables for strip width G (alphabets of up to 7 letters).
+static bool build_tables_v2(const ScoringDev& s, int G, ScoreArgsV2* a) {
+    const int ge = s.gap_extend;
     for (int r = 0; r < 9; ++r) {
         uint8_t by[8];
         for (int q = 0; q < 8; ++q) by[q] = (uint8_t)ge;  // true 0 (+ge): padding, unused slots and the neutral row
@@ -851,16 +584,26 @@ static bool build_tables_v2(const ScoringDev& s, int G, ScoreArgsV2* a) {
         a->wtab[r][0] = by[0] | (by[1] << 8) | (by[2] << 16) | ((uint32_t)by[3] << 24);
         a->wtab[r][1] = by[4] | (by[5] << 8) | (by[6] << 16) | ((uint32_t)by[7] << 24);
     }
-    a->ge2 = (uint32_t)ge * 0x00010001u;
-    a->gd2 = (uint32_t)(go - ge) * 0x00010001u;
-    uint32_t K = 2048;
-    while (K > 16 && K * (uint32_t)ge > 8192) K /= 2;
-    a->K = K;
-    a->floor0 = 1152u + (uint32_t)G * (uint32_t)ge + 128u;
-    const uint32_t dmax = a->floor0 + (K + 2) * (uint32_t)ge;
-    if (dmax + 1024 > 0x7C00u - 512u) return false;
-    a->limit = 0x7C00u - 512u - dmax;
+    return v2_range_setup(s, G, a);
+}
+
+// WIDE kernels: 8..32 letters, every score + ge must fit a signed byte.
+static bool wide_ok(const ScoringDev& s) {
+    if (getenv("ZSW_SCORE_NO_WIDE")) return false;
+    if (s.S <= 7 || s.S > 32) return false;
+    for (int i = 0; i < s.S * s.S; ++i) {
+        const int t = s.w[i] + s.gap_extend;
+        if (t < -128 || t > 127) return false;
+    }
     return true;
+}
+
+static bool build_tables_wide(const ScoringDev& s, int G, ScoreArgsV2* a) {
+    const int ge = s.gap_extend;
+    for (int r = 0; r < 33; ++r)
+        for (int q = 0; q < WIDE_STRIDE; ++q)
+            a->wide[r * WIDE_STRIDE + q] = (int8_t)((r < s.S && q < s.S) ? s.w[r * s.S + q] + ge : ge);
+    return v2_range_setup(s, G, a);
 }
 
 static hipError_t launch_table_cfg(const ScoreArgs& a, int G, int C, bool fast, int mode, hipStream_t stream) {
@@ -923,7 +666,8 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     hipError_t e = hipMemsetAsync(out.fb_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     int G = 0, C = 0;
-    const bool table_ok = h_sc.S <= 7 || fast_ok(h_sc);
+    const bool wide = wide_ok(h_sc);
+    const bool table_ok = h_sc.S <= 7 || fast_ok(h_sc) || wide;
     const uint32_t exact_grid = (uint32_t)(ws.slots / 64);
     ScoreArgs a;
     a.b = b;
@@ -937,8 +681,8 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     a.rev_score = nullptr;
     a.gtab = nullptr;
     const bool fast = fast_ok(h_sc);
-    if (table_ok) build_tables(h_sc, fast, &a);
-    const bool use_v2 = table_ok && v2_ok(h_sc);
+    if (table_ok && !wide) build_tables(h_sc, fast, &a);
+    const bool use_v2 = table_ok && !wide && v2_ok(h_sc);
     ScoreArgsV2 a2;
     a2.b = b;
     a2.ref = d_ref;
@@ -947,6 +691,16 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     a2.rule = rule;
     a2.out = out;
     auto launch_one = [&](const BatchDev& bb, int g, int c) -> hipError_t {
+        if (wide) {
+            if (build_tables_wide(h_sc, g, &a2)) {
+                a2.b = bb;
+                return launch_table_cfg_v2_wide(a2, g, c, mode, stream);
+            }
+            hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, bb, (const uint32_t*)nullptr,
+                               (const uint32_t*)nullptr, d_ref, ref_len, d_sc, rule, out, ws.scratch, (uint32_t)ws.slots,
+                               ws.scratch_len, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+            return hipGetLastError();
+        }
         if (use_v2 && build_tables_v2(h_sc, g, &a2)) {
             a2.b = bb;
             return launch_table_cfg_v2(a2, g, c, mode, stream);

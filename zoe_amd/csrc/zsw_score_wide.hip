@@ -1,0 +1,41 @@
+// zsw_score_wide.hip — score_kernel_v2 for alphabets of 8..32 letters (amino acids with the BLOSUM matrices of
+// src/data/matrices/aa.rs, S = 25): the same packed drift-domain recurrence as zsw_score.hip, the substitution score of a
+// cell read from an LDS copy of the weight matrix (two signed-byte loads per packed cell pair) instead of one v_perm_b32.
+#include "zsw_score_v2.hpp"
+
+namespace zsw {
+
+template <int G, int C>
+static hipError_t launch_cfg_wide(const ScoreArgsV2& a, int mode, hipStream_t stream) {
+    const uint32_t reads_per_block = 2 * (BLOCK / G);
+    const uint32_t grid = (a.b.n_items + reads_per_block - 1) / reads_per_block;
+    if (grid == 0) return hipSuccess;
+    // MODE 1 (score + ref_end) is served by MODE 2: the query end goes nowhere when out.query_end is null
+    if (mode == 0) hipLaunchKernelGGL((score_kernel_v2<G, C, 0, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((score_kernel_v2<G, C, 2, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_table_cfg_v2_wide(const ScoreArgsV2& a, int G, int C, int mode, hipStream_t stream) {
+    switch (G * 100 + C) {
+#define ZSW_CASE(GV, CV) \
+    case GV * 100 + CV: return launch_cfg_wide<GV, CV>(a, mode, stream);
+        ZSW_CASE(4, 19)
+        ZSW_CASE(4, 25)
+        ZSW_CASE(4, 32)
+        ZSW_CASE(4, 38)
+        ZSW_CASE(8, 19)
+        ZSW_CASE(8, 25)
+        ZSW_CASE(8, 32)
+        ZSW_CASE(8, 38)
+        ZSW_CASE(16, 25)
+        ZSW_CASE(16, 32)
+        ZSW_CASE(16, 38)
+        ZSW_CASE(64, 19)
+        ZSW_CASE(64, 38)
+#undef ZSW_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace zsw
