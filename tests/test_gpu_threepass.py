@@ -123,3 +123,38 @@ def test_large_box_and_many_ciglets(za, oracle):
     got = za.StripedProfileBatch([rd], m2, -1, -1, "i16", 16).sw_align_3pass(za.SeqSrc.Reference(ref))
     want, how = oracle.align_3pass("i16", 16, osc(oracle, m2, -1, -1), rd, ref)
     assert got.key(0) == okey(want) and want.n_ciglets > 32
+
+
+def test_three_pass_with_a_25_letter_alphabet(za, oracle):
+    """Ranges + 3-pass alignment with a protein-sized alphabet: forward and reverse passes on the WIDE packed kernels
+    (zsw_score_wide.hip), third pass generic in S."""
+    rng = np.random.default_rng(17)
+    keys = b"ACDEFGHIKLMNPQRSTVWYBJZX*"
+    mp = za.ByteIndexMap.new(keys, b"X")
+    w = rng.integers(-4, 3, size=(25, 25))
+    w = np.minimum(w, w.T)
+    np.fill_diagonal(w, rng.integers(4, 12, size=25))
+    w = w.astype(np.int8)
+    m = za.WeightMatrix.new_custom(mp, w)
+    sc = oracle.Scoring(w, mp.index_map, -11, -1)
+    alpha = np.frombuffer(keys[:20], dtype=np.uint8)
+    ref = bytes(rng.choice(alpha, 900))
+    reads = []
+    for i in range(120):
+        L = int(rng.integers(20, 180))
+        s0 = int(rng.integers(0, 900 - L))
+        r = bytearray(ref[s0:s0 + L])
+        for _ in range(int(rng.integers(0, 5))):
+            k = int(rng.integers(0, len(r)))
+            t = rng.random()
+            if t < 0.5:
+                r[k] = int(rng.choice(alpha))
+            elif t < 0.75 and len(r) > 5:
+                del r[k]
+            else:
+                r.insert(k, int(rng.choice(alpha)))
+        reads.append(bytes(r) if i % 7 else bytes(rng.choice(alpha, L)))
+    got = za.LocalProfilesBatch.new_with_w256(reads, m, -11, -1).sw_align_from_i8_3pass(za.SeqSrc.Reference(ref))
+    for i, rd in enumerate(reads):
+        want, tier, _ = oracle.cascade_align_3pass(8, 256, sc, rd, ref)
+        assert got.key(i) == okey(want), i

@@ -1,6 +1,7 @@
 // zsw_score_wide.hip — score_kernel_v2 for alphabets of 8..32 letters (amino acids with the BLOSUM matrices of
 // src/data/matrices/aa.rs, S = 25): the same packed drift-domain recurrence as zsw_score.hip, the substitution score of a
 // cell read from an LDS copy of the weight matrix (two signed-byte loads per packed cell pair) instead of one v_perm_b32.
+#include "zsw_score_v1.hpp"
 #include "zsw_score_v2.hpp"
 
 namespace zsw {
@@ -36,6 +37,33 @@ hipError_t launch_table_cfg_v2_wide(const ScoreArgsV2& a, int G, int C, int mode
 #undef ZSW_CASE
     }
     return hipErrorInvalidValue;
+}
+
+// reverse pass of sw_simd_score_ranges for these alphabets (score_kernel<..., REV, WIDE>, one read per lane)
+hipError_t launch_cfg_rev_wide(const ScoreArgs& a, int G, int C, hipStream_t stream) {
+    const uint32_t reads_per_block = BLOCK / G;
+    const uint32_t grid = (a.b.n_items + reads_per_block - 1) / reads_per_block;
+    if (grid == 0) return hipSuccess;
+    switch (G * 100 + C) {
+#define ZSW_CASE(GV, CV) \
+    case GV * 100 + CV: hipLaunchKernelGGL((score_kernel<GV, CV, true, 2, true, true>), dim3(grid), dim3(BLOCK), 0, stream, a); break;
+        ZSW_CASE(4, 19)
+        ZSW_CASE(4, 25)
+        ZSW_CASE(4, 32)
+        ZSW_CASE(4, 38)
+        ZSW_CASE(8, 19)
+        ZSW_CASE(8, 25)
+        ZSW_CASE(8, 32)
+        ZSW_CASE(8, 38)
+        ZSW_CASE(16, 25)
+        ZSW_CASE(16, 32)
+        ZSW_CASE(16, 38)
+        ZSW_CASE(64, 19)
+        ZSW_CASE(64, 38)
+#undef ZSW_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 }  // namespace zsw
