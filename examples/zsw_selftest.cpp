@@ -41,6 +41,11 @@ int main() {
             CHECK(r[0].is_some() && r[0].value.score == 26 && r[0].value.query_start == 0 && r[0].value.query_end == 15 &&
                       r[0].value.ref_start == 14 && r[0].value.ref_end == 31,
                   "profile_set.rs:293 sw_score_ranges = 26, query 0..15, ref 14..31");
+            zoe::LocalProfilesBatch lp(ctx, {q1}, m42, -3, -1, 256);
+            auto rf = lp.sw_score_ranges_from_i8(ref1);
+            CHECK(rf[0].is_some() && rf[0].value.score == 26 && rf[0].value.query_end == 15 && rf[0].value.ref_start == 14 &&
+                      rf[0].value.ref_end == 31 && lp.last_tiers()[0] == 8,
+                  "profile_set.rs:293 new_with_w256(..).sw_score_ranges_from_i8 = 26, 0..15, 14..31");
             auto e = p.sw_score_ends(ref1);
             CHECK(e[0].is_some() && e[0].value.ref_end == 31 && e[0].value.query_end == 15, "striped.rs:153 sw_simd_score_ends = (31, 15)");
         }

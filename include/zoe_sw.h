@@ -127,6 +127,13 @@ zsw_error zsw_score_ranges_batch(zsw_context* ctx, const zsw_batch* reads, zsw_i
                                  uint32_t* out_score, uint32_t* out_ref_start, uint32_t* out_ref_end,
                                  uint32_t* out_query_start, uint32_t* out_query_end, uint8_t* out_status, void* stream);
 
+/* ProfileSets::sw_score_ranges_from_i{8,16,32} (src/alignment/profile_set.rs:313-362): the cascade over the tiers of the
+ * w{preset_bits} preset; out_tier (optional) = width that answered. */
+zsw_error zsw_score_ranges_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits,
+                                      uint32_t* out_score, uint32_t* out_ref_start, uint32_t* out_ref_end,
+                                      uint32_t* out_query_start, uint32_t* out_query_end, uint8_t* out_status, uint8_t* out_tier,
+                                      void* stream);
+
 /* ---- full alignment ------------------------------------------------------------------------ */
 /* out_aln[i] / out_status[i] = StripedProfile::<int_type,lanes,S>::new(read_i).sw_align(SeqSrc::Reference(reference))
  * (invert != 0: SeqSrc::Query(reference), i.e. the result passed through Alignment::invert).

@@ -294,6 +294,10 @@ class LocalProfilesBatch : public ProfileBatchBase {
     std::vector<MaybeAligned<uint32_t>> sw_score_from_i8(const std::string& reference) { return score_from(reference, 8); }
     std::vector<MaybeAligned<uint32_t>> sw_score_from_i16(const std::string& reference) { return score_from(reference, 16); }
     std::vector<MaybeAligned<uint32_t>> sw_score_from_i32(const std::string& reference) { return score_from(reference, 32); }
+    // ProfileSets::sw_score_ranges_from_i{8,16,32} (profile_set.rs:313-362)
+    std::vector<MaybeAligned<ScoreAndRanges>> sw_score_ranges_from_i8(const std::string& reference) { return ranges_from(reference, 8); }
+    std::vector<MaybeAligned<ScoreAndRanges>> sw_score_ranges_from_i16(const std::string& reference) { return ranges_from(reference, 16); }
+    std::vector<MaybeAligned<ScoreAndRanges>> sw_score_ranges_from_i32(const std::string& reference) { return ranges_from(reference, 32); }
     // ProfileSets::sw_align_from_i{8,16,32} (profile_set.rs:124-179)
     std::vector<MaybeAligned<Alignment>> sw_align_from_i8(const std::string& seq, bool seq_is_query = false) { return align_from(seq, seq_is_query, 8, false); }
     std::vector<MaybeAligned<Alignment>> sw_align_from_i16(const std::string& seq, bool seq_is_query = false) { return align_from(seq, seq_is_query, 16, false); }
@@ -331,6 +335,19 @@ class LocalProfilesBatch : public ProfileBatchBase {
             return (three_pass ? zsw_align_3pass_batch_from : zsw_align_batch_from)(ctx_.raw(), &b, width, preset_, seq_is_query, aln, st,
                                                                                    tier_.data(), inc, op, cap, total, nullptr);
         });
+    }
+    std::vector<MaybeAligned<ScoreAndRanges>> ranges_from(const std::string& reference, int width) {
+        set_reference(reference);
+        const size_t n = size();
+        zsw_batch b = batch();
+        std::vector<uint32_t> score(n), rs(n), re(n), qs(n), qe(n);
+        std::vector<uint8_t> status(n);
+        tier_.assign(n, 0);
+        ctx_.check(zsw_score_ranges_batch_from(ctx_.raw(), &b, width, preset_, score.data(), rs.data(), re.data(), qs.data(), qe.data(),
+                                               status.data(), tier_.data(), nullptr));
+        std::vector<MaybeAligned<ScoreAndRanges>> out(n);
+        for (size_t i = 0; i < n; ++i) out[i] = {(Status)status[i], ScoreAndRanges{score[i], rs[i], re[i], qs[i], qe[i]}};
+        return out;
     }
     std::vector<MaybeAligned<uint32_t>> score_from(const std::string& reference, int width) {
         set_reference(reference);

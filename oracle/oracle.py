@@ -174,6 +174,18 @@ def score_ranges(T: str, lanes: int, sc: Scoring, prof_seq, other):
     return st.value, o[0], (o[1], o[2]), (o[3], o[4])
 
 
+def cascade_score_ranges(from_width: int, preset: int, sc: Scoring, prof_seq, other):
+    """LocalProfiles::new_with_w{preset}(prof_seq).sw_score_ranges_from_i{from_width}(SeqSrc::Reference(other))
+    → (status, score, ref_range, query_range, tier)."""
+    w, im, a = _sc_args(sc)
+    ps, ot = _u8(prof_seq), _u8(other)
+    st, tier = C.c_uint32(0), C.c_int(0)
+    out = (C.c_uint64 * 5)()
+    _check(lib().zor_cascade_score_ranges(from_width, preset, *a, _p(ps), C.c_size_t(len(ps)), _p(ot), C.c_size_t(len(ot)), C.byref(st), out, C.byref(tier)))
+    o = [int(x) for x in out]
+    return st.value, o[0], (o[1], o[2]), (o[3], o[4]), tier.value
+
+
 def _aln(st, f, buf) -> Aln:
     if st != SOME:
         return Aln(status=st)

@@ -274,6 +274,24 @@ int zor_cascade_score(int from_width, int preset, int S, const int8_t* weights, 
     return 0;
 }
 
+// ProfileSets::sw_score_ranges_from_{i8,i16,i32} (profile_set.rs:313-362)
+int zor_cascade_score_ranges(int from_width, int preset, int S, const int8_t* weights, const uint8_t* index_map, int gap_open,
+                             int gap_extend, const uint8_t* prof_seq, size_t prof_len, const uint8_t* other, size_t other_len,
+                             uint32_t* out_status, uint64_t* out5, int* out_tier) {
+    int e = validate_profile_args(prof_len, gap_open, gap_extend);
+    if (e) return e;
+    const int widths[3] = {8, 16, 32};
+    for (int k = 0; k < 3; ++k) {
+        if (widths[k] < from_width) continue;
+        int rc = zor_score_ranges(k, preset / widths[k], S, weights, index_map, gap_open, gap_extend, prof_seq, prof_len, other,
+                                  other_len, out_status, out5);
+        if (rc) return rc;
+        *out_tier = widths[k];
+        if (*out_status != OVERFLOWED) break;  // or_else_overflowed (output.rs:81-83)
+    }
+    return 0;
+}
+
 // ProfileSets::sw_align_from_{i8,i16,i32} (profile_set.rs:124-179)
 int zor_cascade_align(int from_width, int preset, int S, const int8_t* weights, const uint8_t* index_map, int gap_open,
                       int gap_extend, const uint8_t* prof_seq, size_t prof_len, const uint8_t* other, size_t other_len,

@@ -390,6 +390,20 @@ def test_score_ranges_vs_oracle(za, oracle, dna):
     m = za.WeightMatrix.new_dna_matrix(4, -2, b"N")
     got = za.StripedProfileBatch([b"CGTTCGCCATAAAGGGGG"], m, -3, -1, "i8", 32).sw_score_ranges(za.SeqSrc.Reference(b"ATGCATCGATCGATCGATCGATCGATCGATGC"))
     assert (int(got.score[0]), int(got.query_start[0]), int(got.query_end[0]), int(got.ref_start[0]), int(got.ref_end[0])) == (26, 0, 15, 14, 31)
+    lp = za.LocalProfilesBatch.new_with_w256([b"CGTTCGCCATAAAGGGGG"], m, -3, -1).sw_score_ranges_from_i8(za.SeqSrc.Reference(b"ATGCATCGATCGATCGATCGATCGATCGATGC"))
+    assert (int(lp.score[0]), int(lp.query_start[0]), int(lp.query_end[0]), int(lp.ref_start[0]), int(lp.ref_end[0]), int(lp.tier[0])) == (26, 0, 15, 14, 31, 8)
+    # the cascade (profile_set.rs:313-362) on 150 bp reads: perfect reads overflow i8 and answer at i16
+    ref2 = synth.reference_host(2000)
+    host2 = synth.reads_host(ref2, 31, 300, 150)
+    casc = za.LocalProfilesBatch.new_with_w256([bytes(r) for r in host2], dna, -10, -1).sw_score_ranges_from_i8(za.SeqSrc.Reference(ref2))
+    tiers = set()
+    for i in range(300):
+        o_st, o_s, o_rr, o_qr, o_t = oracle.cascade_score_ranges(8, 256, sc, host2[i], ref2)
+        assert int(casc.status[i]) == o_st, i
+        if o_st == S_:
+            assert (int(casc.score[i]), (int(casc.ref_start[i]), int(casc.ref_end[i])), (int(casc.query_start[i]), int(casc.query_end[i])), int(casc.tier[i])) == (o_s, o_rr, o_qr, o_t), i
+            tiers.add(o_t)
+    assert tiers == {8, 16}
     # synthetic fixed-length batch
     ref = synth.reference_host(1500)
     host = synth.reads_host(ref, 777, 500, 120)

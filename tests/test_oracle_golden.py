@@ -164,6 +164,7 @@ def test_doc_profile_set_ranges(oracle):
     st, score, ref_range, query_range = oracle.score_ranges("i8", 32, sc, QRY_A, REF_A)
     assert (st, score, query_range, ref_range) == (S_, 26, (0, 15), (14, 31))
     assert oracle.cascade_score(8, 256, sc, QRY_A, REF_A) == (S_, 26, 8)  # profile_set.rs:53-68
+    assert oracle.cascade_score_ranges(8, 256, sc, QRY_A, REF_A) == (S_, 26, (14, 31), (0, 15), 8)  # the call of the doc test itself
 
 
 def test_doc_sw_mod_dna(oracle):

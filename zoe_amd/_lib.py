@@ -29,7 +29,7 @@ INT_TYPES = {"i8": 0, "i16": 1, "i32": 2, "u8": 3, "u16": 4, "u32": 5}
 # every symbol include/zoe_sw.h declares (tests/test_capi_symbols.py checks the two lists agree)
 SYMBOLS = [
     "zsw_create", "zsw_destroy", "zsw_last_error_string", "zsw_device_count", "zsw_set_scoring", "zsw_set_reference",
-    "zsw_score_batch", "zsw_score_batch_from", "zsw_score_ends_batch", "zsw_score_ranges_batch", "zsw_align_batch", "zsw_align_batch_from", "zsw_align_3pass_batch", "zsw_align_3pass_batch_from", "zsw_sneaky_snake_batch",
+    "zsw_score_batch", "zsw_score_batch_from", "zsw_score_ends_batch", "zsw_score_ranges_batch", "zsw_score_ranges_batch_from", "zsw_align_batch", "zsw_align_batch_from", "zsw_align_3pass_batch", "zsw_align_3pass_batch_from", "zsw_sneaky_snake_batch",
     "zsw_synth_reads", "zsw_synth_reads_ragged", "zsw_synth_length", "zsw_synth_reference_host", "zsw_synth_reads_host",
     "zsw_synth_reads_ragged_host", "zsw_selftest", "zsw_timing_enable", "zsw_timing_read",
 ]
@@ -94,6 +94,7 @@ def load() -> C.CDLL:
     lib.zsw_score_batch_from.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, u32p, u8p, u8p, vp]
     lib.zsw_score_ends_batch.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, u32p, u32p, u32p, u8p, vp]
     lib.zsw_score_ranges_batch.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, u32p, u32p, u32p, u32p, u32p, u8p, vp]
+    lib.zsw_score_ranges_batch_from.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, u32p, u32p, u32p, u32p, u32p, u8p, u8p, vp]
     lib.zsw_align_batch.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, C.c_int, vp, u8p, u32p, u8p, C.c_uint64, C.POINTER(C.c_uint64), vp]
     lib.zsw_align_batch_from.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, C.c_int, vp, u8p, u8p, u32p, u8p, C.c_uint64, C.POINTER(C.c_uint64), vp]
     lib.zsw_align_3pass_batch.argtypes = lib.zsw_align_batch.argtypes

@@ -523,6 +523,33 @@ class LocalProfilesBatch(_ProfileBatchBase):
     def sw_score_from_i32(self, reference) -> ScoreBatch:
         return self._score_from(reference, 32)
 
+    def _ranges_from(self, seq: SeqSrc, width: int) -> ScoreBatch:
+        """profile_set.rs:313-362: sw_score_ranges over the tiers i{width} -> i32 of this preset"""
+        torch = _torch()
+        self._prep(seq.seq)
+        n = self.reads.n_reads
+        dev = self.reads.bases.device
+        o = [torch.empty(max(n, 1), dtype=torch.int32, device=dev) for _ in range(5)]
+        status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        tier = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        b = self.reads.c_batch()
+        self.ctx.check(self.ctx.lib.zsw_score_ranges_batch_from(self.ctx.h, C.byref(b), width, self.preset, o[0].data_ptr(), o[1].data_ptr(),
+                                                                o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(), status.data_ptr(),
+                                                                tier.data_ptr(), self.ctx.stream()))
+        rs, re_, qs, qe = (x[:n] for x in o[1:])
+        if seq.is_query:
+            rs, re_, qs, qe = qs, qe, rs, re_
+        return ScoreBatch(o[0][:n], status[:n], tier=tier[:n], ref_start=rs, ref_end=re_, query_start=qs, query_end=qe)
+
+    def sw_score_ranges_from_i8(self, seq: SeqSrc) -> ScoreBatch:
+        return self._ranges_from(seq, 8)
+
+    def sw_score_ranges_from_i16(self, seq: SeqSrc) -> ScoreBatch:
+        return self._ranges_from(seq, 16)
+
+    def sw_score_ranges_from_i32(self, seq: SeqSrc) -> ScoreBatch:
+        return self._ranges_from(seq, 32)
+
     def sw_align_from_i8(self, seq: SeqSrc) -> AlignmentBatch:
         return self._align(seq, None, 8, self.preset)
 

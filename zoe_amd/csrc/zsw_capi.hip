@@ -365,7 +365,7 @@ zsw_error ranges_device(zsw_context* ctx, const Staged& st, const ResultRule& ru
 }
 
 zsw_error run_ranges(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, uint32_t* out_score, uint32_t* out_rs,
-                     uint32_t* out_re, uint32_t* out_qs, uint32_t* out_qe, uint8_t* out_status, void* stream_) {
+                     uint32_t* out_re, uint32_t* out_qs, uint32_t* out_qe, uint8_t* out_status, uint8_t* out_tier, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     if (!reads || !out_score || !out_rs || !out_re || !out_qs || !out_qe || !out_status)
@@ -389,6 +389,7 @@ zsw_error run_ranges(zsw_context* ctx, const zsw_batch* reads, const ResultRule&
     uint32_t* devs[5] = {rd.score, rd.rs, rd.re, rd.qs, rd.qe};
     for (int k = 0; k < 5; ++k) ZSW_HIP(ctx, hipMemcpyAsync(outs[k], devs[k], (size_t)n * 4, kind, stream));
     ZSW_HIP(ctx, hipMemcpyAsync(out_status, rd.status, n, kind, stream));
+    if (out_tier) ZSW_HIP(ctx, hipMemcpyAsync(out_tier, rd.tier, n, kind, stream));
     if (reads->mem == ZSW_MEM_HOST) ZSW_HIP(ctx, hipStreamSynchronize(stream));
     return ZSW_OK;
 }
@@ -911,7 +912,19 @@ zsw_error zsw_score_ranges_batch(zsw_context* ctx, const zsw_batch* reads, zsw_i
     if (!valid_lanes(lanes)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "lanes must be a power of two in 2..64");
     ResultRule rule;
     if (!rule_direct(int_type, ctx->bias, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "bad int_type");
-    return run_ranges(ctx, reads, rule, out_score, out_ref_start, out_ref_end, out_query_start, out_query_end, out_status, stream);
+    return run_ranges(ctx, reads, rule, out_score, out_ref_start, out_ref_end, out_query_start, out_query_end, out_status, nullptr, stream);
+}
+
+zsw_error zsw_score_ranges_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits,
+                                      uint32_t* out_score, uint32_t* out_ref_start, uint32_t* out_ref_end,
+                                      uint32_t* out_query_start, uint32_t* out_query_end, uint8_t* out_status, uint8_t* out_tier,
+                                      void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (preset_bits != 128 && preset_bits != 256 && preset_bits != 512) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "preset_bits");
+    ResultRule rule;
+    if (!rule_cascade(from_width, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "from_width");
+    return run_ranges(ctx, reads, rule, out_score, out_ref_start, out_ref_end, out_query_start, out_query_end, out_status, out_tier,
+                      stream);
 }
 
 zsw_error zsw_align_3pass_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, int invert,
