@@ -55,3 +55,12 @@ def test_shard_range():
             for (f0, c0), (f1, _) in zip(parts, parts[1:]):
                 assert f0 + c0 == f1
             assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def test_shared_profiles_mirror_is_the_local_one_under_another_name():
+    # profile_set.rs:552-700: SharedProfiles has the methods of LocalProfiles (ProfileSets trait)
+    import zoe_amd
+
+    assert issubclass(zoe_amd.SharedProfilesBatch, zoe_amd.LocalProfilesBatch)
+    for name in ("sw_score_from_i8", "sw_align_from_i16", "sw_align_from_i32_3pass", "sw_score_ranges_from_i8"):
+        assert hasattr(zoe_amd.SharedProfilesBatch, name)

@@ -597,3 +597,13 @@ def sneaky_snake(reference, reads, ref_start, ref_len, threshold: float, device:
 def into_local_profile(reads, matrix: WeightMatrix, gap_open: int, gap_extend: int, device: int = 0) -> LocalProfilesBatch:
     """Nucleotides::into_local_profile (nucleotides/mod.rs:262-266): the w256 preset."""
     return LocalProfilesBatch.new_with_w256(reads, matrix, gap_open, gap_extend, device)
+
+
+class SharedProfilesBatch(LocalProfilesBatch):
+    """`SharedProfiles` (profile_set.rs:552-700): the same lazily built i8/i16/i32 profile set, `Sync` in the reference.
+    A batch object here holds no lazily initialised state, so the two mirrors only differ in name."""
+
+
+def into_shared_profile(reads, matrix: WeightMatrix, gap_open: int, gap_extend: int, device: int = 0) -> SharedProfilesBatch:
+    """Nucleotides::into_shared_profile (nucleotides/mod.rs:295-299): SharedProfiles<32, 16, 8, S>"""
+    return SharedProfilesBatch(reads, matrix, gap_open, gap_extend, preset=256, device=device)
