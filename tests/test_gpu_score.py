@@ -463,3 +463,35 @@ def test_full_size_10m_reads_properties(za, oracle, dna, monkeypatch):
     ws, wst, wt = oracle.batch_score_w256(8, osc(oracle, dna, -10, -1), host, ref, fixed_len=150, threads=16)
     assert np.array_equal(s2.cpu().numpy()[idx].view(np.uint32), ws) and np.array_equal(st2.cpu().numpy()[idx], wst)
     assert np.array_equal(t2.cpu().numpy()[idx], wt)
+
+
+def test_host_batch_pipeline_matches_device_batch(za, oracle, dna):
+    """Host-memory batches above one chunk are scored chunk by chunk with the next chunk's H2D copy in flight
+    (zsw_capi.hip run_score): the results must equal the device-resident call and, on a sample, the oracle."""
+    import ctypes as C
+
+    import torch
+
+    from zoe_amd import _lib, synth
+
+    n, L = 5_300_000, 150  # three chunks, the last one partial
+    ref = synth.reference_host(2000)
+    ctx = za.SwContext.get(0)
+    rb = synth.reads_device(ctx, ref, 0, n, L)
+    dev = za.into_local_profile(rb, dna, -10, -1).sw_score_from_i8(ref)
+    dscore, dstatus, dtier = dev.score.cpu().numpy().view(np.uint32), dev.status.cpu().numpy(), dev.tier.cpu().numpy()
+    host = rb.bases.cpu().numpy()
+    lib = _lib.load()
+    b = _lib.ZswBatch()
+    b.bases, b.offsets, b.fixed_len, b.n_reads, b.mem = host.ctypes.data, None, L, n, _lib.MEM_HOST
+    score = np.zeros(n, dtype=np.uint32)
+    status = np.full(n, 9, dtype=np.uint8)
+    tier = np.zeros(n, dtype=np.uint8)
+    assert lib.zsw_score_batch_from(ctx.h, C.byref(b), 8, 256, score.ctypes.data, status.ctypes.data, tier.ctypes.data, None) == 0
+    assert np.array_equal(score, dscore) and np.array_equal(status, dstatus) and np.array_equal(tier, dtier)
+    sc = osc(oracle, dna, -10, -1)
+    for i in list(range(0, 200)) + list(range(2_499_900, 2_500_100)) + list(range(n - 100, n)):
+        o_st, o_s, o_t = oracle.cascade_score(8, 256, sc, host[i * L:(i + 1) * L], ref)
+        assert (int(status[i]), int(score[i]) if o_st == S_ else 0) == (o_st, o_s if o_st == S_ else 0), i
+    del dev, rb
+    torch.cuda.empty_cache()

@@ -56,6 +56,9 @@ struct zsw_context {
     DevBuf r_ws[20];
     KernelTimer timer;
     std::string err;
+    // host batches: reads of chunk k+1 cross PCIe on this stream while chunk k computes
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> copy_events;
 };
 
 namespace {
@@ -159,7 +162,7 @@ struct Staged {
 // Brings a batch to the device (or validates device pointers), finds the longest read and sizes the workspace.
 zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bool want_tier, bool want_ends,
                 uint32_t* out_score, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_rend, uint32_t* out_qend,
-                Staged* st) {
+                Staged* st, bool defer_bases_copy = false) {
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     if (!ctx->scoring_set || !ctx->reference_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "scoring/reference not set");
     if (!reads || !out_score || !out_status) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
@@ -175,7 +178,7 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     if (reads->mem == ZSW_MEM_HOST) {
         size_t total = reads->offsets ? (size_t)reads->offsets[n] : (size_t)n * reads->fixed_len;
         ZSW_HIP(ctx, ctx->s_bases.ensure(total + 16));
-        ZSW_HIP(ctx, hipMemcpyAsync(ctx->s_bases.p, reads->bases, total, hipMemcpyHostToDevice, stream));
+        if (!defer_bases_copy) ZSW_HIP(ctx, hipMemcpyAsync(ctx->s_bases.p, reads->bases, total, hipMemcpyHostToDevice, stream));
         st->b.bases = ctx->s_bases.as<uint8_t>();
         st->b.offsets = nullptr;
         st->max_len = reads->fixed_len;
@@ -260,12 +263,17 @@ zsw_error unstage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, 
     return ZSW_OK;
 }
 
+constexpr uint32_t PIPE_CHUNK = 2'500'000;  // reads per chunk of the host-batch pipeline (375 MB at 150 bp)
+
 zsw_error run_score(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, bool want_ends, uint32_t* out_score,
                     uint8_t* out_status, uint8_t* out_tier, uint32_t* out_rend, uint32_t* out_qend, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     Staged st;
+    // fixed-length host batches of more than one chunk: the H2D copy of chunk k+1 overlaps the kernel of chunk k
+    const bool pipelined = reads && reads->mem == ZSW_MEM_HOST && !reads->offsets && reads->fixed_len > 0 &&
+                           reads->n_reads > PIPE_CHUNK && !getenv("ZSW_NO_PIPELINE");
     zsw_error ze = stage(ctx, reads, stream, out_tier != nullptr, want_ends, out_score, out_status, out_tier, out_rend,
-                         out_qend, &st);
+                         out_qend, &st, pipelined);
     if (ze != ZSW_OK) return ze;
     if (reads->n_reads == 0) return ZSW_OK;
     ScoreOut out;
@@ -276,9 +284,45 @@ zsw_error run_score(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     out.query_end = st.d_qend;
     out.fb_list = ctx->d_fb_list.as<uint32_t>();
     out.fb_count = ctx->d_fb_count.as<uint32_t>();
-    hipError_t e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(),
-                                (uint32_t)ctx->ref_len, rule, out, score_ws(ctx), stream, &ctx->timer, want_ends ? 2 : 0);
-    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "score launch", e);
+    if (!pipelined) {
+        hipError_t e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(),
+                                    (uint32_t)ctx->ref_len, rule, out, score_ws(ctx), stream, &ctx->timer, want_ends ? 2 : 0);
+        if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "score launch", e);
+        return unstage(ctx, reads, stream, st, out_score, out_status, out_tier, out_rend, out_qend);
+    }
+    const uint32_t n = (uint32_t)reads->n_reads, L = reads->fixed_len;
+    const uint32_t n_chunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
+    if (!ctx->copy_stream) ZSW_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    while (ctx->copy_events.size() < n_chunks) {
+        hipEvent_t ev;
+        ZSW_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->copy_events.push_back(ev);
+    }
+    auto copy_chunk = [&](uint32_t k) -> hipError_t {
+        const size_t first = (size_t)k * PIPE_CHUNK, cnt = std::min<size_t>(PIPE_CHUNK, n - first);
+        hipError_t e = hipMemcpyAsync(ctx->s_bases.as<uint8_t>() + first * L, reads->bases + first * L, cnt * L, hipMemcpyHostToDevice,
+                                      ctx->copy_stream);
+        if (e != hipSuccess) return e;
+        return hipEventRecord(ctx->copy_events[k], ctx->copy_stream);
+    };
+    ZSW_HIP(ctx, copy_chunk(0));
+    for (uint32_t k = 0; k < n_chunks; ++k) {
+        const uint32_t first = k * PIPE_CHUNK, cnt = std::min<uint32_t>(PIPE_CHUNK, n - first);
+        ZSW_HIP(ctx, hipStreamWaitEvent(stream, ctx->copy_events[k], 0));
+        BatchDev bk = st.b;
+        bk.bases = st.b.bases + (size_t)first * L;
+        bk.n_reads = bk.n_items = cnt;
+        ScoreOut ok = out;
+        ok.score = out.score + first;
+        ok.status = out.status + first;
+        if (out.tier) ok.tier = out.tier + first;
+        if (out.ref_end) ok.ref_end = out.ref_end + first;
+        if (out.query_end) ok.query_end = out.query_end + first;
+        hipError_t e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, bk, st.max_len, ctx->d_ref.as<uint8_t>(),
+                                    (uint32_t)ctx->ref_len, rule, ok, score_ws(ctx), stream, &ctx->timer, want_ends ? 2 : 0);
+        if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "score launch", e);
+        if (k + 1 < n_chunks) ZSW_HIP(ctx, copy_chunk(k + 1));  // issued after the launch: it runs under chunk k's kernel
+    }
     return unstage(ctx, reads, stream, st, out_score, out_status, out_tier, out_rend, out_qend);
 }
 
@@ -829,6 +873,8 @@ void zsw_destroy(zsw_context* ctx) {
     for (DevBuf& b : ctx->a_ws) b.release();
     for (DevBuf& b : ctx->r_ws) b.release();
     ctx->timer.destroy();
+    for (hipEvent_t ev : ctx->copy_events) (void)hipEventDestroy(ev);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     delete ctx;
 }
 
