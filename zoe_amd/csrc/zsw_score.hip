@@ -23,6 +23,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
+#include <new>
 
 #include "zsw_internal.hpp"
 #include "zsw_score_v1.hpp"
@@ -365,6 +367,31 @@ __global__ void bucket_scatter_kernel(const uint64_t* offsets, uint32_t n, Bucke
     }
 }
 
+// Side streams for the ragged path (one set per device, created on first use, never destroyed: process lifetime).
+struct SideStreams {
+    static constexpr int N = 4;
+    hipStream_t s[N];
+    hipEvent_t fork, join[N];
+};
+static SideStreams* side_streams() {
+    static SideStreams* per_device[64] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!per_device[dev]) {
+        SideStreams* p = new (std::nothrow) SideStreams();
+        if (!p) return nullptr;
+        bool ok = hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < SideStreams::N; ++i)
+            ok = hipStreamCreateWithFlags(&p->s[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&p->join[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) return nullptr;  // leaks a few handles in a situation where nothing else works either
+        per_device[dev] = p;
+    }
+    return per_device[dev];
+}
+
 hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
                         const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
                         const ScoreWorkspace& ws, hipStream_t stream, KernelTimer* timer, int mode) {
@@ -447,17 +474,41 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3(hgrid), dim3(256), 0, stream, b.offsets, b.n_items, caps,
                            ws.bucket_counts + 32, ws.bucket_items);
         if (timer) timer->begin(stream);
-        for (int k = 0; k <= NCLS; ++k) {
+        // The length classes are independent launches and the small ones cannot fill the chip on their own (a class of
+        // 70 k reads is two wavefronts per SIMD): they are spread over side streams, forked from and joined to `stream`.
+        SideStreams* side = side_streams();
+        const bool fork = side != nullptr && !getenv("ZSW_NO_SIDE_STREAMS");
+        if (fork) {
+            e = hipEventRecord(side->fork, stream);
+            if (e != hipSuccess) return e;
+            for (int i = 0; i < SideStreams::N; ++i) {
+                e = hipStreamWaitEvent(side->s[i], side->fork, 0);
+                if (e != hipSuccess) return e;
+            }
+        }
+        const hipStream_t main_stream = stream;
+        int used = 0;
+        for (int k = NCLS; k >= 0; --k) {  // longest class first
             if (!counts[k]) continue;
             BatchDev bk = b;
             bk.items = ws.bucket_items + starts[k];
             bk.n_items = counts[k];
             if (k == NCLS) {
-                e = exact_all(bk);
+                e = exact_all(bk);  // shares the scratch rows with the fallback pass below: stays on the main stream
             } else {
+                stream = fork ? side->s[used++ % SideStreams::N] : main_stream;
                 e = launch_one(bk, kCfgs[kBucketCfg[k]].G, kCfgs[kBucketCfg[k]].C);
+                stream = main_stream;
             }
             if (e != hipSuccess) return e;
+        }
+        if (fork) {
+            for (int i = 0; i < SideStreams::N; ++i) {
+                e = hipEventRecord(side->join[i], side->s[i]);
+                if (e != hipSuccess) return e;
+                e = hipStreamWaitEvent(stream, side->join[i], 0);
+                if (e != hipSuccess) return e;
+            }
         }
         if (timer) timer->end(stream);
     } else {
