@@ -4,7 +4,7 @@
 // POS = ref_range.start + 1, CIGAR = states, AS:i = score.
 //
 //   g++ -O2 -std=c++17 -Iinclude examples/zsw_driver.cpp -o examples/zsw_driver -Lzoe_amd -lzoe_sw_hip -Wl,-rpath,$PWD/zoe_amd
-//   ./examples/zsw_driver reference.txt reads.fastq [--score-only]
+//   ./examples/zsw_driver reference.txt reads.fastq [--score-only | --3pass]
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -31,10 +31,11 @@ static std::string read_reference(const std::string& path, std::string* name) {
 
 int main(int argc, char** argv) {
     if (argc < 3) {
-        std::cerr << "usage: zsw_driver reference.(fa|txt) reads.fastq [--score-only]\n";
+        std::cerr << "usage: zsw_driver reference.(fa|txt) reads.fastq [--score-only | --3pass]\n";
         return 2;
     }
     const bool score_only = argc > 3 && !std::strcmp(argv[3], "--score-only");
+    const bool three_pass = argc > 3 && !std::strcmp(argv[3], "--3pass");  // sw_align_from_i8_3pass instead of sw_align_from_i8
     try {
         std::string ref_name;
         const std::string reference = read_reference(argv[1], &ref_name);
@@ -57,7 +58,7 @@ int main(int argc, char** argv) {
                 std::cout << names[i] << '\t' << (scores[i].is_some() ? std::to_string(scores[i].value) : std::string("*")) << '\n';
             return 0;
         }
-        auto alns = profiles.sw_align_from_i8(reference);
+        auto alns = three_pass ? profiles.sw_align_from_i8_3pass(reference) : profiles.sw_align_from_i8(reference);
         std::cout << "@HD\tVN:1.6\n@SQ\tSN:" << ref_name << "\tLN:" << reference.size() << '\n';
         for (size_t i = 0; i < reads.size(); ++i) {
             if (alns[i].is_some()) {

@@ -35,6 +35,16 @@ def test_driver_fastq_to_sam(tmp_path, oracle):
             assert (f[1], f[2], int(f[3]), f[5], f[11]) == ("0", "synthref", want.ref_range[0] + 1, want.cigar, f"AS:i:{want.score}"), i
         else:
             assert f[1] == "4" and f[5] == "*"
+    out = subprocess.run([exe, str(tmp_path / "ref.fa"), str(tmp_path / "reads.fq"), "--3pass"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines3 = [l for l in out.stdout.splitlines() if not l.startswith("@")]
+    for i, line in enumerate(lines3):
+        f = line.split("\t")
+        want, _, _ = oracle.cascade_align_3pass(8, 256, sc, reads[i], ref)
+        if want.status == 0:
+            assert (f[1], int(f[3]), f[5], f[11]) == ("0", want.ref_range[0] + 1, want.cigar, f"AS:i:{want.score}"), i
+        else:
+            assert f[1] == "4"
     out = subprocess.run([exe, str(tmp_path / "ref.fa"), str(tmp_path / "reads.fq"), "--score-only"], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr
     for i, line in enumerate(out.stdout.splitlines()):
