@@ -166,6 +166,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ uint8_t lut[256];
     __shared__ int32_t wsh[MAX_S * MAX_S];
+    __shared__ int32_t wpad[MAX_S * (MAX_S + 1)];  // weights with one more column: the padding residue S scores 0
     constexpr int RPW = 64 / N;
     const int lane = threadIdx.x;
     const int li = lane % N, grp = lane / N;
@@ -174,10 +175,13 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
     const int go = a.sc->gap_open, ge = a.sc->gap_extend;
     int32_t* Hs = reinterpret_cast<int32_t*>(smem);  // [nv][64]
     int32_t* Es = Hs + nv * 64;                      // [nv][64]
-    int8_t* prof = reinterpret_cast<int8_t*>(Es + nv * 64);  // [S][nv][64]
-    uint8_t* fl = reinterpret_cast<uint8_t*>(prof + (size_t)S * nv * 64);  // [nv][64]
+    // the striped profile as residue codes [nv][64] (S = padding, scoring 0); the score of a cell is a second LDS lookup in the
+    // weight matrix, so the footprint does not grow with the alphabet and nv up to ~250 fits one wavefront's LDS
+    uint8_t* kq = reinterpret_cast<uint8_t*>(Es + nv * 64);
+    uint8_t* fl = kq + (size_t)nv * 64;  // [nv][64]
     for (int i = lane; i < 256; i += 64) lut[i] = a.sc->index_map[i];
     for (int i = lane; i < S * S; i += 64) wsh[i] = a.sc->w[i];
+    for (int i = lane; i < S * (S + 1); i += 64) wpad[i] = (i % (S + 1)) < S ? a.sc->w[(i / (S + 1)) * S + i % (S + 1)] : 0;
     __syncthreads();
     const unsigned long long gmask = (N == 64) ? ~0ull : (((1ull << N) - 1ull) << (grp * N));
     const long long warm = warmup_rows(wsh, S, ge, (int)nv * N);
@@ -197,8 +201,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
         // StripedProfile::new_unchecked (profile.rs:270-306): position q = v + lane*nv; padding scores bias (= true 0)
         for (uint32_t v = 0; v < nv; ++v) {
             const uint32_t q = v + (uint32_t)li * nv;
-            const int k = (active && q < len) ? (int)lut[a.b.bases[off + q]] : -1;
-            for (int ri = 0; ri < S; ++ri) prof[((size_t)ri * nv + v) * 64 + lane] = k < 0 ? (int8_t)0 : (int8_t)wsh[ri * S + k];
+            kq[v * 64 + lane] = (active && q < len) ? lut[a.b.bases[off + q]] : (uint8_t)S;
             Hs[v * 64 + lane] = 0;
             Es[v * 64 + lane] = 0;
         }
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
         for (int r = r0; r <= rmax; ++r) {
             const bool act = r <= rend;
             const int ri = lut[a.ref[r]];
-            const int8_t* prow = prof + (size_t)ri * nv * 64 + lane;
+            const int32_t* wrow = wpad + ri * (S + 1);
             // main pass (striped.rs:481-526)
             int32_t F = 0;
             int32_t H = __shfl_up(Hs[(nv - 1) * 64 + lane], 1, N);
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
             for (uint32_t v = 0; v < nv; ++v) {
                 int32_t E = Es[v * 64 + lane];
                 const int32_t hold = Hs[v * 64 + lane];
-                H = max(H + (int32_t)prow[v * 64], 0);
+                H = max(H + wrow[kq[v * 64 + lane]], 0);
                 H = max(H, max(E, F));
                 uint32_t flags = (E == H ? BT_UP : 0) | (F == H ? BT_LEFT : 0);
                 const bool stopped = H == 0;
@@ -659,14 +662,14 @@ __global__ void write_ciglets_kernel(zsw_alignment* aln, const uint8_t* status, 
     aln[i] = rec;
 }
 
-static size_t align_lds_bytes(uint32_t nv, int S) { return (size_t)nv * 64 * (4 + 4 + (size_t)S + 1); }
+static size_t align_lds_bytes(uint32_t nv, int S) { (void)S; return (size_t)nv * 64 * (4 + 4 + 1 + 1); }
 static size_t align_lds_bytes_reg(uint32_t nv, int S) { return (size_t)S * ((nv + 3) / 4) * 64 * 4; }
 
 template <typename K>
 static hipError_t launch_with_lds(K kernel, bool* attr_set, const AlignArgs& a, uint32_t grid, size_t lds, hipStream_t stream) {
     if (!*attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024 - 6 * 1024);
+                                           160 * 1024 - 9 * 1024);
         if (e != hipSuccess) return e;
         *attr_set = true;
     }

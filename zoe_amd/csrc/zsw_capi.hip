@@ -581,7 +581,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     }
     const int S = ctx->h_sc.S;
     for (auto& g : groups)
-        if (align_lds_need(g.nv, S) + 4352 + 64 > 160 * 1024)
+        if (align_lds_need(g.nv, S) + 9216 > 160 * 1024)
             return fail(ctx, ZSW_ERR_UNSUPPORTED, "read too long for the alignment kernel's LDS-resident profile");
 
     const uint32_t MAXC = 32;
