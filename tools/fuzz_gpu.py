@@ -76,6 +76,25 @@ for it in range(iters):
     c_al = lp._align(src, None, from_width=width, preset=preset)
     c_3p = lp._align(src, None, from_width=width, preset=preset, three_pass=True)
     c_rg = lp._ranges_from(za.SeqSrc.Reference(ref), width)
+    # the same batch through HOST pointers (staging path of the C ABI) and the sneaky_snake filter on random windows
+    import ctypes as C
+    from zoe_amd import _lib
+    lib = _lib.load()
+    cat = np.frombuffer(b"".join(reads), dtype=np.uint8).copy()
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    hb = _lib.ZswBatch()
+    hb.bases, hb.offsets, hb.fixed_len, hb.n_reads, hb.mem = cat.ctypes.data, offs.ctypes.data, 0, len(reads), _lib.MEM_HOST
+    h_score = np.zeros(len(reads), dtype=np.uint32); h_status = np.zeros(len(reads), dtype=np.uint8); h_tier = np.zeros(len(reads), dtype=np.uint8)
+    assert lib.zsw_score_batch_from(lp.ctx.h, C.byref(hb), width, preset, h_score.ctypes.data, h_status.ctypes.data, h_tier.ctypes.data, None) == 0
+    assert np.array_equal(h_status, c_sc.status.cpu().numpy()) and np.array_equal(np.where(h_status == 0, h_score, 0), np.where(h_status == 0, c_sc.score.cpu().numpy().view(np.uint32), 0)), ("host score", it)
+    thr = float(rng.choice([0.0, 0.05, 0.1, 0.3, 1.0]))
+    ws = [int(rng.integers(0, max(1, R - len(r) + 1))) if len(r) <= R else 0 for r in reads]
+    wl = [int(np.clip(len(r) + rng.integers(-2, 3), 0, R - s0)) for r, s0 in zip(reads, ws)]
+    g_ss = za.sneaky_snake(ref, reads, ws, wl, thr).cpu().numpy()
+    for i, rd in enumerate(reads):
+        want = oracle.sneaky_snake(ref[ws[i]:ws[i] + wl[i]], rd, thr)
+        assert int(g_ss[i]) == {False: 0, True: 1, None: 2}[want], ("sneaky", it, i, thr, ws[i], wl[i])
     for i, rd in enumerate(reads):
         ctxt = (it, i, T, N, preset, width, inv, go, ge, protein)
         st, s = oracle.score(T, N, sc, rd, ref)
@@ -101,4 +120,4 @@ for it in range(iters):
             assert (int(c_rg.score[i]), (int(c_rg.ref_start[i]), int(c_rg.ref_end[i])), (int(c_rg.query_start[i]), int(c_rg.query_end[i])), int(c_rg.tier[i])) == (s, rr, qr, tier), ("cascade ranges", ctxt)
         n_checked += 1
     print(f"iteration {it}: ok ({len(reads)} reads, R={R}, T={T}x{N}, preset {preset} from i{width}, go={go} ge={ge}, {'protein S=%d' % len(m.mapping) if protein else 'dna'}, invert={inv}) [{time.time() - t_start:.0f} s]", flush=True)
-print(f"FUZZ OK: {n_checked} reads x 10 entry points")
+print(f"FUZZ OK: {n_checked} reads x 12 entry points")
