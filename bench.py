@@ -246,18 +246,27 @@ def main():
     if gather_on_host:
         all_scores, all_status = all_scores.cpu(), all_status.cpu()
 
+    # The result all-gather of step k runs under the kernel of step k+1: it is issued asynchronously (RCCL's own stream, ordered after
+    # the producing kernel) and only the NEXT gather, or the closing fence, waits for it. `pending` keeps the source tensors alive.
+    pending = []
+
+    def drain():
+        for work, _keep in pending:
+            work.wait()
+        pending.clear()
+
     def step():
         r = profiles.sw_score_from_i8(reference)
         if world > 1:
-            if gather_on_host:  # rehearsal path only
-                dist.all_gather_into_tensor(all_scores, r.score.cpu())
-                dist.all_gather_into_tensor(all_status, r.status.cpu())
-            else:
-                dist.all_gather_into_tensor(all_scores, r.score)
-                dist.all_gather_into_tensor(all_status, r.status)
+            src_score, src_status = (r.score.cpu(), r.status.cpu()) if gather_on_host else (r.score, r.status)  # host path: rehearsal only
+            drain()  # the gather of the previous step had this step's kernel launch to hide behind
+            pending.append((dist.all_gather_into_tensor(all_scores, src_score, async_op=True), src_score))
+            pending.append((dist.all_gather_into_tensor(all_status, src_status, async_op=True), src_status))
         return r
 
     def fence():
+        if world > 1:
+            drain()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
