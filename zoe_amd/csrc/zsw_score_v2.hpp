@@ -214,9 +214,11 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
                 if (c + 1 < C) hd_next = pk_addu(H[c], lookup(w, sel[c + 1 < C ? c + 1 : c]));
                 const uint32_t h = pk_max3(hd, E[c], F);
                 H[c] = h;
-                const uint32_t hg = pk_subu(h, gd2);
+                // plain 32-bit subtractions: both halves of every stored value are >= 0x0400 > go - ge, ge, so no borrow crosses
+                // the halves — and v_sub_u32 issues in about 0.6 of a packed instruction's time on gfx950
+                const uint32_t hg = h - gd2;
                 E[c] = pk_max3(E[c], hg, Dn);
-                F = pk_subu(pk_max3(F, hg, Dn), ge2);
+                F = pk_max3(F, hg, Dn) - ge2;
                 if (c & 1) rmax = pk_max3(rmax, H[c - (c & 1)], h);
                 else if (c == C - 1) rmax = pk_max3(rmax, h, h);
                 hd = hd_next;
