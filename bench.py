@@ -29,7 +29,7 @@ READ_LEN = 150
 REF_LEN = 2000
 ALGO_BYTES_PER_READ = READ_LEN + 4  # read bytes in + u32 score out
 # HBM bytes per read measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 fetch correction):
-# profiles/r01_score_v2_summary.txt — 1.500 GB read + 0.060 GB written per 10 M-read launch (status and tier bytes included)
+# profiles/r01_score_v2_final_summary.txt — 1.500 GB read + 0.060 GB written per 10 M-read launch (status and tier bytes included)
 PMC_HBM_BYTES_PER_READ = 156.0
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 # v_pk_{add,sub,max}_i16 and v_perm_b32 issue at one wave64 instruction per 4 cycles per SIMD on gfx950
@@ -346,7 +346,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": PMC_HBM_BYTES_PER_READ * n_local / per_launch_s / 1e9 if per_launch_s > 0 else None,
                 "traffic_bytes_per_launch": PMC_HBM_BYTES_PER_READ * n_local,
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (profiles/r01_score_v2_summary.txt), bytes/read x reads of this launch",
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (profiles/r01_score_v2_final_summary.txt), bytes/read x reads of this launch",
                 "kernel": "zsw::score_kernel_v2<4,38,0>",
                 "kernel_ms": per_launch_s * 1e3,
                 "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
