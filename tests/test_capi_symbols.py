@@ -76,3 +76,28 @@ def test_host_synth_twins():
     lens = np.diff(off)
     assert lens.min() >= 75 and lens.max() <= 400 and off[-1] == len(hb)
     assert np.array_equal(lens, synth.ragged_lengths(5, 40, 75, 400))
+
+
+def test_header_is_c_and_links_from_c(tmp_path):
+    """include/zoe_sw.h is a C header: examples/zsw_c_abi.c (C99, -pedantic) names every entry point, links against the library
+    and runs on a machine without a GPU (zsw_create reports ZSW_ERR_NO_DEVICE)."""
+    import subprocess
+
+    from zoe_amd import build
+
+    build.build()
+    src = os.path.join(ROOT, "examples", "zsw_c_abi.c")
+    txt = open(src).read()
+    for sym in header_symbols():
+        assert sym in txt, f"{sym} missing from examples/zsw_c_abi.c"
+    exe = str(tmp_path / "zsw_c_abi")
+    libdir = os.path.join(ROOT, "zoe_amd")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-o", exe, "-L" + libdir,
+                    "-lzoe_sw_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+    import torch
+
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "25 entry points, sizeof(zsw_alignment) = 40" in out.stdout
