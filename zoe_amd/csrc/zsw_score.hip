@@ -126,8 +126,9 @@ struct Cfg {
     int G, C;
 };
 // strip configurations, ascending capacity G*C
-static const Cfg kCfgs[] = {{4, 19}, {4, 25}, {4, 32}, {4, 38}, {8, 19}, {8, 25}, {8, 32}, {8, 38},
-                            {16, 25}, {16, 32}, {16, 38}, {64, 19}, {64, 38}};
+#define ZSW_CFG_ENTRY(GV, CV) {GV, CV},
+static const Cfg kCfgs[] = {ZSW_FOR_EACH_STRIP_CONFIG(ZSW_CFG_ENTRY)};
+#undef ZSW_CFG_ENTRY
 
 bool score_config_for(uint32_t max_len, int* G, int* C) {
     for (const Cfg& c : kCfgs)
@@ -231,19 +232,7 @@ static hipError_t launch_table_cfg_v2(const ScoreArgsV2& a, int G, int C, int mo
     switch (G * 100 + C) {
 #define ZSW_CASE(GV, CV) \
     case GV * 100 + CV: return launch_cfg_v2<GV, CV>(a, mode, stream);
-        ZSW_CASE(4, 19)
-        ZSW_CASE(4, 25)
-        ZSW_CASE(4, 32)
-        ZSW_CASE(4, 38)
-        ZSW_CASE(8, 19)
-        ZSW_CASE(8, 25)
-        ZSW_CASE(8, 32)
-        ZSW_CASE(8, 38)
-        ZSW_CASE(16, 25)
-        ZSW_CASE(16, 32)
-        ZSW_CASE(16, 38)
-        ZSW_CASE(64, 19)
-        ZSW_CASE(64, 38)
+        ZSW_FOR_EACH_STRIP_CONFIG(ZSW_CASE)
 #undef ZSW_CASE
     }
     return hipErrorInvalidValue;
@@ -317,19 +306,7 @@ static hipError_t launch_table_cfg(const ScoreArgs& a, int G, int C, bool fast, 
     switch (G * 100 + C) {
 #define ZSW_CASE(GV, CV) \
     case GV * 100 + CV: return launch_cfg<GV, CV>(a, fast, mode, stream);
-        ZSW_CASE(4, 19)
-        ZSW_CASE(4, 25)
-        ZSW_CASE(4, 32)
-        ZSW_CASE(4, 38)
-        ZSW_CASE(8, 19)
-        ZSW_CASE(8, 25)
-        ZSW_CASE(8, 32)
-        ZSW_CASE(8, 38)
-        ZSW_CASE(16, 25)
-        ZSW_CASE(16, 32)
-        ZSW_CASE(16, 38)
-        ZSW_CASE(64, 19)
-        ZSW_CASE(64, 38)
+        ZSW_FOR_EACH_STRIP_CONFIG(ZSW_CASE)
 #undef ZSW_CASE
     }
     return hipErrorInvalidValue;
@@ -597,19 +574,7 @@ hipError_t launch_score_rev(const ScoringDev* d_sc, const ScoringDev& h_sc, cons
     switch (G * 100 + C) {
 #define ZSW_CASE(GV, CV) \
     case GV * 100 + CV: e = launch_cfg_rev<GV, CV>(a, fast, stream); break;
-        ZSW_CASE(4, 19)
-        ZSW_CASE(4, 25)
-        ZSW_CASE(4, 32)
-        ZSW_CASE(4, 38)
-        ZSW_CASE(8, 19)
-        ZSW_CASE(8, 25)
-        ZSW_CASE(8, 32)
-        ZSW_CASE(8, 38)
-        ZSW_CASE(16, 25)
-        ZSW_CASE(16, 32)
-        ZSW_CASE(16, 38)
-        ZSW_CASE(64, 19)
-        ZSW_CASE(64, 38)
+        ZSW_FOR_EACH_STRIP_CONFIG(ZSW_CASE)
 #undef ZSW_CASE
         default: e = hipErrorInvalidValue;
     }

@@ -21,19 +21,7 @@ hipError_t launch_table_cfg_v2_wide(const ScoreArgsV2& a, int G, int C, int mode
     switch (G * 100 + C) {
 #define ZSW_CASE(GV, CV) \
     case GV * 100 + CV: return launch_cfg_wide<GV, CV>(a, mode, stream);
-        ZSW_CASE(4, 19)
-        ZSW_CASE(4, 25)
-        ZSW_CASE(4, 32)
-        ZSW_CASE(4, 38)
-        ZSW_CASE(8, 19)
-        ZSW_CASE(8, 25)
-        ZSW_CASE(8, 32)
-        ZSW_CASE(8, 38)
-        ZSW_CASE(16, 25)
-        ZSW_CASE(16, 32)
-        ZSW_CASE(16, 38)
-        ZSW_CASE(64, 19)
-        ZSW_CASE(64, 38)
+        ZSW_FOR_EACH_STRIP_CONFIG(ZSW_CASE)
 #undef ZSW_CASE
     }
     return hipErrorInvalidValue;
@@ -47,19 +35,7 @@ hipError_t launch_cfg_rev_wide(const ScoreArgs& a, int G, int C, hipStream_t str
     switch (G * 100 + C) {
 #define ZSW_CASE(GV, CV) \
     case GV * 100 + CV: hipLaunchKernelGGL((score_kernel<GV, CV, true, 2, true, true>), dim3(grid), dim3(BLOCK), 0, stream, a); break;
-        ZSW_CASE(4, 19)
-        ZSW_CASE(4, 25)
-        ZSW_CASE(4, 32)
-        ZSW_CASE(4, 38)
-        ZSW_CASE(8, 19)
-        ZSW_CASE(8, 25)
-        ZSW_CASE(8, 32)
-        ZSW_CASE(8, 38)
-        ZSW_CASE(16, 25)
-        ZSW_CASE(16, 32)
-        ZSW_CASE(16, 38)
-        ZSW_CASE(64, 19)
-        ZSW_CASE(64, 38)
+        ZSW_FOR_EACH_STRIP_CONFIG(ZSW_CASE)
 #undef ZSW_CASE
         default: return hipErrorInvalidValue;
     }
