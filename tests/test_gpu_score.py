@@ -495,3 +495,63 @@ def test_host_batch_pipeline_matches_device_batch(za, oracle, dna):
         assert (int(status[i]), int(score[i]) if o_st == S_ else 0) == (o_st, o_s if o_st == S_ else 0), i
     del dev, rb
     torch.cuda.empty_cache()
+
+
+def test_long_reads_are_scored_tile_by_tile(za, oracle, dna, monkeypatch):
+    """Reads longer than the widest strip configuration (2,432 columns) run as several TILED launches of the packed kernel, the
+    strip boundary of every reference row passing through HBM: score, ends and ranges must equal the oracle, for DNA and for
+    a 25-letter alphabet, in a ragged and in a fixed-length batch, and must equal the exact-kernel path (ZSW_NO_TILES)."""
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    R = 3500
+    ref = bytes(rng.choice(alpha, R))
+    sc = osc(oracle, dna, -10, -1)
+
+    def mutated(L):
+        base = bytearray((ref * 3)[int(rng.integers(0, R)):][:L])
+        for _ in range(L // 40):
+            k = int(rng.integers(0, len(base)))
+            u = rng.random()
+            if u < 0.5:
+                base[k] = int(rng.choice(alpha))
+            elif u < 0.75:
+                del base[k]
+            else:
+                base.insert(k, int(rng.choice(alpha)))
+        return bytes(base)
+
+    reads = [mutated(L) for L in (2433, 2500, 4864, 4865, 5200, 7400)] + [bytes(rng.choice(alpha, 3000)), ref[500:650], ref[:2432]]
+    p = za.StripedProfileBatch(reads, dna, -10, -1, "i32", 8)
+    got, ends, rg = p.sw_score(ref), p.sw_score_ends(za.SeqSrc.Reference(ref)), p.sw_score_ranges(za.SeqSrc.Reference(ref))
+    for i, rd in enumerate(reads):
+        st, (s, re_, qe) = oracle.score_ends("i32", 8, sc, rd, ref)
+        assert (int(got.status[i]), int(got.score[i])) == (st, s if st == S_ else 0), i
+        assert (int(ends.score[i]), int(ends.ref_end[i]), int(ends.query_end[i])) == (s, re_, qe), i
+        st, s, rr, qr = oracle.score_ranges("i32", 8, sc, rd, ref)
+        assert (int(rg.score[i]), (int(rg.ref_start[i]), int(rg.ref_end[i])), (int(rg.query_start[i]), int(rg.query_end[i]))) == (s, rr, qr), i
+    # i16 tier: scores above 32767 overflow, below do not
+    c16 = za.LocalProfilesBatch.new_with_w256(reads, dna, -10, -1).sw_score_from_i16(ref)
+    for i, rd in enumerate(reads):
+        st, s, tier = oracle.cascade_score(16, 256, sc, rd, ref)
+        assert (int(c16.status[i]), int(c16.score[i]) if st == S_ else 0, int(c16.tier[i])) == (st, s if st == S_ else 0, tier), i
+    # fixed-length batch of long reads
+    fixed = [mutated(5000)[:4900].ljust(4900, b"A") for _ in range(5)]
+    gf = za.StripedProfileBatch(fixed, dna, -10, -1, "i32", 8).sw_score_ends(za.SeqSrc.Reference(ref))
+    for i, rd in enumerate(fixed):
+        st, (s, re_, qe) = oracle.score_ends("i32", 8, sc, rd, ref)
+        assert (int(gf.score[i]), int(gf.ref_end[i]), int(gf.query_end[i])) == (s, re_, qe), i
+    # 25-letter alphabet
+    rngp, keys, mp, w, m = _protein_case(za, 5)
+    pa = np.frombuffer(keys[:20], dtype=np.uint8)
+    pref = bytes(rngp.choice(pa, 1500))
+    preads = [bytes(rngp.choice(pa, 2600)), (pref * 3)[100:3100], bytes(rngp.choice(pa, 5000))]
+    psc = oracle.Scoring(w, mp.index_map, -11, -1)
+    gp = za.StripedProfileBatch(preads, m, -11, -1, "i32", 8).sw_score_ends(za.SeqSrc.Reference(pref))
+    for i, rd in enumerate(preads):
+        st, (s, re_, qe) = oracle.score_ends("i32", 8, psc, rd, pref)
+        assert (int(gp.score[i]), int(gp.ref_end[i]), int(gp.query_end[i])) == (s, re_, qe), i
+    # the exact-kernel path gives the same answers
+    monkeypatch.setenv("ZSW_NO_TILES", "1")
+    ex = p.sw_score_ends(za.SeqSrc.Reference(ref))
+    for name in ("score", "ref_end", "query_end", "status"):
+        assert np.array_equal(getattr(ex, name).cpu().numpy(), getattr(ends, name).cpu().numpy()), name

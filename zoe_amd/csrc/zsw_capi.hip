@@ -45,7 +45,7 @@ struct zsw_context {
     bool scoring_set = false, reference_set = false;
     ScoringDev h_sc{};
     int bias = 0;
-    DevBuf d_sc, d_ref, d_fb_list, d_fb_count, d_scratch, d_maxlen, d_bucket_items, d_bucket_counts;
+    DevBuf d_sc, d_ref, d_fb_list, d_fb_count, d_scratch, d_maxlen, d_bucket_items, d_bucket_counts, d_tile_buf, d_tile_state;
     size_t ref_len = 0;
     uint32_t scratch_len = 0;
     // staging for host-memory batches
@@ -64,6 +64,7 @@ struct zsw_context {
 namespace {
 
 constexpr size_t EXACT_SLOTS = 64 * 256;
+constexpr uint32_t LONGEST_STRIP = 64 * 38;  // columns of the widest strip configuration (zsw_score_v2.hpp)
 
 zsw_error fail(zsw_context* ctx, zsw_error code, const char* what, hipError_t e = hipSuccess) {
     if (ctx) {
@@ -230,7 +231,13 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     // workspace
     ZSW_HIP(ctx, ctx->d_fb_list.ensure((size_t)n * 4 + 4));
     ZSW_HIP(ctx, ctx->d_fb_count.ensure(4));
-    if (reads->offsets) ZSW_HIP(ctx, ctx->d_bucket_items.ensure((size_t)n * 4 + 4));
+    if (reads->offsets || st->max_len > LONGEST_STRIP) ZSW_HIP(ctx, ctx->d_bucket_items.ensure((size_t)n * 4 + 4));
+    if (st->max_len > LONGEST_STRIP) {  // tile-by-tile scoring of long reads: boundary buffers for as many read pairs as 1 GiB holds
+        const size_t per_pair = std::max<size_t>(ctx->ref_len, 1) * 8, pairs = ((size_t)n + 1) / 2;
+        const size_t want = 2 * std::min<size_t>(pairs * per_pair, std::max<size_t>(per_pair, size_t(512) << 20));
+        ZSW_HIP(ctx, ctx->d_tile_buf.ensure(want));
+        ZSW_HIP(ctx, ctx->d_tile_state.ensure((size_t)n * 16 + 16));
+    }
     ZSW_HIP(ctx, ctx->d_bucket_counts.ensure(64 * 4));
     uint32_t need = std::max<uint32_t>(512, (st->max_len + 127) / 128 * 128);
     if (need > ctx->scratch_len || !ctx->d_scratch.p) {
@@ -247,6 +254,9 @@ ScoreWorkspace score_ws(zsw_context* ctx) {
     w.scratch_len = ctx->scratch_len;
     w.bucket_items = ctx->d_bucket_items.as<uint32_t>();
     w.bucket_counts = ctx->d_bucket_counts.as<uint32_t>();
+    w.tile_buf = ctx->d_tile_buf.as<uint2>();
+    w.tile_bytes = ctx->d_tile_buf.cap / 16 * 16;
+    w.tile_state = ctx->d_tile_state.as<uint4>();
     return w;
 }
 
@@ -867,7 +877,7 @@ zsw_error zsw_create(int device_id, zsw_context** out) {
 void zsw_destroy(zsw_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts,
+    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state,
                       &ctx->s_bases, &ctx->s_offsets, &ctx->s_score, &ctx->s_status, &ctx->s_tier, &ctx->s_rend, &ctx->s_qend};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->a_ws) b.release();

@@ -75,6 +75,11 @@ struct ScoreWorkspace {
     uint32_t scratch_len;
     uint32_t* bucket_items;  // n_reads entries (ragged batches: reads grouped by strip configuration)
     uint32_t* bucket_counts; // 32 counters + 32 cursors
+    // reads longer than the widest strip configuration are scored tile by tile (zsw_score_v2.hpp, TILED): two row-boundary buffers
+    // of tile_bytes / 2 each and one running (score, ref_end, query_end) per read. All null when the batch has no such read.
+    uint2* tile_buf = nullptr;
+    size_t tile_bytes = 0;
+    uint4* tile_state = nullptr;
 };
 
 hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,

@@ -327,6 +327,11 @@ __device__ __forceinline__ int bucket_of(const BucketCaps& caps, uint32_t len) {
     return k;
 }
 
+__global__ void iota_kernel(uint32_t* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
 __global__ void bucket_count_kernel(const uint64_t* offsets, uint32_t n, BucketCaps caps, uint32_t* counts) {
     __shared__ uint32_t sh[NCLS + 1];
     if (threadIdx.x <= NCLS) sh[threadIdx.x] = 0;
@@ -417,6 +422,35 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         a.b = bb;
         return launch_table_cfg(a, g, c, fast, mode, stream);
     };
+    // Reads longer than the widest strip configuration: TILE_COLS query columns per launch, the strip boundary of every
+    // reference row handed from tile to tile through HBM, as many reads per round as the boundary buffers hold.
+    // Returns hipErrorNotSupported when the packed kernels cannot take the batch (the caller then uses the exact kernel).
+    auto launch_tiled = [&](const BatchDev& bb, uint32_t longest) -> hipError_t {
+        if (!ws.tile_buf || !ws.tile_state || !bb.items || getenv("ZSW_NO_TILES")) return hipErrorNotSupported;
+        if (!(wide || use_v2)) return hipErrorNotSupported;
+        if (!(wide ? build_tables_wide(h_sc, TILE_G, &a2) : build_tables_v2(h_sc, TILE_G, &a2))) return hipErrorNotSupported;
+        const size_t per_pair = (size_t)ref_len * sizeof(uint2);
+        const size_t half = ws.tile_bytes / 2;
+        const size_t fit = per_pair ? half / per_pair : (size_t)bb.n_items;
+        if (fit == 0) return hipErrorNotSupported;
+        const uint32_t chunk = (uint32_t)std::min<size_t>(2 * fit, 0x7ffffffeu);
+        uint2* buf[2] = {ws.tile_buf, reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(ws.tile_buf) + half)};
+        const uint32_t n_tiles = (longest + TILE_COLS - 1) / TILE_COLS;
+        for (uint32_t first = 0; first < bb.n_items; first += chunk) {
+            a2.b = bb;
+            a2.b.items = bb.items + first;
+            a2.b.n_items = std::min<uint32_t>(chunk, bb.n_items - first);
+            a2.tile_state = ws.tile_state;
+            for (uint32_t t = 0; t < n_tiles; ++t) {
+                a2.tile_q0 = t * (uint32_t)TILE_COLS;
+                a2.tile_in = t ? buf[(t - 1) & 1] : nullptr;
+                a2.tile_out = t + 1 < n_tiles ? buf[t & 1] : nullptr;
+                hipError_t te = launch_tile_v2(a2, wide, mode, stream);
+                if (te != hipSuccess) return te;
+            }
+        }
+        return hipSuccess;
+    };
     auto exact_all = [&](const BatchDev& bb) {
         hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, bb, (const uint32_t*)nullptr,
                            (const uint32_t*)nullptr, d_ref, ref_len, d_sc, rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
@@ -470,8 +504,9 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
             BatchDev bk = b;
             bk.items = ws.bucket_items + starts[k];
             bk.n_items = counts[k];
-            if (k == NCLS) {
-                e = exact_all(bk);  // shares the scratch rows with the fallback pass below: stays on the main stream
+            if (k == NCLS) {  // longer than every strip configuration; stays on the main stream (shares scratch with the pass below)
+                e = launch_tiled(bk, max_len);
+                if (e == hipErrorNotSupported) e = exact_all(bk);
             } else {
                 stream = fork ? side->s[used++ % SideStreams::N] : main_stream;
                 e = launch_one(bk, kCfgs[kBucketCfg[k]].G, kCfgs[kBucketCfg[k]].C);
@@ -491,9 +526,23 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     } else {
         if (!score_config_for_batch(max_len, b.n_items, &G, &C)) {  // longer than every strip configuration
             if (timer) timer->begin(stream);
-            e = exact_all(b);
+            BatchDev bl = b;
+            if (!bl.items && ws.bucket_items) {  // the tiles address reads through an item list
+                hipLaunchKernelGGL(iota_kernel, dim3((b.n_items + 255) / 256), dim3(256), 0, stream, ws.bucket_items, b.n_items);
+                bl.items = ws.bucket_items;
+            }
+            e = launch_tiled(bl, max_len);
+            if (e == hipErrorNotSupported) {
+                e = exact_all(b);
+                if (timer) timer->end(stream);
+                return e;
+            }
             if (timer) timer->end(stream);
-            return e;
+            if (e != hipSuccess) return e;
+            // reads beyond the packed range: exact pass over the worklist
+            hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, b, out.fb_list, out.fb_count, d_ref, ref_len, d_sc,
+                               rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+            return hipGetLastError();
         }
         if (timer) timer->begin(stream);
         e = launch_one(b, G, C);

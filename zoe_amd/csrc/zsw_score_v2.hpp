@@ -69,9 +69,15 @@ struct ScoreArgsV2 {
     uint32_t limit;       // true scores >= limit are recomputed by the exact kernel
     ResultRule rule;
     ScoreOut out;
+    // TILED launches (reads longer than the widest strip configuration): this launch covers query columns
+    // [tile_q0, tile_q0 + G*C); the strip boundary of every reference row travels between launches through HBM.
+    uint32_t tile_q0;
+    const uint2* tile_in;  // [pair][R] (last H, outgoing F) left by the previous tile's last lane, drift domain; null: first tile
+    uint2* tile_out;       // the same, written by this tile's last lane; null: last tile
+    uint4* tile_state;     // per read: (best true score | 0xffffffff = beyond the packed range, ref_end, query_end, -) so far
 };
 
-template <int G, int C, int MODE, bool WIDE = false>
+template <int G, int C, int MODE, bool WIDE = false, bool TILED = false>
 __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(ScoreArgsV2 a) {
     __shared__ uint2 rp[WIDE ? 1 : CH + G];
     __shared__ uint16_t rpw[WIDE ? CH + G : 1];      // WIDE: byte offset of each staged row's table row
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
     uint32_t sel[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const uint32_t q = (uint32_t)(g * C + c);
+        const uint32_t q = (TILED ? a.tile_q0 : 0u) + (uint32_t)(g * C + c);
         uint32_t kA = PAD_K, kB = PAD_K;
         if (q < lenA) kA = lut[a.b.bases[offA + q]];
         if (q < lenB) kB = lut[a.b.bases[offB + q]];
@@ -157,6 +163,10 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
     int rA = 0, rB = 0;
     const int R = (int)a.ref_len;
     const int T = R + G - 1;
+    uint2 bd = make_uint2(0u, 0u);  // TILED: the boundary of the row lane 0 reaches next
+    if (TILED) {
+        if (g == 0 && a.tile_in != nullptr && R > 0) bd = a.tile_in[(size_t)group * (size_t)R];
+    }
 
     for (int base = 0; base < T; base += CH) {
         __syncthreads();
@@ -208,6 +218,13 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
             if (g == 0) {
                 Fin = Dr;
                 Hin = Dr;
+                if (TILED) {  // the strip to the left belongs to the previous tile: its row-r boundary comes from HBM (same D_r)
+                    if (a.tile_in != nullptr && row >= 0 && row < R) {
+                        Hin = bd.x;
+                        Fin = bd.y;
+                    }
+                    if (a.tile_in != nullptr && row + 1 < R) bd = a.tile_in[(size_t)group * (size_t)R + (size_t)(row + 1)];
+                }
             }
             uint32_t hd = pk_addu(Hin_prev, lookup(w, sel[0]));
             Hin_prev = Hin;
@@ -230,6 +247,10 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
             }
             Fout = F;
             Hlast = H[C - 1];
+            if (TILED) {
+                if (g == G - 1 && a.tile_out != nullptr && row >= 0 && row < R)
+                    a.tile_out[(size_t)group * (size_t)R + (size_t)row] = make_uint2(Hlast, Fout);
+            }
             const uint32_t tmax = pk_subu(rmax, Dr);  // true row maximum (>= 0: every H~ >= D_r)
             const uint32_t nb = pk_maxu(best, tmax);
             if (MODE != 0) {
@@ -272,8 +293,8 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
 #pragma unroll
             for (int c = C - 1; c >= 0; --c) {
                 const uint32_t sv = snap[MODE == 2 ? c : 0];
-                if ((int)(sv & 0xffffu) - dA == gbA) cA = g * C + c;
-                if ((int)(sv >> 16) - dB == gbB) cB = g * C + c;
+                if ((int)(sv & 0xffffu) - dA == gbA) cA = (TILED ? (int)a.tile_q0 : 0) + g * C + c;
+                if ((int)(sv >> 16) - dB == gbB) cB = (TILED ? (int)a.tile_q0 : 0) + g * C + c;
             }
             if (!(bA == gbA && rA == kA)) cA = 0x7fffffff;
             if (!(bB == gbB && rB == kB)) cB = 0x7fffffff;
@@ -298,9 +319,27 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
     const uint32_t o_valid = (uint32_t)pick((int)validA, (int)validB);
     const uint32_t o_id = (uint32_t)pick((int)idA, (int)idB);
     const uint32_t o_len = (uint32_t)pick((int)lenA, (int)lenB);
-    const int o_true = pick(gbA, gbB);
-    const uint32_t o_re = (uint32_t)pick((int)reA, (int)reB);
-    const uint32_t o_qe = (uint32_t)pick((int)qeA, (int)qeB);
+    int o_true = pick(gbA, gbB);
+    uint32_t o_re = (uint32_t)pick((int)reA, (int)reB);
+    uint32_t o_qe = (uint32_t)pick((int)qeA, (int)qeB);
+    if (TILED) {
+        // fold this tile into the read's running result: larger score, then earlier row, then earlier column (= earlier tile)
+        if (lane < RW && o_valid) {
+            uint32_t best_u = (uint32_t)o_true >= a.limit ? 0xffffffffu : (uint32_t)o_true;
+            if (a.tile_in != nullptr) {
+                const uint4 prev = a.tile_state[o_id];
+                const bool keep_prev = prev.x == 0xffffffffu || (best_u != 0xffffffffu && (prev.x > best_u || (prev.x == best_u && prev.y <= o_re)));
+                if (keep_prev) {
+                    best_u = prev.x;
+                    o_re = prev.y;
+                    o_qe = prev.z;
+                }
+            }
+            if (a.tile_out != nullptr) a.tile_state[o_id] = make_uint4(best_u, o_re, o_qe, 0u);
+            o_true = best_u == 0xffffffffu ? 0x7fffffff : (int)best_u;
+        }
+        if (a.tile_out != nullptr) return;  // results are written by the last tile
+    }
     if (lane < RW && o_valid) {
         if (o_len == 0) {
             a.out.score[o_id] = 0;
@@ -327,5 +366,9 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
 
 // zsw_score_wide.hip
 hipError_t launch_table_cfg_v2_wide(const ScoreArgsV2& a, int G, int C, int mode, hipStream_t stream);
+// one tile (columns [a.tile_q0, a.tile_q0 + TILE_COLS)) of reads longer than the widest strip configuration; `wide` picks the
+// LDS-table form. The caller sets tile_q0 / tile_in / tile_out / tile_state.
+constexpr int TILE_G = 64, TILE_C = 38, TILE_COLS = TILE_G * TILE_C;
+hipError_t launch_tile_v2(const ScoreArgsV2& a, bool wide, int mode, hipStream_t stream);
 
 }  // namespace zsw

@@ -27,6 +27,22 @@ hipError_t launch_table_cfg_v2_wide(const ScoreArgsV2& a, int G, int C, int mode
     return hipErrorInvalidValue;
 }
 
+// One tile of the reads that are longer than the widest strip configuration (both table forms live here to keep this
+// translation unit and zsw_score.hip of similar size).
+hipError_t launch_tile_v2(const ScoreArgsV2& a, bool wide, int mode, hipStream_t stream) {
+    const uint32_t reads_per_block = 2 * (BLOCK / TILE_G);
+    const uint32_t grid = (a.b.n_items + reads_per_block - 1) / reads_per_block;
+    if (grid == 0) return hipSuccess;
+    if (wide) {
+        if (mode == 0) hipLaunchKernelGGL((score_kernel_v2<TILE_G, TILE_C, 0, true, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((score_kernel_v2<TILE_G, TILE_C, 2, true, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((score_kernel_v2<TILE_G, TILE_C, 0, false, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((score_kernel_v2<TILE_G, TILE_C, 2, false, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    }
+    return hipGetLastError();
+}
+
 // reverse pass of sw_simd_score_ranges for these alphabets (score_kernel<..., REV, WIDE>, one read per lane)
 hipError_t launch_cfg_rev_wide(const ScoreArgs& a, int G, int C, hipStream_t stream) {
     const uint32_t reads_per_block = BLOCK / G;
