@@ -555,3 +555,47 @@ def test_long_reads_are_scored_tile_by_tile(za, oracle, dna, monkeypatch):
     ex = p.sw_score_ends(za.SeqSrc.Reference(ref))
     for name in ("score", "ref_end", "query_end", "status"):
         assert np.array_equal(getattr(ex, name).cpu().numpy(), getattr(ends, name).cpu().numpy()), name
+
+
+def test_scores_beyond_the_packed_range_use_the_32bit_tile_kernel(za, oracle, dna, monkeypatch):
+    """A genome-sized read that matches the reference scores far above what the packed 16-bit kernels can hold (~28,000): the
+    packed pass puts it on the worklist and the 32-bit tile kernel (zsw_score_w32.hip) scores it — score, ends and the cascade tier identical to the oracle; ZSW_NO_W32 (exact
+    kernel) agrees."""
+    rng = np.random.default_rng(123)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    R = 21000
+    ref = bytes(rng.choice(alpha, R))
+    big = bytearray(ref[300:18300])  # 18 kb, a handful of edits: score ~35,000
+    for k in (2000, 7000, 7001, 12000):
+        big[k] = ord("A") if big[k] != ord("A") else ord("C")
+    del big[9000:9003]
+    reads = [bytes(big), ref[1000:16500], ref[50:200], bytes(rng.choice(alpha, 3000))]
+    sc = osc(oracle, dna, -10, -1)
+    p = za.StripedProfileBatch(reads, dna, -10, -1, "i32", 8)
+    got = p.sw_score_ends(za.SeqSrc.Reference(ref))
+    plain = p.sw_score(ref)
+    for i, rd in enumerate(reads):
+        st, (s, re_, qe) = oracle.score_ends("i32", 8, sc, rd, ref)
+        assert (int(got.status[i]), int(got.score[i]), int(got.ref_end[i]), int(got.query_end[i])) == (st, s, re_, qe), i
+        assert (int(plain.status[i]), int(plain.score[i])) == (st, s), i
+    assert int(got.score[0]) > 32767 and int(got.score[1]) > 30000
+    c = za.LocalProfilesBatch.new_with_w256(reads, dna, -10, -1).sw_score_from_i8(ref)
+    for i, rd in enumerate(reads):  # an i16 profile holds true scores up to 65,534 (offset i16::MIN): these answer at the i16 tier
+        st, s, tier = oracle.cascade_score(8, 256, sc, rd, ref)
+        assert (int(c.status[i]), int(c.score[i]), int(c.tier[i])) == (st, s, tier), i
+    assert [int(x) for x in c.tier][:2] == [16, 16]
+    # a heavier matrix reaches the same range with 3 kb reads: oracle, 32-bit tiles and the exact kernel must agree
+    m20 = za.WeightMatrix.new_dna_matrix(20, -30, b"N")
+    ref2 = ref[:4000]
+    reads2 = [ref2[100:3100], bytes(rng.choice(alpha, 2600)), ref2[2000:2100]]
+    sc2 = osc(oracle, m20, -40, -3)
+    p2 = za.StripedProfileBatch(reads2, m20, -40, -3, "i32", 8)
+    w32 = p2.sw_score_ends(za.SeqSrc.Reference(ref2))
+    for i, rd in enumerate(reads2):
+        st, (s, re_, qe) = oracle.score_ends("i32", 8, sc2, rd, ref2)
+        assert (int(w32.status[i]), int(w32.score[i]), int(w32.ref_end[i]), int(w32.query_end[i])) == (st, s, re_, qe), i
+    assert int(w32.score[0]) == 60000
+    monkeypatch.setenv("ZSW_NO_W32", "1")
+    ex = p2.sw_score_ends(za.SeqSrc.Reference(ref2))
+    for name in ("score", "ref_end", "query_end", "status"):
+        assert np.array_equal(getattr(ex, name).cpu().numpy(), getattr(w32, name).cpu().numpy()), name

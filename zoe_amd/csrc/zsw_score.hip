@@ -294,12 +294,30 @@ static bool wide_ok(const ScoringDev& s) {
     return true;
 }
 
-static bool build_tables_wide(const ScoringDev& s, int G, ScoreArgsV2* a) {
+static void fill_wide_table(const ScoringDev& s, ScoreArgsV2* a) {
     const int ge = s.gap_extend;
     for (int r = 0; r < 33; ++r)
         for (int q = 0; q < WIDE_STRIDE; ++q)
             a->wide[r * WIDE_STRIDE + q] = (int8_t)((r < s.S && q < s.S) ? s.w[r * s.S + q] + ge : ge);
+}
+
+static bool build_tables_wide(const ScoringDev& s, int G, ScoreArgsV2* a) {
+    fill_wide_table(s, a);
     return v2_range_setup(s, G, a);
+}
+
+// The 32-bit tile kernel takes any alphabet of up to 32 letters whose weights + gap_extend fit a signed byte, as long as the
+// drifted values stay inside an i32 for this reference and read length.
+static bool w32_ok(const ScoringDev& s, uint32_t ref_len, uint32_t max_len) {
+    if (getenv("ZSW_NO_W32") || s.S > 32) return false;
+    int maxw = 0;
+    for (int i = 0; i < s.S * s.S; ++i) {
+        const int t = s.w[i] + s.gap_extend;
+        if (t < -128 || t > 127) return false;
+        maxw = std::max(maxw, (int)s.w[i]);
+    }
+    const uint64_t top = ((uint64_t)ref_len + TILE_G + 4) * (uint64_t)s.gap_extend + (uint64_t)max_len * (uint64_t)maxw;
+    return top < 0x7f000000ull;
 }
 
 static hipError_t launch_table_cfg(const ScoreArgs& a, int G, int C, bool fast, int mode, hipStream_t stream) {
@@ -451,6 +469,45 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         }
         return hipSuccess;
     };
+    // Reads whose score is beyond the packed range sit in the device-side worklist (usually empty). Batches that can hold such
+    // scores at all (long reads) read the count back and run the 32-bit tile kernel over the list; everything else launches the
+    // exact kernel on the worklist unconditionally, which keeps short-read calls asynchronous.
+    auto finish_worklist = [&]() -> hipError_t {
+        int maxw = 1;
+        for (int i = 0; i < h_sc.S * h_sc.S; ++i) maxw = std::max(maxw, (int)h_sc.w[i]);
+        if ((uint64_t)max_len * (uint64_t)maxw >= 16384 && ws.tile_buf && ws.tile_state && w32_ok(h_sc, ref_len, max_len)) {
+            uint32_t cnt = 0;
+            hipError_t we = hipMemcpyAsync(&cnt, out.fb_count, sizeof(cnt), hipMemcpyDeviceToHost, stream);
+            if (we == hipSuccess) we = hipStreamSynchronize(stream);
+            if (we != hipSuccess) return we;
+            if (cnt == 0) return hipSuccess;
+            fill_wide_table(h_sc, &a2);
+            a2.ge2 = (uint32_t)h_sc.gap_extend * 0x00010001u;
+            a2.gd2 = (uint32_t)(h_sc.gap_open - h_sc.gap_extend) * 0x00010001u;
+            const size_t per_read = (size_t)ref_len * sizeof(uint2), half = ws.tile_bytes / 2;
+            const size_t fit = per_read ? half / per_read : (size_t)cnt;
+            if (fit > 0) {
+                uint2* buf[2] = {ws.tile_buf, reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(ws.tile_buf) + half)};
+                const uint32_t n_tiles = (max_len + TILE_COLS - 1) / TILE_COLS;
+                for (uint32_t first = 0; first < cnt; first += (uint32_t)std::min<size_t>(fit, 0x7fffffffu)) {
+                    a2.b = b;
+                    a2.b.n_items = (uint32_t)std::min<size_t>(fit, cnt - first);
+                    a2.tile_state = ws.tile_state;
+                    for (uint32_t t = 0; t < n_tiles; ++t) {
+                        a2.tile_q0 = t * (uint32_t)TILE_COLS;
+                        a2.tile_in = t ? buf[(t - 1) & 1] : nullptr;
+                        a2.tile_out = t + 1 < n_tiles ? buf[t & 1] : nullptr;
+                        we = launch_tile_w32(a2, out.fb_list + first, mode, stream);
+                        if (we != hipSuccess) return we;
+                    }
+                }
+                return hipSuccess;
+            }
+        }
+        hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, b, out.fb_list, out.fb_count, d_ref, ref_len, d_sc,
+                           rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+        return hipGetLastError();
+    };
     auto exact_all = [&](const BatchDev& bb) {
         hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, bb, (const uint32_t*)nullptr,
                            (const uint32_t*)nullptr, d_ref, ref_len, d_sc, rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
@@ -539,20 +596,14 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
             }
             if (timer) timer->end(stream);
             if (e != hipSuccess) return e;
-            // reads beyond the packed range: exact pass over the worklist
-            hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, b, out.fb_list, out.fb_count, d_ref, ref_len, d_sc,
-                               rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-            return hipGetLastError();
+            return finish_worklist();
         }
         if (timer) timer->begin(stream);
         e = launch_one(b, G, C);
         if (timer) timer->end(stream);
         if (e != hipSuccess) return e;
     }
-    // reads that saturated i16: exact pass over the device-side worklist (usually empty)
-    hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, b, out.fb_list, out.fb_count, d_ref, ref_len, d_sc,
-                       rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-    return hipGetLastError();
+    return finish_worklist();
 }
 
 // ---- reverse pass of sw_simd_score_ranges -------------------------------------------------------------------

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
     const int T = R + G - 1;
     uint2 bd = make_uint2(0u, 0u);  // TILED: the boundary of the row lane 0 reaches next
     if (TILED) {
-        if (g == 0 && a.tile_in != nullptr && R > 0) bd = a.tile_in[(size_t)group * (size_t)R];
+        if (g == 0 && validA && a.tile_in != nullptr && R > 0) bd = a.tile_in[(size_t)group * (size_t)R];
     }
 
     for (int base = 0; base < T; base += CH) {
@@ -219,11 +219,11 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
                 Fin = Dr;
                 Hin = Dr;
                 if (TILED) {  // the strip to the left belongs to the previous tile: its row-r boundary comes from HBM (same D_r)
-                    if (a.tile_in != nullptr && row >= 0 && row < R) {
+                    if (validA && a.tile_in != nullptr && row >= 0 && row < R) {  // lane groups past the batch own no boundary rows
                         Hin = bd.x;
                         Fin = bd.y;
                     }
-                    if (a.tile_in != nullptr && row + 1 < R) bd = a.tile_in[(size_t)group * (size_t)R + (size_t)(row + 1)];
+                    if (validA && a.tile_in != nullptr && row + 1 < R) bd = a.tile_in[(size_t)group * (size_t)R + (size_t)(row + 1)];
                 }
             }
             uint32_t hd = pk_addu(Hin_prev, lookup(w, sel[0]));
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
             Fout = F;
             Hlast = H[C - 1];
             if (TILED) {
-                if (g == G - 1 && a.tile_out != nullptr && row >= 0 && row < R)
+                if (g == G - 1 && validA && a.tile_out != nullptr && row >= 0 && row < R)
                     a.tile_out[(size_t)group * (size_t)R + (size_t)row] = make_uint2(Hlast, Fout);
             }
             const uint32_t tmax = pk_subu(rmax, Dr);  // true row maximum (>= 0: every H~ >= D_r)
@@ -370,5 +370,7 @@ hipError_t launch_table_cfg_v2_wide(const ScoreArgsV2& a, int G, int C, int mode
 // LDS-table form. The caller sets tile_q0 / tile_in / tile_out / tile_state.
 constexpr int TILE_G = 64, TILE_C = 38, TILE_COLS = TILE_G * TILE_C;
 hipError_t launch_tile_v2(const ScoreArgsV2& a, bool wide, int mode, hipStream_t stream);
+// zsw_score_w32.hip: the same tile in 32-bit lanes over the reads list[0 .. a.b.n_items) (scores beyond the packed range)
+hipError_t launch_tile_w32(const ScoreArgsV2& a, const uint32_t* list, int mode, hipStream_t stream);
 
 }  // namespace zsw
