@@ -529,7 +529,11 @@ def test_long_reads_are_scored_tile_by_tile(za, oracle, dna, monkeypatch):
         assert (int(ends.score[i]), int(ends.ref_end[i]), int(ends.query_end[i])) == (s, re_, qe), i
         st, s, rr, qr = oracle.score_ranges("i32", 8, sc, rd, ref)
         assert (int(rg.score[i]), (int(rg.ref_start[i]), int(rg.ref_end[i])), (int(rg.query_start[i]), int(rg.query_end[i]))) == (s, rr, qr), i
-    # i16 tier: scores above 32767 overflow, below do not
+    # 3-pass alignment on top of the tiled forward and reverse passes
+    a3 = za.StripedProfileBatch(reads[:4], dna, -10, -1, "i32", 8).sw_align_3pass(za.SeqSrc.Reference(ref))
+    for i, rd in enumerate(reads[:4]):
+        want = oracle.align_3pass("i32", 8, sc, rd, ref)[0]
+        assert a3.key(i) == (want.key() if want.status == S_ else (want.status, 0, (0, 0), (0, 0), "", 0, 0)), i
     c16 = za.LocalProfilesBatch.new_with_w256(reads, dna, -10, -1).sw_score_from_i16(ref)
     for i, rd in enumerate(reads):
         st, s, tier = oracle.cascade_score(16, 256, sc, rd, ref)

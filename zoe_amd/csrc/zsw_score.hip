@@ -345,6 +345,11 @@ __device__ __forceinline__ int bucket_of(const BucketCaps& caps, uint32_t len) {
     return k;
 }
 
+__global__ void reverse_bytes_kernel(const uint8_t* in, uint32_t n, uint8_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[n - 1 - i];
+}
+
 __global__ void iota_kernel(uint32_t* out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = i;
@@ -422,6 +427,12 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     a2.sc = d_sc;
     a2.rule = rule;
     a2.out = out;
+    a2.tile_q0 = 0;
+    a2.tile_in = nullptr;
+    a2.tile_out = nullptr;
+    a2.tile_state = nullptr;
+    a2.rev_ref_end = nullptr;
+    a2.rev_query_end = nullptr;
     auto launch_one = [&](const BatchDev& bb, int g, int c) -> hipError_t {
         if (wide) {
             if (build_tables_wide(h_sc, g, &a2)) {
@@ -635,6 +646,42 @@ hipError_t launch_score_rev(const ScoringDev* d_sc, const ScoringDev& h_sc, cons
     int G = 0, C = 0;
     const bool wide = wide_ok(h_sc);
     const bool table_ok = (h_sc.S <= 7 || fast_ok(h_sc) || wide) && score_config_for(max_len, &G, &C);
+    if (!score_config_for(max_len, &G, &C) && ws.tile_buf && ws.tile_state && ws.bucket_items && w32_ok(h_sc, ref_len, max_len) && b.n_items) {
+        // reads longer than every strip configuration: the 32-bit tile kernel over the reversed reference (held in d_gtab's bytes)
+        uint8_t* d_rev = reinterpret_cast<uint8_t*>(d_gtab);
+        if (ref_len) hipLaunchKernelGGL(reverse_bytes_kernel, dim3((ref_len + 255) / 256), dim3(256), 0, stream, d_ref, ref_len, d_rev);
+        hipLaunchKernelGGL(iota_kernel, dim3((b.n_items + 255) / 256), dim3(256), 0, stream, ws.bucket_items, b.n_items);
+        ScoreArgsV2 a2;
+        a2.b = b;
+        a2.ref = d_rev;
+        a2.ref_len = ref_len;
+        a2.sc = d_sc;
+        a2.rule = rule;
+        a2.out = out;
+        a2.rev_ref_end = d_fwd_ref_end;
+        a2.rev_query_end = d_fwd_query_end;
+        a2.tile_state = ws.tile_state;
+        fill_wide_table(h_sc, &a2);
+        a2.ge2 = (uint32_t)h_sc.gap_extend * 0x00010001u;
+        a2.gd2 = (uint32_t)(h_sc.gap_open - h_sc.gap_extend) * 0x00010001u;
+        const size_t per_read = (size_t)ref_len * sizeof(uint2), half = ws.tile_bytes / 2;
+        const size_t fit = per_read ? half / per_read : (size_t)b.n_items;
+        if (fit > 0) {
+            uint2* buf[2] = {ws.tile_buf, reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(ws.tile_buf) + half)};
+            const uint32_t n_tiles = (max_len + TILE_COLS - 1) / TILE_COLS;
+            for (uint32_t first = 0; first < b.n_items; first += (uint32_t)std::min<size_t>(fit, 0x7fffffffu)) {
+                a2.b.n_items = (uint32_t)std::min<size_t>(fit, b.n_items - first);
+                for (uint32_t t = 0; t < n_tiles; ++t) {
+                    a2.tile_q0 = t * (uint32_t)TILE_COLS;
+                    a2.tile_in = t ? buf[(t - 1) & 1] : nullptr;
+                    a2.tile_out = t + 1 < n_tiles ? buf[t & 1] : nullptr;
+                    e = launch_tile_w32(a2, ws.bucket_items + first, 2, stream);
+                    if (e != hipSuccess) return e;
+                }
+            }
+            return hipSuccess;
+        }
+    }
     if (!table_ok) {
         hipLaunchKernelGGL(exact32_kernel, dim3(exact_grid), dim3(64), 0, stream, b, (const uint32_t*)nullptr,
                            (const uint32_t*)nullptr, d_ref, ref_len, d_sc, rule, out, ws.scratch, (uint32_t)ws.slots,

@@ -75,6 +75,10 @@ struct ScoreArgsV2 {
     const uint2* tile_in;  // [pair][R] (last H, outgoing F) left by the previous tile's last lane, drift domain; null: first tile
     uint2* tile_out;       // the same, written by this tile's last lane; null: last tile
     uint4* tile_state;     // per read: (best true score | 0xffffffff = beyond the packed range, ref_end, query_end, -) so far
+    // score_kernel_w32 as the reverse pass of sw_simd_score_ranges (null = forward): `ref` is then the REVERSED reference, a read
+    // takes part from row ref_len - rev_ref_end[id] on with reverse(read[..rev_query_end[id]]), and the outputs are the starts.
+    const uint32_t* rev_ref_end;
+    const uint32_t* rev_query_end;
 };
 
 template <int G, int C, int MODE, bool WIDE = false, bool TILED = false>

@@ -41,11 +41,21 @@ __global__ __launch_bounds__(BLOCK, 2) void score_kernel_w32(ScoreArgsV2 a, cons
             len = a.b.fixed_len;
         }
     }
+    const int R = (int)a.ref_len;
+    // Reverse pass: rows before this read's prefix behave like the neutral row (the state stays at the zero floor, which is
+    // what starting the recurrence at that row means), the read is reverse(read[..query_end]).
+    const bool rev = a.rev_ref_end != nullptr;
+    int start_row = 0;
+    if (rev) {
+        const uint32_t qe_fwd = valid ? a.rev_query_end[id] : 0;
+        len = min(len, qe_fwd);
+        start_row = len ? R - (int)min(a.rev_ref_end[id], (uint32_t)R) : R;
+    }
     uint32_t sel[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const uint32_t q = a.tile_q0 + (uint32_t)(g * C + c);
-        sel[c] = q < len ? (uint32_t)lut[a.b.bases[off + q]] : (uint32_t)WIDE_PAD;
+        sel[c] = q < len ? (uint32_t)lut[a.b.bases[rev ? off + (len - 1 - q) : off + q]] : (uint32_t)WIDE_PAD;
     }
     const int32_t ge = (int32_t)(a.ge2 & 0xffffu), gd = (int32_t)(a.gd2 & 0xffffu);
     // D_r = (r + G + 2) * ge: row r of this lane at step t is r = t - g, so every D the lane touches is >= 0
@@ -63,7 +73,6 @@ __global__ __launch_bounds__(BLOCK, 2) void score_kernel_w32(ScoreArgsV2 a, cons
     }
     int32_t snapD = 0, best = 0, rbest = 0;
     int32_t Fout = Dr, Hlast = Dr, Hin_prev = Dr;
-    const int R = (int)a.ref_len;
     const int T = R + G - 1;
     uint2 bd = make_uint2(0u, 0u);
     if (g == 0 && valid && a.tile_in != nullptr && R > 0) bd = a.tile_in[(size_t)group * (size_t)R];
@@ -84,6 +93,7 @@ __global__ __launch_bounds__(BLOCK, 2) void score_kernel_w32(ScoreArgsV2 a, cons
         for (int t = base; t < tend; ++t) {
             const uint32_t wn = rpw[t + 1 + joff];
             const int row = t - g;
+            if (row < start_row) w = WIDE_NEUTRAL * WIDE_STRIDE;
             Dr += ge;                   // D_r
             const int32_t Dn = Dr + ge;  // D_{r+1}
             int32_t Fin = __shfl_up(Fout, 1, G);
@@ -181,6 +191,11 @@ __global__ __launch_bounds__(BLOCK, 2) void score_kernel_w32(ScoreArgsV2 a, cons
     a.out.status[id] = status;
     if (a.out.tier) a.out.tier[id] = tier;
     const bool some = status == ZSW_STATUS_SOME;
+    if (rev) {  // inclusive 0-based starts (striped.rs:326-328); `re` counts rows of the whole reversed reference
+        if (a.out.ref_end) a.out.ref_end[id] = some ? (uint32_t)R - re : 0;
+        if (a.out.query_end) a.out.query_end[id] = some ? len - qe : 0;
+        return;
+    }
     if (MODE != 0 && a.out.ref_end) a.out.ref_end[id] = some ? re : 0;
     if (MODE == 2 && a.out.query_end) a.out.query_end[id] = some ? qe : 0;
 }
