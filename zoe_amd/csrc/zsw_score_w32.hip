@@ -58,8 +58,16 @@ __global__ __launch_bounds__(BLOCK, 2) void score_kernel_w32(ScoreArgsV2 a, cons
         sel[c] = q < len ? (uint32_t)lut[a.b.bases[rev ? off + (len - 1 - q) : off + q]] : (uint32_t)WIDE_PAD;
     }
     const int32_t ge = (int32_t)(a.ge2 & 0xffffu), gd = (int32_t)(a.gd2 & 0xffffu);
+    // Reverse pass: no read of this block takes part before the smallest start row, so the block starts at the chunk holding it
+    // (the state there is the zero floor either way; later tiles skip the same rows and never read their boundary).
+    __shared__ int first_row;
+    if (tid == 0) first_row = rev ? R : 0;
+    __syncthreads();
+    if (rev && g == 0) atomicMin(&first_row, start_row);
+    __syncthreads();
+    const int base0 = (first_row / CH) * CH;
     // D_r = (r + G + 2) * ge: row r of this lane at step t is r = t - g, so every D the lane touches is >= 0
-    int32_t Dr = (G + 1 - g) * ge;  // D of row r-1 at the first step (r = -g)
+    int32_t Dr = (base0 + G + 1 - g) * ge;  // D of row r-1 at the first step (r = base0 - g)
     int32_t H[C], E[C];
     int32_t snap[MODE == 2 ? C : 1];
 #pragma unroll
@@ -75,9 +83,9 @@ __global__ __launch_bounds__(BLOCK, 2) void score_kernel_w32(ScoreArgsV2 a, cons
     int32_t Fout = Dr, Hlast = Dr, Hin_prev = Dr;
     const int T = R + G - 1;
     uint2 bd = make_uint2(0u, 0u);
-    if (g == 0 && valid && a.tile_in != nullptr && R > 0) bd = a.tile_in[(size_t)group * (size_t)R];
+    if (g == 0 && valid && a.tile_in != nullptr && base0 < R) bd = a.tile_in[(size_t)group * (size_t)R + (size_t)base0];
 
-    for (int base = 0; base < T; base += CH) {
+    for (int base = base0; base < T; base += CH) {
         __syncthreads();
         for (int j = tid; j < CH + G - 1; j += BLOCK) {
             const int row = base - (G - 1) + j;
