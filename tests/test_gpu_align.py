@@ -330,3 +330,33 @@ def test_late_start_on_long_references(za, oracle, scheme):
         for i, rd in enumerate(reads):
             want = oracle.align(T, N, sc, rd, ref)
             assert got.key(i) == okey(want), (T, N, i, rd)
+
+
+def test_profiles_too_long_for_lds_keep_their_rows_in_hbm(za, oracle):
+    """nv above ~250 vectors no longer fits one wavefront's LDS: the generic kernel then keeps H, E, the residue codes and the
+    flags of a block in HBM behind the flag ring. A 6 kb and a 4.2 kb read at i16x16 (nv = 375 / 263) against a 7 kb reference."""
+    rng = np.random.default_rng(31)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = bytes(rng.choice(alpha, 7000))
+    m = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    sc = osc(oracle, m, -10, -1)
+
+    def mutated(s0, L):
+        r = bytearray(ref[s0:s0 + L])
+        for _ in range(L // 60):
+            k = int(rng.integers(0, len(r)))
+            u = rng.random()
+            if u < 0.5:
+                r[k] = int(rng.choice(alpha))
+            elif u < 0.75:
+                del r[k]
+            else:
+                r.insert(k, int(rng.choice(alpha)))
+        return bytes(r)
+
+    reads = [mutated(500, 6000), mutated(2000, 4200), ref[100:300]]
+    got = za.StripedProfileBatch(reads, m, -10, -1, "i16", 16).sw_align(za.SeqSrc.Reference(ref))
+    for i, rd in enumerate(reads):
+        want = oracle.align("i16", 16, sc, rd, ref)
+        assert got.key(i) == okey(want), i
+    assert int(got.records[0]["score"]) > 10000

@@ -48,6 +48,7 @@ struct AlignArgs {
     uint32_t* fb_list;
     uint32_t* fb_count;
     int invert;
+    uint8_t* rows;  // GLOBAL_ROWS kernels: per-block H/E/profile/flag rows in HBM (null otherwise)
     int debug;  // ZSW_ALIGN_DEBUG experiments: 1 = skip traceback, 2 = skip ring stores, 4 = no late start
 };
 
@@ -64,6 +65,10 @@ __device__ __forceinline__ int warmup_rows(const int32_t* w, int S, int ge, int 
     const long long b = (long long)l_pad + ((long long)l_pad * maxw) / ge + 2;
     return b > 0x3fffffff ? 0x3fffffff : (int)b;
 }
+
+// bytes of one block's DP rows in the generic kernel: H, E (i32), residue codes and flags (u8) per vector and lane
+__host__ __device__ inline size_t align_rows_bytes(uint32_t nv) { return (size_t)nv * 64 * (4 + 4 + 1 + 1); }
+constexpr size_t ALIGN_LDS_LIMIT = 160 * 1024 - 9 * 1024;
 
 // max(a - b, 0) for non-negative a, b: one v_sub_u32 with clamp
 __device__ __forceinline__ int32_t subsat(int32_t a, int32_t b) {
@@ -160,10 +165,12 @@ __device__ __forceinline__ void traceback_emit(const AlignArgs& a, uint32_t id, 
     }
 }
 
-// Generic form: any nv, DP rows in LDS.
-template <int N>
+// Generic form: any nv, DP rows in LDS — or, for profiles too long for one wavefront's LDS (nv above ~250), in a per-block
+// region of HBM behind the flag ring (GLOBAL_ROWS).
+template <int N, bool GLOBAL_ROWS = false>
 __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
-    extern __shared__ __align__(16) uint8_t smem[];
+    extern __shared__ __align__(16) uint8_t smem_lds[];
+    uint8_t* smem = GLOBAL_ROWS ? a.rows + (size_t)blockIdx.x * align_rows_bytes(a.nv) : smem_lds;
     __shared__ uint8_t lut[256];
     __shared__ int32_t wsh[MAX_S * MAX_S];
     __shared__ int32_t wpad[MAX_S * (MAX_S + 1)];  // weights with one more column: the padding residue S scores 0
@@ -662,7 +669,7 @@ __global__ void write_ciglets_kernel(zsw_alignment* aln, const uint8_t* status, 
     aln[i] = rec;
 }
 
-static size_t align_lds_bytes(uint32_t nv, int S) { (void)S; return (size_t)nv * 64 * (4 + 4 + 1 + 1); }
+static size_t align_lds_bytes(uint32_t nv, int S) { (void)S; return align_rows_bytes(nv); }
 static size_t align_lds_bytes_reg(uint32_t nv, int S) { return (size_t)S * ((nv + 3) / 4) * 64 * 4; }
 
 template <typename K>
@@ -693,7 +700,11 @@ static hipError_t launch_align_n(const AlignArgs& a, int S, uint32_t grid, hipSt
             case 8: return launch_with_lds(&align_kernel_x<N, 8>, &setx[8], a, grid, lds, stream);
         }
     }
-    return launch_with_lds(&align_kernel<N>, &set_lds, a, grid, align_lds_bytes(a.nv, S), stream);
+    if (align_lds_bytes(a.nv, S) > ALIGN_LDS_LIMIT) {  // rows in HBM
+        hipLaunchKernelGGL((align_kernel<N, true>), dim3(grid), dim3(64), 0, stream, a);
+        return hipGetLastError();
+    }
+    return launch_with_lds(&align_kernel<N, false>, &set_lds, a, grid, align_lds_bytes(a.nv, S), stream);
 }
 
 }  // namespace zsw
@@ -719,6 +730,8 @@ hipError_t run_group(int N, AlignArgs a, int S, uint32_t grid, hipStream_t strea
 // The host orchestration (zsw_align_batch / zsw_align_batch_from) lives in zsw_capi.hip because it needs the
 // context internals; it calls these entry points.
 namespace zsw {
+
+static size_t align_ring_only_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid);
 
 hipError_t align_pass2(int N, uint32_t nv, const BatchDev& b, const uint8_t* d_ref, uint32_t ref_len, const ScoringDev* d_sc,
                        int S, const uint32_t* d_score, const uint32_t* d_ref_end, const uint8_t* d_status, uint32_t W,
@@ -747,14 +760,24 @@ hipError_t align_pass2(int N, uint32_t nv, const BatchDev& b, const uint8_t* d_r
     a.fb_count = d_fb_count;
     a.invert = invert;
     a.debug = getenv("ZSW_ALIGN_DEBUG") ? atoi(getenv("ZSW_ALIGN_DEBUG")) : 0;
+    // profiles too long for LDS keep their rows behind the ring (align_ring_bytes reserves the space)
+    a.rows = (nv > 32 && align_rows_bytes(nv) > ALIGN_LDS_LIMIT) ? d_ring + align_ring_only_bytes(N, nv, W, grid) : nullptr;
     return run_group(N, a, S, grid, stream);
 }
 
-size_t align_ring_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid) {
+static size_t align_ring_only_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid) {
     const size_t row = (size_t)N * (nv <= 32 ? ((nv + 3) / 4) * 4 : nv);
-    return (size_t)grid * (64 / N) * (size_t)W * row;
+    return ((size_t)grid * (64 / N) * (size_t)W * row + 255) / 256 * 256;
 }
-size_t align_lds_need(uint32_t nv, int S) { return nv <= 32 ? align_lds_bytes_reg(nv, S) : align_lds_bytes(nv, S); }
+size_t align_ring_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid) {
+    size_t bytes = align_ring_only_bytes(N, nv, W, grid);
+    if (nv > 32 && align_rows_bytes(nv) > ALIGN_LDS_LIMIT) bytes += (size_t)grid * align_rows_bytes(nv);
+    return bytes;
+}
+size_t align_lds_need(uint32_t nv, int S) {
+    if (nv <= 32) return align_lds_bytes_reg(nv, S);
+    return align_lds_bytes(nv, S) > ALIGN_LDS_LIMIT ? 0 : align_lds_bytes(nv, S);  // 0: the rows live in HBM
+}
 
 hipError_t align_finalize(zsw_alignment* d_aln, const uint8_t* d_status, uint32_t n, uint64_t* d_block_sums,
                           uint64_t* d_total, const uint64_t* d_cig_start, const uint32_t* d_cig_raw, int invert,
