@@ -60,10 +60,31 @@ for it in range(iters):
             reads.append(bytes(r))
         else:
             reads.append(bytes(rng.choice(alpha, L)))
-    if rng.random() < 0.3:  # fixed-length batch
+    long_case = rng.random() < 0.12
+    if long_case:  # a few reads beyond the widest strip configuration: tiled / 32-bit / HBM-row paths
+        R = int(rng.integers(3000, 7000))
+        ref = bytes(rng.choice(alpha[:2] if lo_c else alpha, R))
+        reads = reads[:6]
+        for _ in range(2):
+            L = int(rng.integers(2433, 5200))
+            r = bytearray((ref * 3)[int(rng.integers(0, R)):][:L])
+            for _ in range(L // 50):
+                k = int(rng.integers(0, len(r)))
+                u = rng.random()
+                if u < 0.5:
+                    r[k] = int(rng.choice(alpha))
+                elif u < 0.75 and len(r) > 1:
+                    del r[k]
+                else:
+                    r.insert(k, int(rng.choice(alpha)))
+            reads.append(bytes(r))
+        reads = [r for r in reads if len(r) <= R + 40 or len(r) > 2432]
+    if not long_case and rng.random() < 0.3:  # fixed-length batch
         L = int(rng.integers(5, 200))
         reads = [(r * (L // len(r) + 1))[:L] for r in reads]
     T, N = [("i16", 16), ("i8", 32), ("i16", 8), ("i32", 8), ("i8", 16), ("i16", 4), ("i16", 32), ("i8", 64)][int(rng.integers(0, 8))]
+    if long_case:
+        T, N = [("i16", 16), ("i32", 32), ("i16", 64), ("i32", 16)][int(rng.integers(0, 4))]
     preset = int(rng.choice([128, 256, 512]))
     width = int(rng.choice([8, 16, 32]))
     inv = bool(rng.random() < 0.3)
