@@ -89,3 +89,62 @@ def test_error_codes_and_recovery(env):
     bz = _lib.ZswBatch()
     bz.bases, bz.offsets, bz.fixed_len, bz.n_reads, bz.mem = cat.ctypes.data, offs.ctypes.data, 0, 0, _lib.MEM_HOST
     assert lib.zsw_score_batch(h, C.byref(bz), 1, 16, score.ctypes.data, status.ctypes.data, None) == 0
+
+
+def test_two_contexts_on_two_host_threads(env):
+    """"Thread-safe per context": two host threads, each with its own context on the same GPU and its own stream, score ragged
+    batches concurrently (ctypes releases the GIL during the calls); every result equals the single-threaded one."""
+    import threading
+
+    import torch
+
+    za, _lib, lib, _ = env
+    from zoe_amd import synth
+
+    m = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    w = np.ascontiguousarray(m.signed_weights(), dtype=np.int8)
+    im = m.mapping.index_map
+    refs = [synth.reference_host(3000, seed=s) for s in (1, 2)]
+    batches = [synth.reads_ragged_host(refs[k], 0, 20000, 60, 400, seed=10 + k) for k in range(2)]
+    results = [[], []]
+    errors = []
+
+    def worker(k):
+        try:
+            h = C.c_void_p()
+            assert lib.zsw_create(0, C.byref(h)) == 0
+            assert lib.zsw_set_scoring(h, w.ctypes.data, 5, im.ctypes.data, -10, -1) == 0
+            ref = np.frombuffer(refs[k], dtype=np.uint8)
+            assert lib.zsw_set_reference(h, ref.ctypes.data, len(ref), _lib.MEM_HOST) == 0
+            bases, offs = batches[k]
+            offs = np.ascontiguousarray(offs, dtype=np.uint64)
+            b = _lib.ZswBatch()
+            b.bases, b.offsets, b.fixed_len, b.n_reads, b.mem = bases.ctypes.data, offs.ctypes.data, 0, len(offs) - 1, _lib.MEM_HOST
+            stream = torch.cuda.Stream()
+            for _ in range(6):
+                score = np.zeros(len(offs) - 1, dtype=np.uint32)
+                status = np.zeros(len(offs) - 1, dtype=np.uint8)
+                tier = np.zeros(len(offs) - 1, dtype=np.uint8)
+                rc = lib.zsw_score_batch_from(h, C.byref(b), 8, 256, score.ctypes.data, status.ctypes.data, tier.ctypes.data, C.c_void_p(stream.cuda_stream))
+                assert rc == 0
+                results[k].append((score, status, tier))
+            lib.zsw_destroy(h)
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        first = results[k][0]
+        for other in results[k][1:]:
+            for a, b_ in zip(first, other):
+                assert np.array_equal(a, b_)
+        # and equal to a quiet, single-threaded run through the Python mirror
+        bases, offs = batches[k]
+        seqs = [bases[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(0, 400)]
+        quiet = za.LocalProfilesBatch.new_with_w256(seqs, m, -10, -1).sw_score_from_i8(refs[k])
+        assert np.array_equal(quiet.score.cpu().numpy().view(np.uint32), first[0][:400]) and np.array_equal(quiet.status.cpu().numpy(), first[1][:400])

@@ -59,6 +59,8 @@ struct zsw_context {
     // host batches: reads of chunk k+1 cross PCIe on this stream while chunk k computes
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> copy_events;
+    // ragged batches: the length classes run on these (created with the first ragged batch)
+    SideStreams* side = nullptr;
 };
 
 namespace {
@@ -232,6 +234,17 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     ZSW_HIP(ctx, ctx->d_fb_list.ensure((size_t)n * 4 + 4));
     ZSW_HIP(ctx, ctx->d_fb_count.ensure(4));
     if (reads->offsets || st->max_len > LONGEST_STRIP) ZSW_HIP(ctx, ctx->d_bucket_items.ensure((size_t)n * 4 + 4));
+    if (reads->offsets && !ctx->side) {
+        SideStreams* p = new (std::nothrow) SideStreams();
+        if (p) {
+            bool ok = hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; ok && i < SideStreams::N; ++i)
+                ok = hipStreamCreateWithFlags(&p->s[i], hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&p->join[i], hipEventDisableTiming) == hipSuccess;
+            if (ok) ctx->side = p;  // otherwise the classes simply run in sequence
+            else delete p;
+        }
+    }
     if (st->max_len > LONGEST_STRIP) {  // tile-by-tile scoring of long reads: boundary buffers for as many read pairs as 1 GiB holds
         const size_t per_pair = std::max<size_t>(ctx->ref_len, 1) * 8, pairs = ((size_t)n + 1) / 2;
         const size_t want = 2 * std::min<size_t>(pairs * per_pair, std::max<size_t>(per_pair, size_t(512) << 20));
@@ -257,6 +270,7 @@ ScoreWorkspace score_ws(zsw_context* ctx) {
     w.tile_buf = ctx->d_tile_buf.as<uint2>();
     w.tile_bytes = ctx->d_tile_buf.cap / 16 * 16;
     w.tile_state = ctx->d_tile_state.as<uint4>();
+    w.side = ctx->side;
     return w;
 }
 
@@ -883,6 +897,14 @@ void zsw_destroy(zsw_context* ctx) {
     for (DevBuf& b : ctx->a_ws) b.release();
     for (DevBuf& b : ctx->r_ws) b.release();
     ctx->timer.destroy();
+    if (ctx->side) {
+        (void)hipEventDestroy(ctx->side->fork);
+        for (int i = 0; i < SideStreams::N; ++i) {
+            (void)hipStreamDestroy(ctx->side->s[i]);
+            (void)hipEventDestroy(ctx->side->join[i]);
+        }
+        delete ctx->side;
+    }
     for (hipEvent_t ev : ctx->copy_events) (void)hipEventDestroy(ev);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     delete ctx;

@@ -68,6 +68,13 @@ struct ScoreOut {
 
 struct KernelTimer;
 
+// Side streams on which the length classes of a ragged batch run concurrently (forked from / joined to the caller's stream).
+struct SideStreams {
+    static constexpr int N = 4;
+    hipStream_t s[N];
+    hipEvent_t fork, join[N];
+};
+
 // launchers (zsw_score.hip)
 struct ScoreWorkspace {
     int32_t* scratch;       // exact32 kernel rows: 2 * slots * scratch_len ints
@@ -80,6 +87,7 @@ struct ScoreWorkspace {
     uint2* tile_buf = nullptr;
     size_t tile_bytes = 0;
     uint4* tile_state = nullptr;
+    SideStreams* side = nullptr;  // null: the length classes run one after the other on the caller's stream
 };
 
 hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,

@@ -23,8 +23,6 @@
 #include <stdlib.h>
 
 #include <algorithm>
-#include <mutex>
-#include <new>
 
 #include "zsw_internal.hpp"
 #include "zsw_score_v1.hpp"
@@ -372,31 +370,6 @@ __global__ void bucket_scatter_kernel(const uint64_t* offsets, uint32_t n, Bucke
     }
 }
 
-// Side streams for the ragged path (one set per device, created on first use, never destroyed: process lifetime).
-struct SideStreams {
-    static constexpr int N = 4;
-    hipStream_t s[N];
-    hipEvent_t fork, join[N];
-};
-static SideStreams* side_streams() {
-    static SideStreams* per_device[64] = {};
-    static std::mutex mu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!per_device[dev]) {
-        SideStreams* p = new (std::nothrow) SideStreams();
-        if (!p) return nullptr;
-        bool ok = hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; ok && i < SideStreams::N; ++i)
-            ok = hipStreamCreateWithFlags(&p->s[i], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&p->join[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) return nullptr;  // leaks a few handles in a situation where nothing else works either
-        per_device[dev] = p;
-    }
-    return per_device[dev];
-}
-
 hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
                         const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
                         const ScoreWorkspace& ws, hipStream_t stream, KernelTimer* timer, int mode) {
@@ -555,7 +528,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         if (timer) timer->begin(stream);
         // The length classes are independent launches and the small ones cannot fill the chip on their own (a class of
         // 70 k reads is two wavefronts per SIMD): they are spread over side streams, forked from and joined to `stream`.
-        SideStreams* side = side_streams();
+        SideStreams* side = ws.side;  // owned by the context: two contexts never share fork/join events
         const bool fork = side != nullptr && !getenv("ZSW_NO_SIDE_STREAMS");
         if (fork) {
             e = hipEventRecord(side->fork, stream);
