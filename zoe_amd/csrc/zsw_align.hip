@@ -673,12 +673,11 @@ static size_t align_lds_bytes(uint32_t nv, int S) { (void)S; return align_rows_b
 static size_t align_lds_bytes_reg(uint32_t nv, int S) { return (size_t)S * ((nv + 3) / 4) * 64 * 4; }
 
 template <typename K>
-static hipError_t launch_with_lds(K kernel, bool* attr_set, const AlignArgs& a, uint32_t grid, size_t lds, hipStream_t stream) {
-    if (!*attr_set) {
+static hipError_t launch_with_lds(K kernel, const AlignArgs& a, uint32_t grid, size_t lds, hipStream_t stream) {
+    if (lds > 48 * 1024) {  // above the default dynamic-LDS limit: raise it (per device, so it is not cached in a process-wide flag)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 9 * 1024);
         if (e != hipSuccess) return e;
-        *attr_set = true;
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, stream, a);
     return hipGetLastError();
@@ -686,25 +685,24 @@ static hipError_t launch_with_lds(K kernel, bool* attr_set, const AlignArgs& a, 
 
 template <int N>
 static hipError_t launch_align_n(const AlignArgs& a, int S, uint32_t grid, hipStream_t stream) {
-    static bool set_lds = false, setx[9] = {};
     const size_t lds = align_lds_bytes_reg(a.nv, S);
     if (a.nv <= 32) {
         switch ((a.nv + 3) / 4) {
-            case 1: return launch_with_lds(&align_kernel_x<N, 1>, &setx[1], a, grid, lds, stream);
-            case 2: return launch_with_lds(&align_kernel_x<N, 2>, &setx[2], a, grid, lds, stream);
-            case 3: return launch_with_lds(&align_kernel_x<N, 3>, &setx[3], a, grid, lds, stream);
-            case 4: return launch_with_lds(&align_kernel_x<N, 4>, &setx[4], a, grid, lds, stream);
-            case 5: return launch_with_lds(&align_kernel_x<N, 5>, &setx[5], a, grid, lds, stream);
-            case 6: return launch_with_lds(&align_kernel_x<N, 6>, &setx[6], a, grid, lds, stream);
-            case 7: return launch_with_lds(&align_kernel_x<N, 7>, &setx[7], a, grid, lds, stream);
-            case 8: return launch_with_lds(&align_kernel_x<N, 8>, &setx[8], a, grid, lds, stream);
+            case 1: return launch_with_lds(&align_kernel_x<N, 1>, a, grid, lds, stream);
+            case 2: return launch_with_lds(&align_kernel_x<N, 2>, a, grid, lds, stream);
+            case 3: return launch_with_lds(&align_kernel_x<N, 3>, a, grid, lds, stream);
+            case 4: return launch_with_lds(&align_kernel_x<N, 4>, a, grid, lds, stream);
+            case 5: return launch_with_lds(&align_kernel_x<N, 5>, a, grid, lds, stream);
+            case 6: return launch_with_lds(&align_kernel_x<N, 6>, a, grid, lds, stream);
+            case 7: return launch_with_lds(&align_kernel_x<N, 7>, a, grid, lds, stream);
+            case 8: return launch_with_lds(&align_kernel_x<N, 8>, a, grid, lds, stream);
         }
     }
     if (align_lds_bytes(a.nv, S) > ALIGN_LDS_LIMIT) {  // rows in HBM
         hipLaunchKernelGGL((align_kernel<N, true>), dim3(grid), dim3(64), 0, stream, a);
         return hipGetLastError();
     }
-    return launch_with_lds(&align_kernel<N, false>, &set_lds, a, grid, align_lds_bytes(a.nv, S), stream);
+    return launch_with_lds(&align_kernel<N, false>, a, grid, align_lds_bytes(a.nv, S), stream);
 }
 
 }  // namespace zsw
