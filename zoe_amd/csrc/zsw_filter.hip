@@ -61,21 +61,32 @@ __global__ __launch_bounds__(256) void sneaky_kernel(const uint8_t* __restrict__
         const int finish = n1 - 1 - ((int)et - obstacles);  // a match at col >= finish (or at n1-1) ends the walk (:116)
         for (int row = l; row < window; row += G) {
             const int shift = row + diffpad - (int)et;
-            int col = checkpoint;
-            while (col < n1) {
-                const int idx = col + shift;
-                if (idx >= 0 && idx < n2 && s2[idx] == s1[col]) {
-                    if (col >= finish) {
-                        hit = true;
-                        break;
+            // m = first column >= checkpoint of this diagonal that does not match (or leaves s2); four columns per step while
+            // both words are inside the sequences, then byte by byte
+            int m = checkpoint;
+            const int stop = min(n1, n2 - shift);  // columns < stop have a partner inside s2 (if col + shift >= 0)
+            if (m + shift >= 0) {
+                const uint8_t* p1 = s1;
+                const uint8_t* p2 = s2 + shift;
+                while (m + 4 <= stop) {
+                    uint32_t x, y;
+                    __builtin_memcpy(&x, p1 + m, 4);
+                    __builtin_memcpy(&y, p2 + m, 4);
+                    const uint32_t d = x ^ y;
+                    if (d) {
+                        m += __builtin_ctz(d) >> 3;
+                        goto scanned;
                     }
-                    ++col;
-                } else {
-                    last = max(last, col);
-                    break;
+                    m += 4;
                 }
+                while (m < stop && p1[m] == p2[m]) ++m;
             }
-            if (hit) break;
+        scanned:
+            if (m > finish) {  // the match at column `finish` (or the last column) ends the walk (:116)
+                hit = true;
+                break;
+            }
+            last = max(last, m);
         }
         int h = hit ? 1 : 0;
 #pragma unroll
