@@ -124,7 +124,15 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
             // classify pass: the no-gaps shortcut (three_pass.rs:37-58) is resolved here, the rest is queued for the DP pass
             if (qlen == rlen) {
                 int64_t sum = 0;
-                for (uint32_t k = 0; k < qlen; ++k) sum += wt(a.ref[rs + k], query[qs + k]);
+                uint32_t k = 0;
+                for (; k + 4 <= qlen; k += 4) {  // four residues per (unaligned) load
+                    uint32_t rw, qw;
+                    __builtin_memcpy(&rw, a.ref + rs + k, 4);
+                    __builtin_memcpy(&qw, query + qs + k, 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sum += wt((uint8_t)(rw >> (8 * j)), (uint8_t)(qw >> (8 * j)));
+                }
+                for (; k < qlen; ++k) sum += wt(a.ref[rs + k], query[qs + k]);
                 if ((sum < 0 ? 0u : (uint32_t)sum) == score) {
                     w.push(query_len - qe, 'S');
                     w.push(qe - qs, 'M');
