@@ -60,7 +60,7 @@ for it in range(iters):
             reads.append(bytes(r))
         else:
             reads.append(bytes(rng.choice(alpha, L)))
-    long_case = rng.random() < 0.12
+    long_case = rng.random() < float(os.environ.get("FUZZ_LONG_P", "0.12"))
     if long_case:  # a few reads beyond the widest strip configuration: tiled / 32-bit / HBM-row paths
         R = int(rng.integers(3000, 7000))
         ref = bytes(rng.choice(alpha[:2] if lo_c else alpha, R))
