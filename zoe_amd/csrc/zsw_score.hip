@@ -128,13 +128,17 @@ struct Cfg {
 static const Cfg kCfgs[] = {ZSW_FOR_EACH_STRIP_CONFIG(ZSW_CFG_ENTRY)};
 #undef ZSW_CFG_ENTRY
 
+constexpr int N_ASCENDING_CFGS = 13;  // the rest of kCfgs is for small batches only (score_config_for_batch)
+
 bool score_config_for(uint32_t max_len, int* G, int* C) {
-    for (const Cfg& c : kCfgs)
+    for (int k = 0; k < N_ASCENDING_CFGS; ++k) {
+        const Cfg& c = kCfgs[k];
         if ((uint32_t)(c.G * c.C) >= max_len) {
             *G = c.G;
             *C = c.C;
             return true;
         }
+    }
     return false;
 }
 

@@ -10,10 +10,12 @@ constexpr int CH = 2048;       // reference rows staged in LDS per chunk
 constexpr int NEUTRAL = 8;     // table row used outside [0, R): scores 0 for every residue
 constexpr int PAD_K = 255;     // residue code of a padded query column
 
-// The strip configurations (G lanes per read pair x C columns per lane), ascending capacity G*C. Every launcher switch and the
-// configuration table are generated from this one list.
+// The strip configurations (G lanes per read pair x C columns per lane). Every launcher switch and the configuration table are
+// generated from this one list: thirteen of ascending capacity G*C, which the first-fit choice and the length classes of ragged
+// batches walk in order, then (32, 5), which only the batch-size-aware choice picks (short reads, too few of them to fill the
+// chip with four lanes per pair).
 #define ZSW_FOR_EACH_STRIP_CONFIG(X) \
-    X(4, 19) X(4, 25) X(4, 32) X(4, 38) X(8, 19) X(8, 25) X(8, 32) X(8, 38) X(16, 25) X(16, 32) X(16, 38) X(64, 19) X(64, 38)
+    X(4, 19) X(4, 25) X(4, 32) X(4, 38) X(8, 19) X(8, 25) X(8, 32) X(8, 38) X(16, 25) X(16, 32) X(16, 38) X(64, 19) X(64, 38) X(32, 5)
 constexpr int WIDE_STRIDE = 36;  // bytes per table row of the WIDE kernels (9 dwords: rows start in different LDS banks)
 constexpr int WIDE_PAD = 32, WIDE_NEUTRAL = 32;
 
