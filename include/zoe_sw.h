@@ -207,6 +207,20 @@ void zsw_synth_reads_ragged_host(uint64_t seed, uint64_t first, uint64_t n, uint
 zsw_error zsw_timing_enable(zsw_context* ctx, int enable);
 zsw_error zsw_timing_read(zsw_context* ctx, double* seconds, uint64_t* launches);
 
+/* Kernel-selection overrides for the parity tests (every path below is bit-identical to the default one; the tests
+ * prove it by running both). Results never depend on these bits, only which kernel produces them. The library reads
+ * no environment variable. */
+typedef enum zsw_debug_flag {
+    ZSW_DEBUG_SCORE_V1 = 1,          /* score: Zoe's signed-offset arithmetic (score_kernel) instead of the drift-domain kernel */
+    ZSW_DEBUG_NO_TILES = 2,          /* score: reads longer than the widest strip configuration go to the exact 32-bit kernel */
+    ZSW_DEBUG_NO_W32 = 4,            /* score: scores beyond the packed range go to the exact 32-bit kernel, not the 32-bit tile kernel */
+    ZSW_DEBUG_NO_WIDE = 8,           /* score: 8..32-letter alphabets go to the exact 32-bit kernel */
+    ZSW_DEBUG_NO_SIDE_STREAMS = 16,  /* score: length classes of a ragged batch run one after the other */
+    ZSW_DEBUG_NO_PIPELINE = 32,      /* score: host batches are copied whole before the kernel */
+    ZSW_DEBUG_ALIGN_NO_PACKED = 64   /* align: the 32-bit one-read-per-lane-group kernel answers every group */
+} zsw_debug_flag;
+zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags);
+
 #ifdef __cplusplus
 }
 #endif

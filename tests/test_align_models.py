@@ -1,0 +1,31 @@
+"""CPU checks of the alignment kernel's arithmetic (no GPU): the closed form of Zoe's lazy-F loop (striped.rs:528-553)
+and the packed row update the gfx950 kernel is compiled from (zoe_amd/csrc/zsw_align_pk.hpp), both compared cell by
+cell with the oracle's literal restatement of sw_simd_align."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp_path, name):
+    exe = str(tmp_path / name)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-o", exe, os.path.join(ROOT, "tests", "models", name + ".cpp")], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("seed", [20261004, 7])
+def test_closed_form_lazy_f_equals_the_literal_loop(tmp_path, seed):
+    """T = (round, vector) of the loop's break from per-round bit strings, flags and H from M(v, lane): identical striped
+    backtrack matrices for N = 2..64, ten scoring schemes (gap_open = 0, gap_extend = 0 and equal gaps among them)."""
+    out = subprocess.run([_build(tmp_path, "align_closed_form"), "120", str(seed)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("seed", [20261004, 99])
+def test_packed_row_update_twin_equals_the_oracle(tmp_path, seed):
+    """zsw_align_pk.hpp compiled for the host (64 explicit lanes, the plain-C meaning of each gfx950 instruction): 2*64/N reads
+    per wavefront with different lengths and last rows, the first rows through the flag-less scan path."""
+    out = subprocess.run([_build(tmp_path, "align_pk_twin"), "6", str(seed)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -100,4 +100,4 @@ def test_header_is_c_and_links_from_c(tmp_path):
     env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "25 entry points, sizeof(zsw_alignment) = 40" in out.stdout
+    assert f"{len(header_symbols())} entry points, sizeof(zsw_alignment) = 40" in out.stdout

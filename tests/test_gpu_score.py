@@ -6,6 +6,8 @@ Bar: bit-exact score, status (and ends) for every read.
 import numpy as np
 import pytest
 
+from conftest import stable_seed
+
 pytestmark = pytest.mark.gpu
 
 S_, O_, U_, E_ = 0, 1, 2, 3
@@ -214,12 +216,12 @@ def _protein_case(za, seed, S=25, lo=-4, hi=12):
 
 
 @pytest.mark.parametrize("wide", [True, False])
-def test_protein_alphabet_wide_and_exact_kernels(za, oracle, monkeypatch, wide):
+def test_protein_alphabet_wide_and_exact_kernels(za, oracle, debug, wide):
     """25-letter alphabets (the reference's BLOSUM matrices are WeightMatrix<i8, 25>, src/data/matrices/aa.rs) run on the
-    WIDE packed kernels (zsw_score_wide.hip); ZSW_SCORE_NO_WIDE forces the exact 32-bit kernel. Both must equal the oracle:
+    WIDE packed kernels (zsw_score_wide.hip); ZSW_DEBUG_NO_WIDE forces the exact 32-bit kernel. Both must equal the oracle:
     score, ends and ranges, fixed-length and ragged batches."""
     if not wide:
-        monkeypatch.setenv("ZSW_SCORE_NO_WIDE", "1")
+        debug.set(debug.NO_WIDE)
     rng, keys, mp, w, m = _protein_case(za, 3)
     alpha = np.frombuffer(keys[:20], dtype=np.uint8)
     ref = bytes(rng.choice(alpha, 700))
@@ -308,7 +310,7 @@ def test_config5_mixed_lengths_30kb_reference(za, oracle, dna):
         assert (int(ends.status[i]), int(ends.score[i]), int(ends.ref_end[i]), int(ends.query_end[i])) == (st, s, re_, qe), i
 
 
-def test_v1_and_v2_score_kernels_agree(za, oracle, dna, monkeypatch):
+def test_v1_and_v2_score_kernels_agree(za, oracle, dna, debug):
     """score_kernel_v2 (row-drifted domain + v_pk_maximum3_f16) and score_kernel (saturating packed i16) are both
     bit-exact: same 10k-read batch through each, scores / ends compared with the oracle."""
     import torch
@@ -321,10 +323,7 @@ def test_v1_and_v2_score_kernels_agree(za, oracle, dna, monkeypatch):
     ws, wst, wt = oracle.batch_score_w256(8, sc, host, ref, fixed_len=150, threads=16)
     rb = za.ReadBatch.from_fixed(torch.from_numpy(host.reshape(-1)).cuda(), 150)
     for force_v1 in (False, True):
-        if force_v1:
-            monkeypatch.setenv("ZSW_SCORE_V1", "1")
-        else:
-            monkeypatch.delenv("ZSW_SCORE_V1", raising=False)
+        debug.set(debug.SCORE_V1 if force_v1 else 0)
         got = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1).sw_score_from_i8(ref)
         assert np.array_equal(got.score.cpu().numpy().view(np.uint32), ws), force_v1
         assert np.array_equal(got.status.cpu().numpy(), wst) and np.array_equal(got.tier.cpu().numpy(), wt)
@@ -341,7 +340,7 @@ def test_v2_ranges_gap_extremes_and_limit(za, oracle, scheme):
     ma, mi, go, ge = scheme
     m = za.WeightMatrix.new_dna_matrix(ma, mi, b"N")
     sc = osc(oracle, m, go, ge)
-    rng = np.random.default_rng(abs(hash(scheme)) % (2**32))
+    rng = np.random.default_rng(stable_seed(scheme))
     alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
     ref = bytes(rng.choice(alpha[:4], 2600))
     reads = []
@@ -426,7 +425,7 @@ def test_score_ranges_vs_oracle(za, oracle, dna):
             assert (int(got.score[i]), (int(got.query_start[i]), int(got.query_end[i])), (int(got.ref_start[i]), int(got.ref_end[i]))) == (s, rr, qr), i
 
 
-def test_full_size_10m_reads_properties(za, oracle, dna, monkeypatch):
+def test_full_size_10m_reads_properties(za, oracle, dna, debug):
     """BASELINE.json configs[1] at full size (10 M x 150 bp vs 2 kb), checked through size-independent properties:
     the two independent kernels (v1 saturating-i16, v2 drifted/max3) agree on every read, a second run is identical,
     shard-wise generation equals whole-batch generation, bounds hold, and a random sample equals the oracle."""
@@ -439,15 +438,15 @@ def test_full_size_10m_reads_properties(za, oracle, dna, monkeypatch):
     n = 10_000_000
     rb = synth.reads_device(ctx, ref, 0, n, 150)
     prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
-    monkeypatch.delenv("ZSW_SCORE_V1", raising=False)
+    debug.set(0)
     a = prof.sw_score_from_i8(ref)
     s2, st2, t2 = a.score.clone(), a.status.clone(), a.tier.clone()
     b = prof.sw_score_from_i8(ref)
     assert torch.equal(b.score, s2) and torch.equal(b.status, st2)  # deterministic
-    monkeypatch.setenv("ZSW_SCORE_V1", "1")
+    debug.set(debug.SCORE_V1)
     c = prof.sw_score_from_i8(ref)
     assert torch.equal(c.score, s2) and torch.equal(c.status, st2) and torch.equal(c.tier, t2)  # v1 == v2 on all 10 M reads
-    monkeypatch.delenv("ZSW_SCORE_V1", raising=False)
+    debug.set(0)
     # bounds: 0 <= score <= 2 * L; status Some <=> score > 0; tier 8 <=> score < 255
     assert int(s2.max()) <= 300 and int(s2.min()) >= 0
     assert torch.equal(st2 == 0, s2 > 0) and torch.equal(t2 == 8, s2 < 255)
@@ -497,10 +496,10 @@ def test_host_batch_pipeline_matches_device_batch(za, oracle, dna):
     torch.cuda.empty_cache()
 
 
-def test_long_reads_are_scored_tile_by_tile(za, oracle, dna, monkeypatch):
+def test_long_reads_are_scored_tile_by_tile(za, oracle, dna, debug):
     """Reads longer than the widest strip configuration (2,432 columns) run as several TILED launches of the packed kernel, the
     strip boundary of every reference row passing through HBM: score, ends and ranges must equal the oracle, for DNA and for
-    a 25-letter alphabet, in a ragged and in a fixed-length batch, and must equal the exact-kernel path (ZSW_NO_TILES)."""
+    a 25-letter alphabet, in a ragged and in a fixed-length batch, and must equal the exact-kernel path (ZSW_DEBUG_NO_TILES)."""
     rng = np.random.default_rng(77)
     alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
     R = 3500
@@ -555,15 +554,15 @@ def test_long_reads_are_scored_tile_by_tile(za, oracle, dna, monkeypatch):
         st, (s, re_, qe) = oracle.score_ends("i32", 8, psc, rd, pref)
         assert (int(gp.score[i]), int(gp.ref_end[i]), int(gp.query_end[i])) == (s, re_, qe), i
     # the exact-kernel path gives the same answers
-    monkeypatch.setenv("ZSW_NO_TILES", "1")
+    debug.set(debug.NO_TILES)
     ex = p.sw_score_ends(za.SeqSrc.Reference(ref))
     for name in ("score", "ref_end", "query_end", "status"):
         assert np.array_equal(getattr(ex, name).cpu().numpy(), getattr(ends, name).cpu().numpy()), name
 
 
-def test_scores_beyond_the_packed_range_use_the_32bit_tile_kernel(za, oracle, dna, monkeypatch):
+def test_scores_beyond_the_packed_range_use_the_32bit_tile_kernel(za, oracle, dna, debug):
     """A genome-sized read that matches the reference scores far above what the packed 16-bit kernels can hold (~28,000): the
-    packed pass puts it on the worklist and the 32-bit tile kernel (zsw_score_w32.hip) scores it — score, ends and the cascade tier identical to the oracle; ZSW_NO_W32 (exact
+    packed pass puts it on the worklist and the 32-bit tile kernel (zsw_score_w32.hip) scores it — score, ends and the cascade tier identical to the oracle; ZSW_DEBUG_NO_W32 (exact
     kernel) agrees."""
     rng = np.random.default_rng(123)
     alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -599,7 +598,7 @@ def test_scores_beyond_the_packed_range_use_the_32bit_tile_kernel(za, oracle, dn
         st, (s, re_, qe) = oracle.score_ends("i32", 8, sc2, rd, ref2)
         assert (int(w32.status[i]), int(w32.score[i]), int(w32.ref_end[i]), int(w32.query_end[i])) == (st, s, re_, qe), i
     assert int(w32.score[0]) == 60000
-    monkeypatch.setenv("ZSW_NO_W32", "1")
+    debug.set(debug.NO_W32)
     ex = p2.sw_score_ends(za.SeqSrc.Reference(ref2))
     for name in ("score", "ref_end", "query_end", "status"):
         assert np.array_equal(getattr(ex, name).cpu().numpy(), getattr(w32, name).cpu().numpy()), name

@@ -3,6 +3,8 @@ bit-exact status, score, ranges and CIGAR (including the reference's way of addi
 import numpy as np
 import pytest
 
+from conftest import stable_seed
+
 pytestmark = pytest.mark.gpu
 
 S_, O_, U_ = 0, 1, 2
@@ -40,7 +42,7 @@ def test_random_pairs_all_routes(za, oracle, scheme):
     ma, mi, go, ge = scheme
     m = za.WeightMatrix.new_dna_matrix(ma, mi, b"N")
     sc = osc(oracle, m, go, ge)
-    rng = np.random.default_rng(abs(hash(scheme)) % (2**32))
+    rng = np.random.default_rng(stable_seed(scheme))
     alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
     ref = bytes(rng.choice(alpha, 300))
     reads = []

@@ -250,6 +250,10 @@ class SwContext:
     def selftest(self):
         self.check(self.lib.zsw_selftest(self.h), profile_errors=False)
 
+    def debug_set(self, flags: int = 0):
+        """zsw_debug_set: kernel-selection overrides (_lib.DEBUG_*) for the parity tests; 0 restores the defaults."""
+        self.check(self.lib.zsw_debug_set(self.h, int(flags)))
+
     def timing_enable(self, on: bool):
         self.check(self.lib.zsw_timing_enable(self.h, int(on)))
 

@@ -23,147 +23,9 @@
 #include <type_traits>
 #include <vector>
 
-#include "zsw_align.hpp"
+#include "zsw_align_dev.hpp"
 
 namespace zsw {
-
-constexpr uint8_t BT_UP = 1, BT_UP_EXT = 2, BT_LEFT = 4, BT_LEFT_EXT = 8, BT_STOP = 16;  // backtrack.rs:18-34
-
-struct AlignArgs {
-    BatchDev b;
-    const uint8_t* ref;
-    uint32_t ref_len;
-    const ScoringDev* sc;
-    const uint32_t* score;    // pass-1 results, indexed by read id
-    const uint32_t* ref_end;  // exclusive end (r_end + 1)
-    const uint8_t* status;
-    uint32_t nv, W, maxc;
-    uint8_t* ring;           // [gridDim.x][64/N][W][nv][N] flag bytes
-    uint32_t* cig;           // ciglet pool of this launch: (inc << 8 | op) in traceback order, maxc slots per read
-    uint64_t pool_base;      // first pool slot of this launch
-    int by_item;             // slot = pool_base + (by_item ? item : read id) * maxc
-    uint64_t* cig_start;     // per read: device address of its first slot (pools differ between launches)
-    uint32_t* cig_raw;       // per read: ciglets written to the pool (traceback order)
-    zsw_alignment* aln;      // per read; n_ciglets = count after the optional inversion
-    uint32_t* fb_list;
-    uint32_t* fb_count;
-    int invert;
-    uint8_t* rows;  // GLOBAL_ROWS kernels: per-block H/E/profile/flag rows in HBM (null otherwise)
-    int debug;  // ZSW_ALIGN_DEBUG experiments: 1 = skip traceback, 2 = skip ring stores, 4 = no late start
-};
-
-// Late start of pass 2. The state after row r (the H and E rows) is a (max,+) function of earlier rows in which every
-// positive term is the score of an alignment path; a path that spans `span` reference rows has at most L diagonal steps and
-// at least span - L vertical gap steps, so its score is <= L*maxw - (span - L)*gap_extend and it is positive only while
-// span < L + L*maxw/gap_extend. Rows older than that bound cannot influence the rows whose flags are kept, so the recompute
-// may start that many rows before the first retained row with a zero state and still be bit-identical (gap_extend = 0: no
-// bound, start at row 0).
-__device__ __forceinline__ int warmup_rows(const int32_t* w, int S, int ge, int l_pad) {
-    if (ge <= 0) return 0x3fffffff;
-    int maxw = 0;
-    for (int i = 0; i < S * S; ++i) maxw = max(maxw, w[i]);
-    const long long b = (long long)l_pad + ((long long)l_pad * maxw) / ge + 2;
-    return b > 0x3fffffff ? 0x3fffffff : (int)b;
-}
-
-// bytes of one block's DP rows in the generic kernel: H, E (i32), residue codes and flags (u8) per vector and lane
-__host__ __device__ inline size_t align_rows_bytes(uint32_t nv) { return (size_t)nv * 64 * (4 + 4 + 1 + 1); }
-constexpr size_t ALIGN_LDS_LIMIT = 160 * 1024 - 9 * 1024;
-
-// max(a - b, 0) for non-negative a, b: one v_sub_u32 with clamp
-__device__ __forceinline__ int32_t subsat(int32_t a, int32_t b) {
-    return (int32_t)__builtin_elementwise_sub_sat((uint32_t)a, (uint32_t)b);
-}
-
-__device__ __forceinline__ uint32_t read_len(const BatchDev& b, uint32_t id, uint64_t* off) {
-    if (b.offsets) {
-        *off = b.offsets[id];
-        return (uint32_t)(b.offsets[id + 1] - *off);
-    }
-    *off = (uint64_t)id * b.fixed_len;
-    return b.fixed_len;
-}
-
-
-// BackTrackable::to_alignment (backtrack.rs:290-342) with AlignmentStates::add_ciglet merging (state.rs:142-152),
-// run by one lane per read. `cell(r, c)` returns the flag byte of DP cell (r, c) from the retained window.
-template <typename CellFn>
-__device__ __forceinline__ void traceback_emit(const AlignArgs& a, uint32_t id, uint32_t item, uint32_t len, int rend, int cend,
-                                               int32_t best, CellFn cell) {
-    const uint64_t slot0 = a.pool_base + (uint64_t)(a.by_item ? item : id) * a.maxc;
-    uint32_t* cig = a.cig + slot0;
-    uint32_t ncig = 0, cur_op = 0, cur_inc = 0;
-    bool overflow = cend == 0x7fffffff;
-    auto push = [&](uint32_t inc, uint32_t op) {
-        if (inc == 0) return;
-        if (cur_inc && cur_op == op) {
-            cur_inc += inc;
-            return;
-        }
-        if (cur_inc) {
-            if (ncig < a.maxc) cig[ncig] = (cur_inc << 8) | cur_op;
-            else overflow = true;
-            ++ncig;
-        }
-        cur_op = op;
-        cur_inc = inc;
-    };
-    const int r_end1 = rend + 1, c_end1 = cend + 1;
-    int r = r_end1, c = c_end1;
-    uint32_t n_nons = 0;  // ciglets that are not soft clips (for the inverted count)
-    if (!overflow) {
-        push(len - (uint32_t)c, 'S');
-        uint32_t f = cell(rend, cend);
-        uint32_t op = 0;
-        while (!(f & BT_STOP) && r > 0 && c > 0) {
-            if (op == 'D' && (f & BT_UP_EXT)) {
-                r -= 1;
-            } else if (op == 'I' && (f & BT_LEFT_EXT)) {
-                c -= 1;
-            } else if (f & BT_UP) {
-                op = 'D';
-                r -= 1;
-            } else if (f & BT_LEFT) {
-                op = 'I';
-                c -= 1;
-            } else {
-                op = 'M';
-                r -= 1;
-                c -= 1;
-            }
-            if (!(cur_inc && cur_op == op)) ++n_nons;
-            push(1, op);
-            if (r > 0 && c > 0) {
-                if (r - 1 + (int)a.W <= rend) {  // the walk left the retained window
-                    overflow = true;
-                    break;
-                }
-                f = cell(r - 1, c - 1);
-            }
-        }
-        push((uint32_t)c, 'S');
-        push(1, 0);  // flush the pending ciglet (the sentinel op 0 itself is never stored)
-    }
-    if (overflow || ncig > a.maxc) {
-        const uint32_t k = atomicAdd(a.fb_count, 1u);
-        a.fb_list[k] = id;
-    } else {
-        zsw_alignment out;
-        out.score = (uint32_t)best;
-        out.ref_start = (uint32_t)r;
-        out.ref_end = (uint32_t)r_end1;
-        out.query_start = (uint32_t)c;
-        out.query_end = (uint32_t)c_end1;
-        out.ref_len = a.ref_len;
-        out.query_len = len;
-        // forward count; inverted: clips re-derived from ref_range (output.rs:399-414)
-        out.n_ciglets = a.invert ? n_nons + (r > 0 ? 1u : 0u) + (a.ref_len > (uint32_t)r_end1 ? 1u : 0u) : ncig;
-        out.ciglet_offset = 0;  // filled by write_ciglets_kernel
-        a.aln[id] = out;
-        a.cig_start[id] = (uint64_t)(uintptr_t)cig;
-        a.cig_raw[id] = ncig;
-    }
-}
 
 // Generic form: any nv, DP rows in LDS — or, for profiles too long for one wavefront's LDS (nv above ~250), in a per-block
 // region of HBM behind the flag ring (GLOBAL_ROWS).
@@ -219,7 +81,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
             rmax = max(rmax, __shfl_xor(rmax, d, 64));
             rmin = min(rmin, __shfl_xor(rmin, d, 64));
         }
-        const int r0 = (a.debug & 4) ? 0 : max(0, (int)min((long long)rmin - (long long)a.W - warm, (long long)rmax));
+        const int r0 = max(0, (int)min((long long)rmin - (long long)a.W - warm, (long long)rmax));
 
         for (int r = r0; r <= rmax; ++r) {
             const bool act = r <= rend;
@@ -410,7 +272,7 @@ __global__ __launch_bounds__(64) void align_kernel_x(AlignArgs a) {
         const int rmax = __builtin_amdgcn_readfirstlane(rmax_v);
         const int rmin = __builtin_amdgcn_readfirstlane(rmin_v);
         const int rflag = (int)max(0ll, (long long)rmin - W + 1);  // first row whose flags some read of the wave keeps
-        const int r0 = (a.debug & 4) ? 0 : (int)max(0ll, min((long long)rmin - (long long)W - warm, (long long)rmax));
+        const int r0 = (int)max(0ll, min((long long)rmin - (long long)W - warm, (long long)rmax));
 
         uint32_t pn[NVQ];  // profile dwords of the row about to run
 
@@ -515,7 +377,7 @@ __global__ __launch_bounds__(64) void align_kernel_x(AlignArgs a) {
             }
             if constexpr (FLAGS) {
                 // keep the last W rows of flags of every read still running
-                if (act && r + W > rend && !(a.debug & 2)) {
+                if (act && r + W > rend) {
                     uint32_t* dst = reinterpret_cast<uint32_t*>(ring + (size_t)(r % W) * row_bytes) + (size_t)li * NVQ;
 #pragma unroll
                     for (int vq = 0; vq < NVQ; ++vq)
@@ -559,7 +421,7 @@ __global__ __launch_bounds__(64) void align_kernel_x(AlignArgs a) {
         for (int d = 1; d < N; d <<= 1) cend = min(cend, __shfl_xor(cend, d, N));
         __threadfence_block();  // this wave's ring stores are visible to its own traceback loads
 
-        if (active && li == 0 && !(a.debug & 1)) {
+        if (active && li == 0) {
             auto cell = [&](int rr, int cc) -> uint32_t {
                 return __hip_atomic_load(ring + (size_t)(rr % W) * row_bytes + (size_t)(cc / nv) * (size_t)NVQ * 4 + (size_t)(cc % nv),
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -757,7 +619,6 @@ hipError_t align_pass2(int N, uint32_t nv, const BatchDev& b, const uint8_t* d_r
     a.fb_list = d_fb_list;
     a.fb_count = d_fb_count;
     a.invert = invert;
-    a.debug = getenv("ZSW_ALIGN_DEBUG") ? atoi(getenv("ZSW_ALIGN_DEBUG")) : 0;
     // profiles too long for LDS keep their rows behind the ring (align_ring_bytes reserves the space)
     a.rows = (nv > 32 && align_rows_bytes(nv) > ALIGN_LDS_LIMIT) ? d_ring + align_ring_only_bytes(N, nv, W, grid) : nullptr;
     return run_group(N, a, S, grid, stream);
@@ -772,6 +633,76 @@ size_t align_ring_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid) {
     if (nv > 32 && align_rows_bytes(nv) > ALIGN_LDS_LIMIT) bytes += (size_t)grid * align_rows_bytes(nv);
     return bytes;
 }
+// ---- packed kernel (zsw_align_pk{8,16,32,64}.hip) ----
+hipError_t align_pk_occupancy_8(uint32_t nv, size_t lds, int* blocks_per_cu);
+hipError_t align_pk_occupancy_16(uint32_t nv, size_t lds, int* blocks_per_cu);
+hipError_t align_pk_occupancy_32(uint32_t nv, size_t lds, int* blocks_per_cu);
+hipError_t align_pk_occupancy_64(uint32_t nv, size_t lds, int* blocks_per_cu);
+hipError_t align_pk_launch_8(const AlignArgs& a, uint32_t grid, size_t lds, hipStream_t stream);
+hipError_t align_pk_launch_16(const AlignArgs& a, uint32_t grid, size_t lds, hipStream_t stream);
+hipError_t align_pk_launch_32(const AlignArgs& a, uint32_t grid, size_t lds, hipStream_t stream);
+hipError_t align_pk_launch_64(const AlignArgs& a, uint32_t grid, size_t lds, hipStream_t stream);
+
+static size_t align_pk_lds(uint32_t nv, int S) { return (size_t)S * nv * 64 * 4; }
+
+bool align_pk_supported(int N, uint32_t nv, int S) {
+    // at least two wavefronts' profiles per CU
+    return (N == 8 || N == 16 || N == 32 || N == 64) && nv >= 1 && nv <= 16 && align_pk_lds(nv, S) <= 72 * 1024;
+}
+
+uint32_t align_pk_grid(int N, uint32_t nv, int S, uint32_t count, uint32_t cu_count) {
+    const uint32_t rpw = 2 * 64 / (uint32_t)N;
+    const uint32_t items = (count + rpw - 1) / rpw;
+    int per_cu = 0;
+    const size_t lds = align_pk_lds(nv, S);
+    hipError_t e = N == 8 ? align_pk_occupancy_8(nv, lds, &per_cu) : N == 16 ? align_pk_occupancy_16(nv, lds, &per_cu)
+                 : N == 32 ? align_pk_occupancy_32(nv, lds, &per_cu) : align_pk_occupancy_64(nv, lds, &per_cu);
+    if (e != hipSuccess || per_cu < 1) per_cu = 4;
+    return std::max<uint32_t>(1u, std::min<uint32_t>(items, cu_count * (uint32_t)per_cu));
+}
+
+size_t align_pk_ring_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid) {
+    const size_t row = (size_t)N * ((nv + 3) / 4) * 4;
+    return ((size_t)grid * (2 * 64 / (size_t)N) * (size_t)W * row + 255) / 256 * 256;
+}
+
+hipError_t align_pass2_pk(int N, uint32_t nv, const BatchDev& b, const uint8_t* d_ref, uint32_t ref_len, const ScoringDev* d_sc,
+                          int S, const uint32_t* d_score, const uint32_t* d_ref_end, const uint8_t* d_status, uint32_t W,
+                          uint32_t maxc, uint8_t* d_ring, uint32_t grid, uint32_t* d_cig, uint64_t pool_base, int by_item,
+                          uint64_t* d_cig_start, uint32_t* d_cig_raw, zsw_alignment* d_aln, uint32_t* d_fb_list,
+                          uint32_t* d_fb_count, int invert, hipStream_t stream) {
+    AlignArgs a;
+    a.b = b;
+    a.ref = d_ref;
+    a.ref_len = ref_len;
+    a.sc = d_sc;
+    a.score = d_score;
+    a.ref_end = d_ref_end;
+    a.status = d_status;
+    a.nv = nv;
+    a.W = W;
+    a.maxc = maxc;
+    a.ring = d_ring;
+    a.cig = d_cig;
+    a.pool_base = pool_base;
+    a.by_item = by_item;
+    a.cig_start = d_cig_start;
+    a.cig_raw = d_cig_raw;
+    a.aln = d_aln;
+    a.fb_list = d_fb_list;
+    a.fb_count = d_fb_count;
+    a.invert = invert;
+    a.rows = nullptr;
+    const size_t lds = align_pk_lds(nv, S);
+    switch (N) {
+        case 8: return align_pk_launch_8(a, grid, lds, stream);
+        case 16: return align_pk_launch_16(a, grid, lds, stream);
+        case 32: return align_pk_launch_32(a, grid, lds, stream);
+        case 64: return align_pk_launch_64(a, grid, lds, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
 size_t align_lds_need(uint32_t nv, int S) {
     if (nv <= 32) return align_lds_bytes_reg(nv, S);
     return align_lds_bytes(nv, S) > ALIGN_LDS_LIMIT ? 0 : align_lds_bytes(nv, S);  // 0: the rows live in HBM

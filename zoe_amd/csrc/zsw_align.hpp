@@ -17,10 +17,22 @@ hipError_t align_finalize(zsw_alignment* d_aln, const uint8_t* d_status, uint32_
                           uint64_t* d_total, const uint64_t* d_cig_start, const uint32_t* d_cig_raw, int invert,
                           uint32_t* out_inc, uint8_t* out_op, uint64_t cap, bool count_only, hipStream_t stream);
 
-// Device-side grouping (zsw_group.hip): read ids sorted by (N, nv, ref_end) + the table of group starts.
+// The packed kernel (zsw_align_pk_kernel.hpp): two reads per lane group in 16-bit halves. It takes groups of 8..64 lanes and
+// up to 16 vectors whose striped profile fits LDS, and reads whose score leaves head-room below 2^15 for Y = H - go + v*ge.
+constexpr uint32_t ALIGN_PK_MAX_SCORE = 30000;
+bool align_pk_supported(int N, uint32_t nv, int S);
+uint32_t align_pk_grid(int N, uint32_t nv, int S, uint32_t count, uint32_t cu_count);  // blocks that fill the chip once
+size_t align_pk_ring_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid);
+hipError_t align_pass2_pk(int N, uint32_t nv, const BatchDev& b, const uint8_t* d_ref, uint32_t ref_len, const ScoringDev* d_sc,
+                          int S, const uint32_t* d_score, const uint32_t* d_ref_end, const uint8_t* d_status, uint32_t W,
+                          uint32_t maxc, uint8_t* d_ring, uint32_t grid, uint32_t* d_cig, uint64_t pool_base, int by_item,
+                          uint64_t* d_cig_start, uint32_t* d_cig_raw, zsw_alignment* d_aln, uint32_t* d_fb_list,
+                          uint32_t* d_fb_count, int invert, hipStream_t stream);
+
+// Device-side grouping (zsw_group.hip): read ids sorted by (N, packed/wide, nv, ref_end) + the table of group starts.
 size_t group_temp_bytes(uint32_t n);
-hipError_t group_reads(const BatchDev& b, const uint8_t* d_status, const uint8_t* d_tier, const uint32_t* d_ref_end, int lanes_w8,
-                       int lanes_w16, int lanes_w32, uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* items_out,
+hipError_t group_reads(const BatchDev& b, const uint8_t* d_status, const uint8_t* d_tier, const uint32_t* d_ref_end, const uint32_t* d_score,
+                       int lanes_w8, int lanes_w16, int lanes_w32, uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* items_out,
                        void* temp, size_t temp_bytes, uint32_t* table, uint32_t* table_count, uint32_t cap, hipStream_t stream);
 
 // Third pass of sw_align_3pass (zsw_threepass.hip). list == null: classify pass over all reads (resolves the no-gaps

@@ -42,6 +42,7 @@ struct DevBuf {
 
 struct zsw_context {
     int device = 0;
+    uint32_t cu_count = 256;
     bool scoring_set = false, reference_set = false;
     ScoringDev h_sc{};
     int bias = 0;
@@ -56,6 +57,7 @@ struct zsw_context {
     DevBuf r_ws[20];
     KernelTimer timer;
     std::string err;
+    uint32_t debug = 0;  // zsw_debug_set
     // host batches: reads of chunk k+1 cross PCIe on this stream while chunk k computes
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> copy_events;
@@ -271,6 +273,7 @@ ScoreWorkspace score_ws(zsw_context* ctx) {
     w.tile_bytes = ctx->d_tile_buf.cap / 16 * 16;
     w.tile_state = ctx->d_tile_state.as<uint4>();
     w.side = ctx->side;
+    w.debug = ctx->debug;
     return w;
 }
 
@@ -295,7 +298,7 @@ zsw_error run_score(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     Staged st;
     // fixed-length host batches of more than one chunk: the H2D copy of chunk k+1 overlaps the kernel of chunk k
     const bool pipelined = reads && reads->mem == ZSW_MEM_HOST && !reads->offsets && reads->fixed_len > 0 &&
-                           reads->n_reads > PIPE_CHUNK && !getenv("ZSW_NO_PIPELINE");
+                           reads->n_reads > PIPE_CHUNK && !(ctx && (ctx->debug & ZSW_DEBUG_NO_PIPELINE));
     zsw_error ze = stage(ctx, reads, stream, out_tier != nullptr, want_ends, out_score, out_status, out_tier, out_rend,
                          out_qend, &st, pipelined);
     if (ze != ZSW_OK) return ze;
@@ -564,6 +567,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     struct GroupRun {
         int N;
         uint32_t nv, start, count;
+        bool wide;  // scores beyond the packed kernel's 16-bit lanes
     };
     const uint32_t TABLE_CAP = 1u << 16;
     ZSW_HIP(ctx, ws[WS_ITEMS].ensure((size_t)n * 4 + 4));
@@ -573,7 +577,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     const size_t sort_bytes = group_temp_bytes(n);
     ZSW_HIP(ctx, ws[WS_SORT_TMP].ensure(sort_bytes + 256));
     ZSW_HIP(ctx, ws[WS_GTABLE].ensure((size_t)TABLE_CAP * 8 + 8));
-    e = group_reads(st.b, so.status, so.tier, so.ref_end, lanes_w8, lanes_w16, lanes_w32, ws[WS_KEYS_IN].as<uint64_t>(),
+    e = group_reads(st.b, so.status, so.tier, so.ref_end, so.score, lanes_w8, lanes_w16, lanes_w32, ws[WS_KEYS_IN].as<uint64_t>(),
                     ws[WS_KEYS_OUT].as<uint64_t>(), ws[WS_VALS_IN].as<uint32_t>(), ws[WS_ITEMS].as<uint32_t>(), ws[WS_SORT_TMP].p,
                     sort_bytes, ws[WS_GTABLE].as<uint32_t>() + 2, ws[WS_GTABLE].as<uint32_t>(), TABLE_CAP - 1, stream);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align grouping", e);
@@ -588,7 +592,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     {
         // sort the table by start (atomic slots are unordered) and derive the counts; the last group ends where the reads
         // without an alignment (key ~0) begin, i.e. at the number of SOME statuses (counted on the device)
-        std::vector<std::pair<uint32_t, uint32_t>> t;  // (start, N<<24|nv)
+        std::vector<std::pair<uint32_t, uint32_t>> t;  // (start, N<<24 | wide<<23 | nv)
         for (uint32_t k = 0; k < n_groups; ++k) t.emplace_back(h_table[2 * k + 1], h_table[2 * k]);
         std::sort(t.begin(), t.end());
         if (!t.empty()) {
@@ -600,7 +604,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
         }
         for (size_t k = 0; k < t.size(); ++k) {
             const uint32_t end = k + 1 < t.size() ? t[k + 1].first : n_some;
-            groups.push_back(GroupRun{(int)(t[k].second >> 24), t[k].second & 0xffffffu, t[k].first, end - t[k].first});
+            groups.push_back(GroupRun{(int)(t[k].second >> 24), t[k].second & 0x7fffffu, t[k].first, end - t[k].first, ((t[k].second >> 23) & 1u) != 0});
         }
     }
     const int S = ctx->h_sc.S;
@@ -622,10 +626,23 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
         uint32_t W = full ? (uint32_t)ctx->ref_len : std::min<uint32_t>((uint32_t)ctx->ref_len, lpad + std::max<uint32_t>(32, lpad / 4));
         return W ? W : 1u;
     };
+    // the packed kernel (two reads per lane group, zsw_align_pk_kernel.hpp) answers the groups it covers; the 32-bit kernels
+    // take scores beyond 16-bit lanes, more than 16 vectors, large alphabets and the full-window reruns
+    auto packed = [&](const GroupRun& g, bool full) {
+        return !full && !g.wide && !(ctx->debug & ZSW_DEBUG_ALIGN_NO_PACKED) && align_pk_supported(g.N, g.nv, S);
+    };
+    auto ring_bytes_of = [&](const GroupRun& g, bool full, uint32_t grid) {
+        return packed(g, full) ? align_pk_ring_bytes(g.N, g.nv, window_of(g, full), grid) : align_ring_bytes(g.N, g.nv, window_of(g, full), grid);
+    };
     auto grid_of = [&](const GroupRun& g, bool full) {
-        const uint32_t rpw = 64 / (uint32_t)g.N;
-        uint32_t grid = std::min<uint32_t>((g.count + rpw - 1) / rpw, full ? 256u : 4096u);
-        while (grid > 1 && align_ring_bytes(g.N, g.nv, window_of(g, full), grid) > (size_t(3) << 30)) grid /= 2;
+        uint32_t grid;
+        if (packed(g, full)) {
+            grid = align_pk_grid(g.N, g.nv, S, g.count, ctx->cu_count);
+        } else {
+            const uint32_t rpw = 64 / (uint32_t)g.N;
+            grid = std::min<uint32_t>((g.count + rpw - 1) / rpw, full ? 256u : 4096u);
+        }
+        while (grid > 1 && ring_bytes_of(g, full, grid) > (size_t(3) << 30)) grid /= 2;
         return grid;
     };
     // one ring per pass, shared by its launches (they run in order on one stream): size it for the largest group up front
@@ -634,7 +651,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
         size_t ring_need = 0;
         uint64_t pool_need = 0;
         for (auto& g : gs) {
-            ring_need = std::max(ring_need, align_ring_bytes(g.N, g.nv, window_of(g, full), grid_of(g, full)));
+            ring_need = std::max(ring_need, ring_bytes_of(g, full, grid_of(g, full)));
             pool_need += (uint64_t)g.count * ((uint64_t)g.N * g.nv + ctx->ref_len + 4);
         }
         ZSW_HIP(ctx, ringbuf.ensure(ring_need + 64));
@@ -646,7 +663,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
             BatchDev b = st.b;
             b.items = d_items + g.start;
             b.n_items = g.count;
-            hipError_t he = align_pass2(g.N, g.nv, b, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len, ctx->d_sc.as<ScoringDev>(), S,
+            hipError_t he = (packed(g, full) ? align_pass2_pk : align_pass2)(g.N, g.nv, b, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len, ctx->d_sc.as<ScoringDev>(), S,
                                         so.score, so.ref_end, so.status, W, maxc, ringbuf.as<uint8_t>(), grid_of(g, full),
                                         cigbuf.as<uint32_t>(), pool, full ? 1 : 0, ws[WS_CIGSTART].as<uint64_t>(),
                                         ws[WS_CIGRAW].as<uint32_t>(), ws[WS_ALN].as<zsw_alignment>(),
@@ -681,7 +698,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
         std::vector<uint32_t> ids;
         std::vector<GroupRun> runs;
         for (auto& g : g2) {
-            runs.push_back(GroupRun{g.first.first, g.first.second, (uint32_t)ids.size(), (uint32_t)g.second.size()});
+            runs.push_back(GroupRun{g.first.first, g.first.second, (uint32_t)ids.size(), (uint32_t)g.second.size(), true});
             ids.insert(ids.end(), g.second.begin(), g.second.end());
         }
         ZSW_HIP(ctx, ws[WS_ITEMS2].ensure(ids.size() * 4 + 4));
@@ -884,6 +901,7 @@ zsw_error zsw_create(int device_id, zsw_context** out) {
     zsw_context* c = new (std::nothrow) zsw_context();
     if (!c) return ZSW_ERR_INVALID_ARGUMENT;
     c->device = device_id;
+    c->cu_count = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     *out = c;
     return ZSW_OK;
 }
@@ -1137,6 +1155,12 @@ zsw_error zsw_selftest(zsw_context* ctx) {
         if (h[192 + l] != (uint32_t)(((uint32_t)(uint16_t)(int16_t)31000 << 16) | (uint16_t)(int16_t)-31000))
             return fail(ctx, ZSW_ERR_HIP, "selftest: packed saturating sub");
     }
+    return ZSW_OK;
+}
+
+zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    ctx->debug = flags;
     return ZSW_OK;
 }
 

@@ -10,8 +10,8 @@
 
 namespace zsw {
 
-__global__ void group_keys_kernel(BatchDev b, const uint8_t* status, const uint8_t* tier, const uint32_t* ref_end, int lanes_w8,
-                                  int lanes_w16, int lanes_w32, uint64_t* keys, uint32_t* vals) {
+__global__ void group_keys_kernel(BatchDev b, const uint8_t* status, const uint8_t* tier, const uint32_t* ref_end, const uint32_t* score,
+                                  int lanes_w8, int lanes_w16, int lanes_w32, uint64_t* keys, uint32_t* vals) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.n_reads) return;
     uint64_t key = ~0ull;  // reads without an alignment sort to the end
@@ -19,7 +19,9 @@ __global__ void group_keys_kernel(BatchDev b, const uint8_t* status, const uint8
         const uint32_t len = b.offsets ? (uint32_t)(b.offsets[i + 1] - b.offsets[i]) : b.fixed_len;
         const uint32_t N = tier[i] == 8 ? lanes_w8 : tier[i] == 16 ? lanes_w16 : lanes_w32;
         const uint32_t nv = (len + N - 1) / N;
-        key = ((uint64_t)N << 56) | ((uint64_t)(nv & 0xffffffu) << 32) | ref_end[i];
+        // bit 55: the score does not fit the packed kernel's 16-bit lanes (its reads form a group of their own)
+        const uint64_t wide = score[i] > ALIGN_PK_MAX_SCORE ? 1u : 0u;
+        key = ((uint64_t)N << 56) | (wide << 55) | ((uint64_t)(nv & 0x7fffffu) << 32) | ref_end[i];
     }
     keys[i] = key;
     vals[i] = i;
@@ -34,7 +36,7 @@ __global__ void group_bounds_kernel(const uint64_t* sorted_keys, uint32_t n, uin
     if (j == 0 || (uint32_t)(sorted_keys[j - 1] >> 32) != g) {
         const uint32_t slot = atomicAdd(table_count, 1u);
         if (slot < cap) {
-            table[2 * slot] = g;      // N << 24 | nv
+            table[2 * slot] = g;      // N << 24 | wide << 23 | nv
             table[2 * slot + 1] = j;  // first position of the group in the sorted order
         }
     }
@@ -48,14 +50,14 @@ size_t group_temp_bytes(uint32_t n) {
 }
 
 // keys_in/keys_out: n u64 each; vals_in: n u32; items_out: n u32 (sorted read ids); table: 2*cap u32; table_count: 1 u32.
-hipError_t group_reads(const BatchDev& b, const uint8_t* d_status, const uint8_t* d_tier, const uint32_t* d_ref_end, int lanes_w8,
-                       int lanes_w16, int lanes_w32, uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* items_out,
+hipError_t group_reads(const BatchDev& b, const uint8_t* d_status, const uint8_t* d_tier, const uint32_t* d_ref_end, const uint32_t* d_score,
+                       int lanes_w8, int lanes_w16, int lanes_w32, uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* items_out,
                        void* temp, size_t temp_bytes, uint32_t* table, uint32_t* table_count, uint32_t cap, hipStream_t stream) {
     const uint32_t n = b.n_reads;
     if (n == 0) return hipSuccess;
     const uint32_t grid = (n + 255) / 256;
-    hipLaunchKernelGGL(group_keys_kernel, dim3(grid), dim3(256), 0, stream, b, d_status, d_tier, d_ref_end, lanes_w8, lanes_w16,
-                       lanes_w32, keys_in, vals_in);
+    hipLaunchKernelGGL(group_keys_kernel, dim3(grid), dim3(256), 0, stream, b, d_status, d_tier, d_ref_end, d_score, lanes_w8,
+                       lanes_w16, lanes_w32, keys_in, vals_in);
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, items_out, (int)n, 0, 64, stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(table_count, 0, 4, stream);

@@ -88,6 +88,7 @@ struct ScoreWorkspace {
     size_t tile_bytes = 0;
     uint4* tile_state = nullptr;
     SideStreams* side = nullptr;  // null: the length classes run one after the other on the caller's stream
+    uint32_t debug = 0;           // ZSW_DEBUG_* bits of the context (zsw_debug_set): kernel-selection overrides for tests
 };
 
 hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,

@@ -241,8 +241,8 @@ static hipError_t launch_table_cfg_v2(const ScoreArgsV2& a, int G, int C, int mo
 }
 
 // v2 needs: S <= 7; for query residues 0..3: s + ge in [-128, 127]; for residues >= 4: s + ge in [0, 255].
-static bool v2_ok(const ScoringDev& s) {
-    if (getenv("ZSW_SCORE_V1")) return false;
+static bool v2_ok(const ScoringDev& s, uint32_t debug) {
+    if (debug & ZSW_DEBUG_SCORE_V1) return false;
     if (s.S > 7) return false;
     for (int r = 0; r < s.S; ++r)
         for (int q = 0; q < s.S; ++q) {
@@ -286,8 +286,8 @@ static bool build_tables_v2(const ScoringDev& s, int G, ScoreArgsV2* a) {
 }
 
 // WIDE kernels: 8..32 letters, every score + ge must fit a signed byte.
-static bool wide_ok(const ScoringDev& s) {
-    if (getenv("ZSW_SCORE_NO_WIDE")) return false;
+static bool wide_ok(const ScoringDev& s, uint32_t debug) {
+    if (debug & ZSW_DEBUG_NO_WIDE) return false;
     if (s.S <= 7 || s.S > 32) return false;
     for (int i = 0; i < s.S * s.S; ++i) {
         const int t = s.w[i] + s.gap_extend;
@@ -310,8 +310,8 @@ static bool build_tables_wide(const ScoringDev& s, int G, ScoreArgsV2* a) {
 
 // The 32-bit tile kernel takes any alphabet of up to 32 letters whose weights + gap_extend fit a signed byte, as long as the
 // drifted values stay inside an i32 for this reference and read length.
-static bool w32_ok(const ScoringDev& s, uint32_t ref_len, uint32_t max_len) {
-    if (getenv("ZSW_NO_W32") || s.S > 32) return false;
+static bool w32_ok(const ScoringDev& s, uint32_t ref_len, uint32_t max_len, uint32_t debug) {
+    if ((debug & ZSW_DEBUG_NO_W32) || s.S > 32) return false;
     int maxw = 0;
     for (int i = 0; i < s.S * s.S; ++i) {
         const int t = s.w[i] + s.gap_extend;
@@ -380,7 +380,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     hipError_t e = hipMemsetAsync(out.fb_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     int G = 0, C = 0;
-    const bool wide = wide_ok(h_sc);
+    const bool wide = wide_ok(h_sc, ws.debug);
     const bool table_ok = h_sc.S <= 7 || fast_ok(h_sc) || wide;
     const uint32_t exact_grid = (uint32_t)(ws.slots / 64);
     ScoreArgs a;
@@ -396,7 +396,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     a.gtab = nullptr;
     const bool fast = fast_ok(h_sc);
     if (table_ok && !wide) build_tables(h_sc, fast, &a);
-    const bool use_v2 = table_ok && !wide && v2_ok(h_sc);
+    const bool use_v2 = table_ok && !wide && v2_ok(h_sc, ws.debug);
     ScoreArgsV2 a2;
     a2.b = b;
     a2.ref = d_ref;
@@ -432,7 +432,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     // reference row handed from tile to tile through HBM, as many reads per round as the boundary buffers hold.
     // Returns hipErrorNotSupported when the packed kernels cannot take the batch (the caller then uses the exact kernel).
     auto launch_tiled = [&](const BatchDev& bb, uint32_t longest) -> hipError_t {
-        if (!ws.tile_buf || !ws.tile_state || !bb.items || getenv("ZSW_NO_TILES")) return hipErrorNotSupported;
+        if (!ws.tile_buf || !ws.tile_state || !bb.items || (ws.debug & ZSW_DEBUG_NO_TILES)) return hipErrorNotSupported;
         if (!(wide || use_v2)) return hipErrorNotSupported;
         if (!(wide ? build_tables_wide(h_sc, TILE_G, &a2) : build_tables_v2(h_sc, TILE_G, &a2))) return hipErrorNotSupported;
         const size_t per_pair = (size_t)ref_len * sizeof(uint2);
@@ -463,7 +463,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     auto finish_worklist = [&]() -> hipError_t {
         int maxw = 1;
         for (int i = 0; i < h_sc.S * h_sc.S; ++i) maxw = std::max(maxw, (int)h_sc.w[i]);
-        if ((uint64_t)max_len * (uint64_t)maxw >= 16384 && ws.tile_buf && ws.tile_state && w32_ok(h_sc, ref_len, max_len)) {
+        if ((uint64_t)max_len * (uint64_t)maxw >= 16384 && ws.tile_buf && ws.tile_state && w32_ok(h_sc, ref_len, max_len, ws.debug)) {
             uint32_t cnt = 0;
             hipError_t we = hipMemcpyAsync(&cnt, out.fb_count, sizeof(cnt), hipMemcpyDeviceToHost, stream);
             if (we == hipSuccess) we = hipStreamSynchronize(stream);
@@ -533,7 +533,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         // The length classes are independent launches and the small ones cannot fill the chip on their own (a class of
         // 70 k reads is two wavefronts per SIMD): they are spread over side streams, forked from and joined to `stream`.
         SideStreams* side = ws.side;  // owned by the context: two contexts never share fork/join events
-        const bool fork = side != nullptr && !getenv("ZSW_NO_SIDE_STREAMS");
+        const bool fork = side != nullptr && !(ws.debug & ZSW_DEBUG_NO_SIDE_STREAMS);
         if (fork) {
             e = hipEventRecord(side->fork, stream);
             if (e != hipSuccess) return e;
@@ -621,9 +621,9 @@ hipError_t launch_score_rev(const ScoringDev* d_sc, const ScoringDev& h_sc, cons
     if (e != hipSuccess) return e;
     const uint32_t exact_grid = (uint32_t)(ws.slots / 64);
     int G = 0, C = 0;
-    const bool wide = wide_ok(h_sc);
+    const bool wide = wide_ok(h_sc, ws.debug);
     const bool table_ok = (h_sc.S <= 7 || fast_ok(h_sc) || wide) && score_config_for(max_len, &G, &C);
-    if (!score_config_for(max_len, &G, &C) && ws.tile_buf && ws.tile_state && ws.bucket_items && w32_ok(h_sc, ref_len, max_len) && b.n_items) {
+    if (!score_config_for(max_len, &G, &C) && ws.tile_buf && ws.tile_state && ws.bucket_items && w32_ok(h_sc, ref_len, max_len, ws.debug) && b.n_items) {
         // reads longer than every strip configuration: the 32-bit tile kernel over the reversed reference (held in d_gtab's bytes)
         uint8_t* d_rev = reinterpret_cast<uint8_t*>(d_gtab);
         if (ref_len) hipLaunchKernelGGL(reverse_bytes_kernel, dim3((ref_len + 255) / 256), dim3(256), 0, stream, d_ref, ref_len, d_rev);
