@@ -643,7 +643,7 @@ hipError_t align_pk_launch_16(const AlignArgs& a, uint32_t grid, size_t lds, hip
 hipError_t align_pk_launch_32(const AlignArgs& a, uint32_t grid, size_t lds, hipStream_t stream);
 hipError_t align_pk_launch_64(const AlignArgs& a, uint32_t grid, size_t lds, hipStream_t stream);
 
-static size_t align_pk_lds(uint32_t nv, int S) { return (size_t)S * nv * 64 * 4; }
+static size_t align_pk_lds(uint32_t nv, int S) { return (size_t)S * nv * 64 * 4 + (((size_t)S * S + 15) / 16) * 16; }
 
 bool align_pk_supported(int N, uint32_t nv, int S) {
     // at least two wavefronts' profiles per CU
@@ -693,6 +693,9 @@ hipError_t align_pass2_pk(int N, uint32_t nv, const BatchDev& b, const uint8_t* 
     a.fb_count = d_fb_count;
     a.invert = invert;
     a.rows = nullptr;
+    a.next_item = d_fb_count + 1;  // the word after the fallback counter (the caller zeroes both)
+    hipError_t ce = hipMemsetAsync(a.next_item, 0, 4, stream);
+    if (ce != hipSuccess) return ce;
     const size_t lds = align_pk_lds(nv, S);
     switch (N) {
         case 8: return align_pk_launch_8(a, grid, lds, stream);

@@ -28,6 +28,7 @@ struct AlignArgs {
     uint32_t* fb_count;
     int invert;
     uint8_t* rows;  // GLOBAL_ROWS kernels: per-block H/E/profile/flag rows in HBM (null otherwise)
+    uint32_t* next_item;  // packed kernel: work counter (zeroed before the launch); a wavefront takes its next reads from it
 };
 
 // Late start of pass 2. The state after row r (the H and E rows) is a (max,+) function of earlier rows in which every

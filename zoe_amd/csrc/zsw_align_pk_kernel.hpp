@@ -89,15 +89,15 @@ __global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
     using O = DevOps;
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ uint8_t lut[256];
-    __shared__ int32_t wsh[MAX_S * MAX_S];
     constexpr int RPW = 2 * 64 / N;
     constexpr int NVQ = (NV + 3) / 4;
     const int lane = threadIdx.x;
     const int li = lane % N, grp = lane / N;
     const int S = a.sc->S;
     uint32_t* prof2 = reinterpret_cast<uint32_t*>(smem);  // [S][NV][64]: the two reads' scores of (residue, vector, lane)
+    int8_t* wsh = reinterpret_cast<int8_t*>(prof2 + (size_t)S * NV * 64);  // [S][S] weights (i8, as in WeightMatrix<i8, S>)
     for (int i = lane; i < 256; i += 64) lut[i] = a.sc->index_map[i];
-    for (int i = lane; i < S * S; i += 64) wsh[i] = a.sc->w[i];
+    for (int i = lane; i < S * S; i += 64) wsh[i] = (int8_t)a.sc->w[i];
     __syncthreads();
     zsw_pk::Consts<O, NV> c;
     c.ge = (uint32_t)a.sc->gap_extend;
@@ -106,12 +106,18 @@ __global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
     c.nvge2 = (uint32_t)NV * c.ge * zsw_pk::ONE2;
     c.keep = li == 0 ? 0u : ~0u;
     asm volatile("v_mov_b32 %0, 0x10001" : "=v"(c.one));
-    const long long warm = warmup_rows(wsh, S, (int)c.ge, NV * N);
+    const long long warm = warmup_rows(a.sc->w, S, (int)c.ge, NV * N);
     const size_t row_bytes = (size_t)N * NVQ * 4;
     const int W = (int)a.W;
     const uint32_t* plane = prof2 + lane;
 
-    for (uint32_t first = blockIdx.x * RPW; first < a.b.n_items; first += gridDim.x * RPW) {
+    // Reads are handed out through a counter: the rows a read costs vary with its r_end, and a CU holds a number of
+    // wavefronts that need not be a multiple of its four SIMDs, so a fixed share per wavefront would leave SIMDs idle.
+    for (;;) {
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(a.next_item, (uint32_t)RPW);
+        first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+        if (first >= a.b.n_items) break;  // every wavefront gets here: the counter only grows
         // this lane group's two reads (halves 0 and 1 of every lane value)
         uint32_t id[2], len[2], item[2];
         uint64_t off[2];
@@ -163,14 +169,16 @@ __global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
 
         auto do_row = [&](const int r, const uint32_t next_off, auto flags_tag) __attribute__((always_inline)) {
             constexpr bool FLAGS = decltype(flags_tag)::value;
-            uint32_t flg[NV];
-            auto next_row = [&]() __attribute__((always_inline)) {
+            uint32_t pc[NV], flg[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) pc[v] = p[v];
+            {  // the next row's profile dwords travel while this row computes
                 const uint32_t* nrow = plane + next_off;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) p[v] = nrow[v * 64];
-            };
+            }
             const uint32_t act2 = (r <= rend[0] ? 0xffffu : 0u) | (r <= rend[1] ? 0xffff0000u : 0u);
-            zsw_pk::row<O, N, NV, FLAGS>(st, p, act2, c, flg, next_row);
+            zsw_pk::row<O, N, NV, FLAGS>(st, pc, act2, c, flg, [] {});
             if constexpr (FLAGS) {
                 // one byte per cell and read: bytes 4*vq .. 4*vq+3 of the lane's row slice
                 uint32_t d0[NVQ], d1[NVQ], fp[NVQ * 4];

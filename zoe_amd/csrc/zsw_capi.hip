@@ -596,7 +596,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
         for (uint32_t k = 0; k < n_groups; ++k) t.emplace_back(h_table[2 * k + 1], h_table[2 * k]);
         std::sort(t.begin(), t.end());
         if (!t.empty()) {
-            ZSW_HIP(ctx, ws[WS_FBCOUNT].ensure(4));
+            ZSW_HIP(ctx, ws[WS_FBCOUNT].ensure(8));  // fallback counter + the packed kernel's work counter
             ZSW_HIP(ctx, hipMemsetAsync(ws[WS_FBCOUNT].p, 0, 4, stream));
             hipLaunchKernelGGL(count_some_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, so.status, n, ws[WS_FBCOUNT].as<uint32_t>());
             ZSW_HIP(ctx, hipMemcpyAsync(&n_some, ws[WS_FBCOUNT].p, 4, hipMemcpyDeviceToHost, stream));
@@ -617,13 +617,13 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     ZSW_HIP(ctx, ws[WS_CIGSTART].ensure((size_t)n * 8));
     ZSW_HIP(ctx, ws[WS_CIGRAW].ensure((size_t)n * 4));
     ZSW_HIP(ctx, ws[WS_FBLIST].ensure((size_t)n * 4 + 4));
-    ZSW_HIP(ctx, ws[WS_FBCOUNT].ensure(4));
+    ZSW_HIP(ctx, ws[WS_FBCOUNT].ensure(8));  // fallback counter + the packed kernel's work counter
     ZSW_HIP(ctx, ws[WS_CIG].ensure((size_t)n * MAXC * 4));
     ZSW_HIP(ctx, hipMemsetAsync(ws[WS_FBCOUNT].p, 0, 4, stream));
 
     auto window_of = [&](const GroupRun& g, bool full) {
         const uint32_t lpad = g.nv * (uint32_t)g.N;
-        uint32_t W = full ? (uint32_t)ctx->ref_len : std::min<uint32_t>((uint32_t)ctx->ref_len, lpad + std::max<uint32_t>(32, lpad / 4));
+        uint32_t W = full ? (uint32_t)ctx->ref_len : std::min<uint32_t>((uint32_t)ctx->ref_len, lpad + std::max<uint32_t>(16, lpad / 8));
         return W ? W : 1u;
     };
     // the packed kernel (two reads per lane group, zsw_align_pk_kernel.hpp) answers the groups it covers; the 32-bit kernels
