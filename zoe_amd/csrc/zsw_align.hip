@@ -57,7 +57,11 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
     const size_t row_bytes = (size_t)nv * N;
     uint8_t* ring = a.ring + ((size_t)blockIdx.x * RPW + grp) * (size_t)a.W * row_bytes;
 
-    for (uint32_t first = blockIdx.x * RPW; first < a.b.n_items; first += gridDim.x * RPW) {
+    for (;;) {  // reads are handed out through a work counter (see align_kernel_pk)
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(a.next_item, (uint32_t)RPW);
+        first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+        if (first >= a.b.n_items) break;
         const uint32_t item = first + grp;
         const bool valid = item < a.b.n_items;
         const uint32_t id = valid ? (a.b.items ? a.b.items[item] : item) : 0;
@@ -228,7 +232,11 @@ __global__ __launch_bounds__(64) void align_kernel_x(AlignArgs a) {
     const int W = (int)a.W;
     const uint32_t* plane = prof4 + lane;
 
-    for (uint32_t first = blockIdx.x * RPW; first < a.b.n_items; first += gridDim.x * RPW) {
+    for (;;) {  // reads are handed out through a work counter (see align_kernel_pk)
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(a.next_item, (uint32_t)RPW);
+        first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+        if (first >= a.b.n_items) break;
         const uint32_t item = first + grp;
         const bool valid = item < a.b.n_items;
         const uint32_t id = valid ? (a.b.items ? a.b.items[item] : item) : 0;
@@ -621,6 +629,9 @@ hipError_t align_pass2(int N, uint32_t nv, const BatchDev& b, const uint8_t* d_r
     a.invert = invert;
     // profiles too long for LDS keep their rows behind the ring (align_ring_bytes reserves the space)
     a.rows = (nv > 32 && align_rows_bytes(nv) > ALIGN_LDS_LIMIT) ? d_ring + align_ring_only_bytes(N, nv, W, grid) : nullptr;
+    a.next_item = d_fb_count + 1;  // the word after the fallback counter
+    hipError_t ce = hipMemsetAsync(a.next_item, 0, 4, stream);
+    if (ce != hipSuccess) return ce;
     return run_group(N, a, S, grid, stream);
 }
 
