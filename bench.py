@@ -8,8 +8,11 @@
 One process per GPU.  A "step" is one pass of the hot path (`read.into_local_profile(..).sw_score_from_i8(reference)`
 for every read, i.e. zsw_score_batch_from) over the rank's batch of synthetic reads, already resident in HBM,
 followed — for N > 1 — by the RCCL all-gather of the per-read scores and statuses (the only exchange the path
-has).  Reads shard by contiguous index ranges (weak scaling: --reads-per-gpu is fixed as N grows); the counter-
-based generator lets every rank synthesise exactly its own shard on its own GPU.
+has; one collective per step, zoe_amd/dist.py).  Workloads (BASELINE.json):
+  N = 1  configs[1]: 10 M reads on the GPU.
+  N > 1  configs[3]: 500 M reads in total, sharded by contiguous index ranges [i*n/N, (i+1)*n/N) (62.5 M per GPU at
+         N = 8); the counter-based generator lets every rank synthesise exactly its own shard on its own GPU.
+--reads-per-gpu overrides both with a fixed per-GPU batch (weak scaling).
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the kernel's stream;
 `cpu_baseline` times the restated Zoe CPU path (oracle/, AVX2 w256) on the host cores over a bounded sample.
@@ -29,8 +32,12 @@ READ_LEN = 150
 REF_LEN = 2000
 ALGO_BYTES_PER_READ = READ_LEN + 4  # read bytes in + u32 score out
 # HBM bytes per read measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 fetch correction):
-# profiles/r01_score_v2_final_summary.txt — 1.500 GB read + 0.060 GB written per 10 M-read launch (status and tier bytes included)
+# 1.500 GB read + 0.060 GB written per 10 M-read launch (status and tier bytes included). A CONSTANT from that profile,
+# not a measurement of this run (the bench line says so).
 PMC_HBM_BYTES_PER_READ = 156.0
+PMC_PROFILE = "profiles/r01_score_v2_final_summary.txt"
+VALU_PEAK_SOURCE = "profiles/r01_valu_issue_rates_ubench.txt"  # this repo's micro-benchmark (tools/ubench.hip), not a figure of the guide
+TOTAL_READS_MULTI_GPU = 500_000_000  # BASELINE.json configs[3]
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 # v_pk_{add,sub,max}_i16 and v_perm_b32 issue at one wave64 instruction per 4 cycles per SIMD on gfx950
 # (profiles/r01_valu_issue_rates_ubench.txt: half the v_fma_f32/v_add_u32 rate), i.e. 16 lanes/clk/SIMD.
@@ -43,7 +50,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--reads-per-gpu", type=int, default=0, help="fixed batch per GPU (weak scaling); default: 10 M at N = 1, "
+                    "500 M / N at N > 1 (BASELINE.json configs[1] / configs[3])")
+    ap.add_argument("--total-reads", type=int, default=TOTAL_READS_MULTI_GPU, help="total reads of the N > 1 workload")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=2048, help="reads checked against the oracle after the timed region")
@@ -133,75 +142,150 @@ def rate_guess_1t(rate_fn, cores):
     return 1000 / (time.perf_counter() - t)
 
 
+def file_tag(rel: str) -> str:
+    """name + first 12 hex digits of the sha256 of a committed profile file (so a constant can be traced to its source)."""
+    import hashlib
+
+    try:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            return f"{rel}#sha256:{hashlib.sha256(f.read()).hexdigest()[:12]}"
+    except OSError:
+        return rel + " (missing)"
+
+
+WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4  # wave64 VALU instructions/s: 1,024 SIMDs, one per 4 cycles at 2.4 GHz (VALU_PEAK_SOURCE)
+# VALU wave-instructions per read of the pass-2 / score kernels, from committed rocprofv3 --pmc SQ_INSTS_VALU passes
+# (constants from those profiles, not measured in the bench run): see profiles/r02_align_pk_pmc.txt
+ALIGN_PK_VALU_PER_READ = 24_350
+ALIGN_PK_PROFILE = "profiles/r02_align_pk_pmc.txt"
+
+
+def rooflines(algo_bytes: float, kernel_s: float, valu_instr: float = None, source: str = None):
+    """The two roofs of a secondary entry: algorithmic bytes over the kernels' time against HBM, and (where a committed PMC
+    pass gives the instruction count) issued VALU wave-instructions against the 4-cycle issue rate."""
+    out = {"roofline": {"bound": "hbm", "achieved": algo_bytes / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_s * 1e3}}
+    if valu_instr:
+        out["valu_roofline"] = {"bound": "valu", "achieved": valu_instr / kernel_s / 1e9, "peak": WAVE_INSTR_PEAK / 1e9,
+                                "unit": "G wave64 VALU instructions/s", "frac": valu_instr / kernel_s / WAVE_INSTR_PEAK,
+                                "instruction_count_source": file_tag(source) if source else None,
+                                "instruction_count_measured_in_this_run": False, "valu_peak_source": VALU_PEAK_SOURCE}
+    return out
+
+
 def secondary_configs(zoe_amd, synth, ctx, matrix):
-    """Short measurements of the other BASELINE.json configs on this GPU (after the timed region; not part of `value`):
-    configs[2] full traceback and configs[4] mixed lengths vs a 30 kb reference, 1 M reads each."""
+    """Measurements of the other BASELINE.json configs on this GPU (after the timed region; not part of `value`):
+    configs[2] full traceback at its full size (10 M reads) and configs[4] mixed lengths vs a 30 kb reference (1 M reads),
+    plus the neighbouring entry points on 1 M reads. Every entry carries its own roofline(s)."""
     import torch
 
     out = {}
     ref2k = synth.reference_host(REF_LEN)
+
+    def timed(fn):
+        fn()  # warm-up (allocations, first-launch costs)
+        torch.cuda.synchronize()
+        ctx.timing_read()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ks, _ = ctx.timing_read()
+        return r, dt, ks
+
+    ctx.timing_enable(True)
+    # configs[2]: 10 M reads, sw_simd_align with CIGAR, bit-exact vs the CPU path of the same <T, N>
+    n_full = 10_000_000
+    rb = synth.reads_device(ctx, ref2k, 0, n_full, READ_LEN)
+    prof = zoe_amd.into_local_profile(rb, matrix, -10, -1, device=ctx.device)
+    a, dt, ks = timed(lambda: prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref2k)))
+    n_cig = int(len(a.inc))
+    n_some = int((a.status == 0).sum())
+    entry = {"reads_per_s_end_to_end_incl_d2h": n_full / dt, "pass2_kernel_ms": ks * 1e3, "pass2_kernel_ms_per_1M_reads": ks * 1e3 / (n_full / 1e6),
+             "ciglets": n_cig, "aligned_reads": n_some,
+             "call": "into_local_profile(..).sw_align_from_i8(SeqSrc::Reference(ref)) (CIGAR of the i16x16 / i8x32 tier), 10 M reads (BASELINE.json configs[2] at full size)",
+             "kernel": "zsw::align_kernel_pk<16,10> (+ <32,5> for the reads that answer at i8x32); pass 1 = score_kernel_v2<4,38,1>"}
+    # algorithmic bytes (SURVEY.md 8d): read in, record out (score, 4 coordinates, 2 lengths, count, offset = 40 B), 5 B per ciglet
+    entry.update(rooflines(n_full * (READ_LEN + 4.0) + n_some * 40.0 + n_cig * 5.0, ks, ALIGN_PK_VALU_PER_READ * n_full, ALIGN_PK_PROFILE))
+    out["align_full_traceback_10M_x_150bp_vs_2kb"] = entry
+    del a, prof, rb
+    torch.cuda.empty_cache()
+
     rb = synth.reads_device(ctx, ref2k, 0, 1_000_000, READ_LEN)
     prof = zoe_amd.into_local_profile(rb, matrix, -10, -1, device=ctx.device)
-    prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref2k))
-    ctx.timing_enable(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    a = prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref2k))
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ks, _ = ctx.timing_read()
-    out["align_full_traceback_1M_x_150bp_vs_2kb"] = {
-        "reads_per_s_end_to_end_incl_d2h": 1_000_000 / dt, "pass2_kernel_ms": ks * 1e3, "ciglets": int(len(a.inc)),
-        "call": "into_local_profile(..).sw_align_from_i8(SeqSrc::Reference(ref)) (CIGAR of the i16x16 / i8x32 tier)"}
-    prof.sw_align_from_i8_3pass(zoe_amd.SeqSrc.Reference(ref2k))
-    torch.cuda.synchronize()
-    ctx.timing_read()
-    t0 = time.perf_counter()
-    a3 = prof.sw_align_from_i8_3pass(zoe_amd.SeqSrc.Reference(ref2k))
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ks, _ = ctx.timing_read()
-    out["align_3pass_1M_x_150bp_vs_2kb"] = {
-        "reads_per_s_end_to_end_incl_d2h": 1_000_000 / dt, "kernels_ms": ks * 1e3, "ciglets": int(len(a3.inc)),
-        "call": "into_local_profile(..).sw_align_from_i8_3pass(SeqSrc::Reference(ref)) (three_pass.rs: ranges, then no-gaps / banded / scalar in the box)"}
-    del a, a3
+    a3, dt, ks = timed(lambda: prof.sw_align_from_i8_3pass(zoe_amd.SeqSrc.Reference(ref2k)))
+    entry = {"reads_per_s_end_to_end_incl_d2h": 1_000_000 / dt, "kernels_ms": ks * 1e3, "ciglets": int(len(a3.inc)),
+             "call": "into_local_profile(..).sw_align_from_i8_3pass(SeqSrc::Reference(ref)) (three_pass.rs: ranges, then no-gaps / banded / scalar in the box)"}
+    entry.update(rooflines(1e6 * (READ_LEN + 4.0) + float((a3.status == 0).sum()) * 40.0 + len(a3.inc) * 5.0, ks))
+    out["align_3pass_1M_x_150bp_vs_2kb"] = entry
+    del a3
     # score + ranges (striped.rs:355-388) and the sneaky_snake filter on the window each read maps to
     sp = zoe_amd.StripedProfileBatch(rb, matrix, -10, -1, T="i16", N=16, device=ctx.device)
-    sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rg = sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k))
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out["score_ranges_1M_x_150bp_vs_2kb"] = {"reads_per_s": 1_000_000 / dt,
-                                             "call": "StripedProfile::<i16,16,5>::sw_score_ranges(SeqSrc::Reference(ref))"}
+    rg, dt, ks = timed(lambda: sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k)))
+    entry = {"reads_per_s": 1_000_000 / dt, "kernels_ms": ks * 1e3, "call": "StripedProfile::<i16,16,5>::sw_score_ranges(SeqSrc::Reference(ref))"}
+    entry.update(rooflines(1e6 * (READ_LEN + 4.0 + 16.0), max(ks, 1e-9) if ks > 0 else dt))
+    out["score_ranges_1M_x_150bp_vs_2kb"] = entry
     st = (rg.ref_start.to(torch.int64) - rg.query_start.to(torch.int64)).clamp(0, REF_LEN - READ_LEN).to(torch.int32)
     ln = torch.full_like(st, READ_LEN)
-    zoe_amd.sneaky_snake(ref2k, rb, st, ln, 0.05)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    flt = zoe_amd.sneaky_snake(ref2k, rb, st, ln, 0.05)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out["sneaky_snake_1M_x_150bp_windows"] = {"pairs_per_s": 1_000_000 / dt, "pass_fraction": float((flt == 1).float().mean()),
-                                              "call": "sneaky_snake(&ref[start..start+150], read, 0.05) per read"}
-    del rg, flt, sp
+    flt, dt, ks = timed(lambda: zoe_amd.sneaky_snake(ref2k, rb, st, ln, 0.05))
+    entry = {"pairs_per_s": 1_000_000 / dt, "pass_fraction": float((flt == 1).float().mean()),
+             "call": "sneaky_snake(&ref[start..start+150], read, 0.05) per read"}
+    entry.update(rooflines(1e6 * (2 * READ_LEN + 8.0 + 1.0), dt))
+    out["sneaky_snake_1M_x_150bp_windows"] = entry
+    del rg, flt, sp, rb, prof
+    torch.cuda.empty_cache()
+    # configs[4]: mixed lengths vs a 30 kb reference, bucketed by strip configuration on the device
     ref30k = synth.reference_host(30000)
     rr = synth.reads_ragged_device(ctx, ref30k, 0, 1_000_000, 75, 400)
     pm = zoe_amd.into_local_profile(rr, matrix, -10, -1, device=ctx.device)
-    pm.sw_score_from_i8(ref30k)
-    torch.cuda.synchronize()
-    ctx.timing_read()  # drop the warm-up launch from the kernel timer
-    t0 = time.perf_counter()
-    pm.sw_score_from_i8(ref30k)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ks, _ = ctx.timing_read()
+    _, dt, ks = timed(lambda: pm.sw_score_from_i8(ref30k))
     ctx.timing_enable(False)
-    cells = float(rr.offsets[-1]) * 30000
-    out["score_mixed_1M_x_75_400bp_vs_30kb"] = {"reads_per_s": 1_000_000 / dt, "gcups": cells / dt / 1e9, "kernel_ms": ks * 1e3,
-                                                "call": "sw_score_from_i8, reads bucketed by strip configuration on the device"}
+    total_bases = float(rr.offsets[-1])
+    cells = total_bases * 30000
+    entry = {"reads_per_s": 1_000_000 / dt, "gcups": cells / dt / 1e9, "kernel_ms": ks * 1e3,
+             "call": "sw_score_from_i8, reads bucketed by strip configuration on the device"}
+    entry.update(mixed_padding_report(rr, 30000))
+    entry.update(rooflines(total_bases + 1e6 * (8.0 + 4.0), dt))
+    lane_ops = cells / dt / 2 * PACKED_OPS_PER_CELL_PAIR
+    entry["valu_roofline"] = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": VALU_LANE_OPS_PEAK / 1e12,
+                              "unit": "T lane-ops/s of USEFUL cells (7.5 packed VALU per two cells; padding columns and rows not counted)",
+                              "frac": lane_ops / VALU_LANE_OPS_PEAK, "valu_peak_source": VALU_PEAK_SOURCE}
+    out["score_mixed_1M_x_75_400bp_vs_30kb"] = entry
     return out
+
+
+def mixed_padding_report(rr, ref_len: int):
+    """cells launched / cells needed per strip configuration of the ragged batch (zsw_score.hip: a read runs in the smallest
+    G x C columns that hold it, and a lane group walks ref_len + G - 1 rows because of the skew)."""
+    import numpy as np
+
+    lens = (rr.offsets[1:] - rr.offsets[:-1]).cpu().numpy().astype(np.int64)
+    # the length classes of a ragged batch, read from the kernel sources (zsw_score_v2.hpp: the strip configurations;
+    # zsw_score.hip: kBucketCfg, the ones a ragged batch is bucketed into)
+    import re
+
+    csrc = os.path.join(ROOT, "zoe_amd", "csrc")
+    with open(os.path.join(csrc, "zsw_score_v2.hpp")) as f:
+        cfgs = [(int(g), int(c)) for g, c in re.findall(r"X\((\d+), (\d+)\)", f.read().split("#define ZSW_FOR_EACH_STRIP_CONFIG(X)")[1].split("constexpr")[0])]
+    with open(os.path.join(csrc, "zsw_score.hip")) as f:
+        idx_list = [int(x) for x in re.search(r"kBucketCfg\[\] = \{([^}]*)\}", f.read()).group(1).split(",")]
+    classes = [cfgs[i] for i in idx_list]
+    caps = np.array(sorted(set(g * c for g, c in classes)))
+    per = {}
+    need_total = launched_total = 0
+    idx = np.searchsorted(caps, lens)
+    for k, cap in enumerate(caps):
+        sel = lens[idx == k]
+        if sel.size == 0:
+            continue
+        g = min(gg for gg, cc in classes if gg * cc == cap)
+        need = int(sel.sum()) * ref_len
+        launched = int(sel.size) * int(cap) * (ref_len + g - 1)
+        per[str(int(cap))] = {"reads": int(sel.size), "cells_launched_over_needed": launched / need}
+        need_total += need
+        launched_total += launched
+    return {"padding": {"cells_launched_over_needed": launched_total / max(need_total, 1), "per_columns_class": per}}
 
 
 def main():
@@ -229,39 +313,57 @@ def main():
 
     import zoe_amd
     from zoe_amd import synth
+    from zoe_amd.dist import GatheredResults, ResultSlab, gather_slabs, shard_capacity, shard_range, slab_bytes
 
     ctx = zoe_amd.SwContext.get(local_rank)
     reference = synth.reference_host(REF_LEN)
     matrix = zoe_amd.WeightMatrix.new_dna_matrix(2, -5, b"N")  # the reference's test/bench constants (sw/mod.rs:465-471)
-    n_local = args.reads_per_gpu
-    first = rank * n_local
+    if args.reads_per_gpu > 0:  # fixed batch per GPU
+        n_total, scaling = args.reads_per_gpu * world, "weak"
+        workload = f"{args.reads_per_gpu} synthetic {READ_LEN} bp reads per GPU"
+    elif world == 1:  # BASELINE.json configs[1]
+        n_total, scaling = 10_000_000, "weak"
+        workload = f"BASELINE.json configs[1]: {n_total} synthetic {READ_LEN} bp reads on one GPU"
+    else:  # BASELINE.json configs[3]
+        n_total, scaling = args.total_reads, "strong"
+        workload = (f"BASELINE.json configs[3]: {n_total} synthetic {READ_LEN} bp reads in total, sharded over {world} GPUs "
+                    f"({shard_capacity(n_total, world)} per GPU), per-read best-score gather over RCCL")
+    workload += f" vs one {REF_LEN} bp reference, score-only (sw_score_from_i8, w256 preset; 2/-5/N ignored, gaps -10/-1)"
+    first, n_local = shard_range(n_total, rank, world)
     reads = synth.reads_device(ctx, reference, first, n_local, READ_LEN)
     profiles = zoe_amd.LocalProfilesBatch.new_with_w256(reads, matrix, -10, -1, device=local_rank)
     dev = torch.device("cuda", local_rank)
+
+    # N > 1: the kernel writes scores + statuses into a byte slab, and ONE all-gather per step moves the slabs (zoe_amd/dist.py).
+    # Two slabs alternate: the gather of step k runs (asynchronously, on RCCL's stream, ordered after the producing kernel)
+    # under the kernel of step k+1, which fills the other slab; only the next gather, or the closing fence, waits for it.
+    gather_on_host = world > 1 and args.backend != "nccl"  # gloo rehearsal of the same code path on a one-GPU box
     if world > 1:
-        all_scores = torch.empty(world * n_local, dtype=torch.int32, device=dev)
-        all_status = torch.empty(world * n_local, dtype=torch.uint8, device=dev)
-
-    gather_on_host = world > 1 and args.backend != "nccl"
-    if gather_on_host:
-        all_scores, all_status = all_scores.cpu(), all_status.cpu()
-
-    # The result all-gather of step k runs under the kernel of step k+1: it is issued asynchronously (RCCL's own stream, ordered after
-    # the producing kernel) and only the NEXT gather, or the closing fence, waits for it. `pending` keeps the source tensors alive.
+        cap = shard_capacity(n_total, world)
+        counts = [shard_range(n_total, r, world)[1] for r in range(world)]
+        slabs = [ResultSlab(cap, device=dev), ResultSlab(cap, device=dev)]
+        host_slabs = [ResultSlab(cap), ResultSlab(cap)] if gather_on_host else None
+        gathered = GatheredResults(world, cap, counts, device=None if gather_on_host else dev)
     pending = []
+    step_no = [0]
 
     def drain():
-        for work, _keep in pending:
+        for work in pending:
             work.wait()
         pending.clear()
 
     def step():
-        r = profiles.sw_score_from_i8(reference)
-        if world > 1:
-            src_score, src_status = (r.score.cpu(), r.status.cpu()) if gather_on_host else (r.score, r.status)  # host path: rehearsal only
-            drain()  # the gather of the previous step had this step's kernel launch to hide behind
-            pending.append((dist.all_gather_into_tensor(all_scores, src_score, async_op=True), src_score))
-            pending.append((dist.all_gather_into_tensor(all_status, src_status, async_op=True), src_status))
+        if world == 1:
+            return profiles.sw_score_from_i8(reference)
+        k = step_no[0] % 2
+        step_no[0] += 1
+        r = profiles.sw_score_from_i8(reference, out=slabs[k])
+        src = slabs[k]
+        if gather_on_host:
+            host_slabs[k].buf.copy_(slabs[k].buf)  # rehearsal only: gloo gathers host memory
+            src = host_slabs[k]
+        drain()  # the gather of the previous step had this step's kernel launch to hide behind
+        pending.append(gather_slabs(src, gathered, async_op=True))
         return r
 
     def fence():
@@ -288,10 +390,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if gather_on_host else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # the gathered array must be every rank's shard in read order
+        # the gathered array must be every rank's shard in read order: own shard, and the first read of every other shard
+        # against a single-process score of the same (regenerated) read
+        mine = gathered.score_of_rank(rank)
+        assert torch.equal(mine.cpu(), last.score.cpu()), "all-gather order"
         if rank == 0:
-            mine = last.score.cpu() if gather_on_host else last.score
-            assert torch.equal(all_scores[:n_local].to(mine.device), mine), "all-gather order"
+            probe = zoe_amd.LocalProfilesBatch.new_with_w256(_first_reads(zoe_amd, synth, ctx, reference, n_total, world), matrix, -10, -1,
+                                                             device=local_rank).sw_score_from_i8(reference)
+            got = torch.stack([gathered.score_of_rank(r)[0] for r in range(world)]).cpu()
+            assert torch.equal(got, probe.score.cpu()), "gathered shards do not start with the right reads"
 
     # parity spot check outside the timed region (rank 0): a slice of the batch against the oracle
     verified = None
@@ -310,7 +417,7 @@ def main():
             raise SystemExit("PARITY FAILURE: GPU scores differ from the oracle")
 
     if rank == 0:
-        total_reads = world * n_local * args.steps
+        total_reads = n_total * args.steps
         value = total_reads / dt
         per_launch_s = kern_s / max(launches, 1)
         achieved = ALGO_BYTES_PER_READ * n_local / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
@@ -325,17 +432,19 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
             "config": {
-                "workload": f"{n_local} synthetic {READ_LEN} bp reads per GPU vs one {REF_LEN} bp reference, score-only "
-                            "(sw_score_from_i8, w256 preset; 2/-5/N ignored, gaps -10/-1)",
+                "workload": workload,
+                "total_reads": n_total,
                 "reads_per_gpu": n_local,
                 "read_len": READ_LEN,
                 "ref_len": REF_LEN,
-                "parallelism": f"reads sharded over {world} GPU(s); RCCL all-gather of scores+status" if world > 1 else "single GPU",
+                "parallelism": (f"reads sharded over {world} GPU(s), contiguous index ranges; one RCCL all-gather per step of a "
+                                f"{slab_bytes(shard_capacity(n_total, world))} B slab per rank (u32 scores + u8 statuses), issued under the next step's kernel"
+                                if world > 1 else "single GPU"),
             },
             "gcups": value * READ_LEN * REF_LEN / 1e9,
             "roofline": {
@@ -346,9 +455,11 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": PMC_HBM_BYTES_PER_READ * n_local / per_launch_s / 1e9 if per_launch_s > 0 else None,
                 "traffic_bytes_per_launch": PMC_HBM_BYTES_PER_READ * n_local,
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (profiles/r01_score_v2_final_summary.txt), bytes/read x reads of this launch",
+                "traffic_measured_in_this_run": False,
+                "traffic_source": "constant 156 B/read from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of the same kernel and workload: " + file_tag(PMC_PROFILE),
                 "kernel": "zsw::score_kernel_v2<4,38,0>",
                 "kernel_ms": per_launch_s * 1e3,
+                "kernel_ms_source": "HIP events recorded around the kernel on its stream, inside this run",
                 "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
                 "note": "HBM is not the binding roof: 7.5 packed VALU ops per 2 cells at 4 cycles each, see valu_roofline",
             },
@@ -358,6 +469,8 @@ def main():
                 "peak": VALU_LANE_OPS_PEAK / 1e12,
                 "unit": "T lane-ops/s (32-bit lanes of packed-i16 VALU; each lane-op advances 2 cells)",
                 "frac": lane_ops / VALU_LANE_OPS_PEAK,
+                "valu_peak_source": "one wave64 packed/perm/max3 instruction per 4 cycles per SIMD, measured by this repo's micro-benchmark: "
+                                    + file_tag(VALU_PEAK_SOURCE) + " (MI355X_MICROARCH.md lists only v_fma_f32)",
             },
             "parity_checked_reads": args.verify if verified else 0,
         }
@@ -371,6 +484,15 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _first_reads(zoe_amd, synth, ctx, reference, n_total, world):
+    """The first read of every rank's shard as one small batch (for the gather-order check)."""
+    import torch
+    from zoe_amd.dist import shard_range
+
+    parts = [synth.reads_device(ctx, reference, shard_range(n_total, r, world)[0], 1, READ_LEN).bases.view(-1) for r in range(world)]
+    return zoe_amd.ReadBatch.from_fixed(torch.cat(parts), READ_LEN)
 
 
 if __name__ == "__main__":

@@ -28,6 +28,17 @@ def _worker(rank, world, n_total, port, out_dir):
     sc = oracle.dna_scoring(2, -5, b"N", -10, -1)
     s, st, _ = oracle.batch_score_w256(8, sc, reads, ref, fixed_len=60, threads=1)
     gs, gst = all_gather_results(torch.from_numpy(s.view(np.int32)), torch.from_numpy(st), n_total)
+    # the form bench.py uses: results written into a slab, ONE asynchronous collective, views per rank
+    from zoe_amd.dist import GatheredResults, ResultSlab, gather_slabs, shard_capacity
+
+    cap = shard_capacity(n_total, world)
+    slab = ResultSlab(cap)
+    slab.score[:count] = torch.from_numpy(s.view(np.int32))
+    slab.status[:count] = torch.from_numpy(st)
+    out = GatheredResults(world, cap, [shard_range(n_total, r, world)[1] for r in range(world)])
+    gather_slabs(slab, out, async_op=True).wait()
+    assert torch.equal(out.scores(), gs) and torch.equal(out.statuses(), gst)
+    assert torch.equal(out.score_of_rank(rank), slab.score[:count])
     if rank == 0:
         np.save(os.path.join(out_dir, "s.npy"), gs.numpy())
         np.save(os.path.join(out_dir, "st.npy"), gst.numpy())

@@ -247,7 +247,7 @@ def test_align_degenerate_batches(za, oracle):
 
 
 def test_config3_large_batch_properties(za, oracle):
-    """BASELINE.json configs[2] shape at 2 M reads, through size-independent properties: every CIGAR consumes exactly the
+    """BASELINE.json configs[2] at its full size (10 M reads x 150 bp vs 2 kb, full traceback), through size-independent properties: every CIGAR consumes exactly the
     read and its reference range, scores and ends agree with the (independent) score+ends kernel for every read, and a
     random sample is bit-identical to the oracle and re-scores to its own score."""
     import torch
@@ -256,7 +256,7 @@ def test_config3_large_batch_properties(za, oracle):
 
     ctx = za.SwContext.get(0)
     ref = synth.reference_host(2000)
-    n = 2_000_000
+    n = 10_000_000
     rb = synth.reads_device(ctx, ref, 1_000_000, n, 150)
     dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
     a = za.into_local_profile(rb, dna, -10, -1).sw_align_from_i8(za.SeqSrc.Reference(ref))

@@ -505,21 +505,28 @@ class LocalProfilesBatch(_ProfileBatchBase):
     def new_with_w512(cls, reads, matrix, gap_open, gap_extend, device=0):
         return cls(reads, matrix, gap_open, gap_extend, 512, device)
 
-    def _score_from(self, reference, width: int) -> ScoreBatch:
+    def _score_from(self, reference, width: int, out=None) -> ScoreBatch:
+        """`out`: an object with preallocated `score` (int32) and `status` (uint8) device tensors of at least n reads, e.g. a
+        zoe_amd.dist.ResultSlab, so that the kernel writes straight into the buffer a collective sends."""
         torch = _torch()
         self._prep(reference)
         n = self.reads.n_reads
         dev = self.reads.bases.device
-        score = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        if out is not None:
+            score, status = out.score, out.status
+            if score.numel() < n or status.numel() < n or score.device != dev:
+                raise ValueError("out.score / out.status too small or on another device")
+        else:
+            score = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+            status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
         tier = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
         b = self.reads.c_batch()
         self.ctx.check(self.ctx.lib.zsw_score_batch_from(self.ctx.h, C.byref(b), width, self.preset, score.data_ptr(),
                                                          status.data_ptr(), tier.data_ptr(), self.ctx.stream()))
         return ScoreBatch(score[:n], status[:n], tier=tier[:n])
 
-    def sw_score_from_i8(self, reference) -> ScoreBatch:
-        return self._score_from(reference, 8)
+    def sw_score_from_i8(self, reference, out=None) -> ScoreBatch:
+        return self._score_from(reference, 8, out)
 
     def sw_score_from_i16(self, reference) -> ScoreBatch:
         return self._score_from(reference, 16)
