@@ -16,8 +16,9 @@
  *   Nucleotides::into_local_profile (w256)                   src/data/types/nucleotides/mod.rs:262-266
  *   SeqSrc::make_alignment / Alignment::invert               src/alignment/mod.rs:176-190, types/output.rs:396-425
  *
- * Plain pointers and sizes only; no hidden global state; one context per GPU; a context may be used
- * from one host thread at a time.  Every function returns a zsw_error and never aborts.
+ * Plain pointers and sizes only; no hidden global state; one context per GPU (zsw_group for several); a context may
+ * be used from one host thread at a time.  Every function returns a zsw_error and never aborts.  A call leaves the
+ * calling thread's current HIP device as it found it.  At most 2^31-1 reads per call.
  * Results are bit-identical to the reference's CPU path: score and status for every read; for the
  * alignment calls also ranges and CIGAR of the stated <T,N> instantiation.
  */
@@ -88,6 +89,8 @@ typedef struct zsw_alignment {
 /* ---- context ------------------------------------------------------------------------------- */
 zsw_error zsw_create(int device_id, zsw_context** out);
 void zsw_destroy(zsw_context* ctx);
+/* The message of the context's last failing call. ctx == NULL: why the last zsw_create of the CALLING THREAD failed
+ * (thread-local; no state is shared between threads). */
 const char* zsw_last_error_string(const zsw_context* ctx);
 int zsw_device_count(void);
 
@@ -98,7 +101,10 @@ int zsw_device_count(void);
 zsw_error zsw_set_scoring(zsw_context* ctx, const int8_t* weights, int S, const uint8_t* index_map, int gap_open,
                           int gap_extend);
 
-/* The `reference: &[u8]` argument of sw_simd_*; copied into the context (replicated per GPU). */
+/* The `reference: &[u8]` argument of sw_simd_*; copied into the context (replicated per GPU).
+ * zsw_set_reference and zsw_set_scoring wait for the device to finish the work already queued (asynchronous score calls on
+ * any stream may still be reading the previous tables) before they overwrite them; they are configuration calls, not
+ * per-batch calls. */
 zsw_error zsw_set_reference(zsw_context* ctx, const uint8_t* reference, size_t len, zsw_mem mem);
 
 /* ---- score-only ---------------------------------------------------------------------------- */
@@ -177,6 +183,35 @@ typedef enum zsw_filter_result {
 } zsw_filter_result;
 zsw_error zsw_sneaky_snake_batch(zsw_context* ctx, const zsw_batch* reads, const uint32_t* ref_start, const uint32_t* ref_len,
                                  float threshold, uint8_t* out_pass, void* stream);
+
+/* ---- several GPUs behind one handle --------------------------------------------------------- */
+/* The batched counterpart of scoring many reads against SharedProfiles (src/alignment/profile_set.rs:552-560) from many
+ * threads: one caller, one batch, n GPUs. Reads shard into contiguous index ranges [i*n/G, (i+1)*n/G), context i takes shard i
+ * on device_ids[i] from its own host thread; scoring tables and reference are replicated; nothing is exchanged while the
+ * kernels run. A device may be listed more than once (two contexts on one GPU). A group is used from one host thread at a time;
+ * the contexts it owns are reachable through zsw_group_context (e.g. for zsw_timing_* or to run other entry points per shard). */
+typedef struct zsw_group zsw_group;
+zsw_error zsw_group_create(const int* device_ids, int n_devices, zsw_group** out);
+void zsw_group_destroy(zsw_group* group);
+int zsw_group_size(const zsw_group* group);
+zsw_context* zsw_group_context(zsw_group* group, int i);
+const char* zsw_group_last_error_string(const zsw_group* group);
+zsw_error zsw_group_set_scoring(zsw_group* group, const int8_t* weights, int S, const uint8_t* index_map, int gap_open,
+                                int gap_extend);
+zsw_error zsw_group_set_reference(zsw_group* group, const uint8_t* reference, size_t len); /* host memory */
+
+/* ProfileSets::sw_score_from_i{from_width} (src/alignment/profile_set.rs:71-107) for every read of a batch in HOST memory,
+ * spread over the group's GPUs. out_score / out_status / out_tier (optional) are host arrays of reads->n_reads entries and are
+ * written in place, shard by shard: no collective is involved. Synchronous. */
+zsw_error zsw_group_score_batch_from(zsw_group* group, const zsw_batch* reads, int from_width, int preset_bits,
+                                     uint32_t* out_score, uint8_t* out_status, uint8_t* out_tier);
+
+/* The same with reads and results in DEVICE memory: shards[i] is the batch of context i on device_ids[i]; out_score[i] and
+ * out_status[i] are arrays on device i with room for ALL reads (sum of the shards' n_reads). Context i writes its slice in
+ * place and one RCCL all-gather over xGMI (grouped broadcasts: the shards need not be equal) completes the arrays on every
+ * device, in shard order. librccl is opened at the first call; without it the call returns ZSW_ERR_UNSUPPORTED. Synchronous. */
+zsw_error zsw_group_score_batch_from_device(zsw_group* group, const zsw_batch* shards, int from_width, int preset_bits,
+                                            uint32_t* const* out_score, uint8_t* const* out_status);
 
 /* ---- bench/test utilities (not part of the reference surface) ------------------------------ */
 /* Counter-based synthetic reads: read i depends only on (seed, i, reference), so any

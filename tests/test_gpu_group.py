@@ -1,0 +1,99 @@
+"""GPU tests of the multi-device entry points (zsw_group_*, include/zoe_sw.h): a group shards a batch over its contexts and
+must return exactly what one context returns. A one-GPU box exercises the host-memory path with two contexts on device 0
+(two host threads, two streams of work on one GPU) and the RCCL leg at world size 1; ragged and fixed-length batches."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def za():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests need an MI355X")
+    import zoe_amd
+
+    return zoe_amd
+
+
+def _reference_and_reads(n, fixed):
+    from zoe_amd import synth
+
+    ref = synth.reference_host(2000)
+    if fixed:
+        host = synth.reads_host(ref, 5000, n, 150)
+        return ref, host.reshape(-1), None, 150
+    rng = np.random.default_rng(11)
+    lens = rng.integers(1, 400, size=n)
+    lens[::97] = 0  # empty reads: ZSW_STATUS_EMPTY
+    off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    full = synth.reads_host(ref, 0, n, 400)
+    bases = np.concatenate([full[i, : lens[i]] for i in range(n)]) if n else np.zeros(0, np.uint8)
+    return ref, bases, off, 0
+
+
+@pytest.mark.parametrize("fixed", [True, False])
+@pytest.mark.parametrize("n", [0, 1, 7, 20001])
+def test_two_contexts_on_one_gpu_equal_one_context(za, fixed, n):
+    import torch
+
+    ref, bases, off, L = _reference_and_reads(n, fixed)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    g = za.SwGroup([0, 0])
+    try:
+        assert len(g) == 2
+        g.configure(dna, -10, -1, ref)
+        s, st, t = g.sw_score_from_host(bases, n, fixed_len=L, offsets=off)
+    finally:
+        g.close()
+    if n == 0:
+        return
+    if fixed:
+        rb = za.ReadBatch.from_fixed(torch.from_numpy(bases).cuda(), 150)
+    else:
+        rb = za.ReadBatch(torch.from_numpy(bases if bases.size else np.zeros(1, np.uint8)).cuda(), n, offsets=torch.from_numpy(off.astype(np.int64)).cuda())
+    one = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1).sw_score_from_i8(ref)
+    assert np.array_equal(st, one.status.cpu().numpy())
+    some = st == 0
+    assert np.array_equal(s[some], one.score.cpu().numpy().view(np.uint32)[some])
+    assert np.array_equal(t[some], one.tier.cpu().numpy()[some])
+
+
+def test_device_shards_and_the_rccl_gather_at_world_size_one(za, oracle):
+    """Device-memory form: the context writes its slice of the device's result arrays and the grouped RCCL broadcast completes
+    them (world size 1 here: the collective is issued and must leave the results intact); checked against the oracle."""
+    import torch
+
+    from zoe_amd import synth
+
+    ref = synth.reference_host(2000)
+    n = 3000
+    host = synth.reads_host(ref, 123, n, 150)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    g = za.SwGroup([0])
+    try:
+        g.configure(dna, -10, -1, ref)
+        rb = za.ReadBatch.from_fixed(torch.from_numpy(host.reshape(-1)).cuda(), 150)
+        (score, status), = g.sw_score_from_device([rb])
+    finally:
+        g.close()
+    sc = oracle.dna_scoring(2, -5, b"N", -10, -1)
+    ws, wst, _ = oracle.batch_score_w256(8, sc, host, ref, fixed_len=150, threads=8)
+    assert np.array_equal(status.cpu().numpy(), wst)
+    assert np.array_equal(score.cpu().numpy().view(np.uint32), ws)
+
+
+def test_group_errors_are_reported_not_fatal(za):
+    from zoe_amd import _lib
+
+    with pytest.raises(_lib.ZswError):
+        za.SwGroup([99])  # no such device
+    g = za.SwGroup([0, 0])
+    try:
+        with pytest.raises(_lib.ZswError):  # not configured
+            g.sw_score_from_host(np.zeros(150, np.uint8), 1, fixed_len=150)
+    finally:
+        g.close()

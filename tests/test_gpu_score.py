@@ -602,3 +602,51 @@ def test_scores_beyond_the_packed_range_use_the_32bit_tile_kernel(za, oracle, dn
     ex = p2.sw_score_ends(za.SeqSrc.Reference(ref2))
     for name in ("score", "ref_end", "query_end", "status"):
         assert np.array_equal(getattr(ex, name).cpu().numpy(), getattr(w32, name).cpu().numpy()), name
+
+
+def test_reconfiguring_the_reference_behind_asynchronous_calls(za, oracle, dna):
+    """Score calls on device memory are asynchronous on the caller's stream. Two calls with DIFFERENT references back to back on
+    a non-blocking side stream: zsw_set_reference must not overwrite the first reference while the first kernel still reads it."""
+    import torch
+
+    from zoe_amd import synth
+
+    ctx = za.SwContext.get(0)
+    ref_a, ref_b = synth.reference_host(2000), synth.reference_host(2000)[::-1]
+    n = 2_000_000  # ~60 ms of kernel per call: the second configuration call arrives while the first kernel runs
+    rb = synth.reads_device(ctx, ref_a, 0, n, 150)
+    prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        a = prof.sw_score_from_i8(ref_a)
+        b = prof.sw_score_from_i8(ref_b)
+        a2 = prof.sw_score_from_i8(ref_a)
+    side.synchronize()
+    assert torch.equal(a.score, a2.score) and torch.equal(a.status, a2.status)
+    sc = osc(oracle, dna, -10, -1)
+    idx = np.arange(0, n, n // 512)
+    host = rb.bases.view(n, 150)[torch.from_numpy(idx).cuda()].cpu().numpy()
+    for ref, got in ((ref_a, a), (ref_b, b)):
+        ws, wst, _ = oracle.batch_score_w256(8, sc, host, ref, fixed_len=150, threads=8)
+        assert np.array_equal(got.score[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32), ws)
+        assert np.array_equal(got.status[torch.from_numpy(idx).cuda()].cpu().numpy(), wst)
+
+
+def test_a_megabase_read_against_a_short_reference(za, oracle, dna):
+    """No length limit below 2^31 on either sequence: a 1.1 Mb read (453 tiles of 2,432 columns; the exact kernel's scratch is
+    sized from a byte budget, not from a fixed slot count) against a 150 bp reference, score and ends equal to the oracle."""
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = bytes(rng.choice(alpha, 150))
+    big = bytearray(rng.choice(alpha, 1_100_000))
+    big[700_000:700_150] = ref  # the reference itself, with two edits
+    big[700_040] = ord("A") if big[700_040] != ord("A") else ord("C")
+    del big[700_100]
+    reads = [bytes(big), bytes(rng.choice(alpha, 300)), ref[20:120]]
+    sc = osc(oracle, dna, -10, -1)
+    got = za.StripedProfileBatch(reads, dna, -10, -1, "i32", 8).sw_score_ends(za.SeqSrc.Reference(ref))
+    for i, rd in enumerate(reads):
+        st, (s, re_, qe) = oracle.score_ends("i32", 8, sc, rd, ref)
+        assert (int(got.status[i]), int(got.score[i]), int(got.ref_end[i]), int(got.query_end[i])) == (st, s, re_, qe), i
+    assert int(got.score[0]) > 250

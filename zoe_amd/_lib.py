@@ -34,6 +34,8 @@ SYMBOLS = [
     "zsw_score_batch", "zsw_score_batch_from", "zsw_score_ends_batch", "zsw_score_ranges_batch", "zsw_score_ranges_batch_from", "zsw_align_batch", "zsw_align_batch_from", "zsw_align_3pass_batch", "zsw_align_3pass_batch_from", "zsw_sneaky_snake_batch",
     "zsw_synth_reads", "zsw_synth_reads_ragged", "zsw_synth_length", "zsw_synth_reference_host", "zsw_synth_reads_host",
     "zsw_synth_reads_ragged_host", "zsw_selftest", "zsw_timing_enable", "zsw_timing_read", "zsw_debug_set",
+    "zsw_group_create", "zsw_group_destroy", "zsw_group_size", "zsw_group_context", "zsw_group_last_error_string", "zsw_group_set_scoring",
+    "zsw_group_set_reference", "zsw_group_score_batch_from", "zsw_group_score_batch_from_device",
 ]
 
 
@@ -116,5 +118,17 @@ def load() -> C.CDLL:
     lib.zsw_timing_enable.argtypes = [vp, C.c_int]
     lib.zsw_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.zsw_debug_set.argtypes = [vp, C.c_uint32]
+    lib.zsw_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    lib.zsw_group_destroy.argtypes = [vp]
+    lib.zsw_group_destroy.restype = None
+    lib.zsw_group_size.argtypes = [vp]
+    lib.zsw_group_context.argtypes = [vp, C.c_int]
+    lib.zsw_group_context.restype = vp
+    lib.zsw_group_last_error_string.argtypes = [vp]
+    lib.zsw_group_last_error_string.restype = C.c_char_p
+    lib.zsw_group_set_scoring.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int]
+    lib.zsw_group_set_reference.argtypes = [vp, vp, C.c_size_t]
+    lib.zsw_group_score_batch_from.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, vp, vp, vp]
+    lib.zsw_group_score_batch_from_device.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     _lib = lib
     return lib

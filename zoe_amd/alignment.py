@@ -263,6 +263,78 @@ class SwContext:
         return s.value, n.value
 
 
+class SwGroup:
+    """zsw_group: several GPUs (or several contexts on one GPU) behind one handle; reads shard into contiguous index ranges,
+    one host thread drives each context (include/zoe_sw.h). Host batches get their results in place; device shards are
+    completed on every device by one RCCL all-gather."""
+
+    def __init__(self, device_ids: Sequence[int]):
+        self.lib = _lib.load()
+        self.devices = [int(d) for d in device_ids]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        rc = self.lib.zsw_group_create(arr, len(self.devices), C.byref(h))
+        if rc != 0:
+            raise _lib.ZswError(rc, "zsw_group_create: " + self.lib.zsw_last_error_string(None).decode())
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.zsw_group_destroy(self.h)
+            self.h = None
+
+    def check(self, rc: int):
+        if rc == 0:
+            return
+        if 1 <= rc <= 4:
+            raise ProfileError(rc)
+        raise _lib.ZswError(rc, self.lib.zsw_group_last_error_string(self.h).decode())
+
+    def __len__(self):
+        return int(self.lib.zsw_group_size(self.h))
+
+    def configure(self, matrix: WeightMatrix, gap_open: int, gap_extend: int, reference: bytes):
+        w = np.ascontiguousarray(matrix.signed_weights(), dtype=np.int8)
+        im = matrix.mapping.index_map
+        self.check(self.lib.zsw_group_set_scoring(self.h, w.ctypes.data, w.shape[0], im.ctypes.data, gap_open, gap_extend))
+        ref = np.frombuffer(bytes(reference), dtype=np.uint8) if len(reference) else np.zeros(1, dtype=np.uint8)
+        self.check(self.lib.zsw_group_set_reference(self.h, ref.ctypes.data, len(reference)))
+
+    def sw_score_from_host(self, bases: np.ndarray, n_reads: int, fixed_len: int = 0, offsets: Optional[np.ndarray] = None,
+                           width: int = 8, preset: int = 256):
+        """ProfileSets::sw_score_from_i{width} for a batch in host memory; returns (score u32, status u8, tier u8) numpy arrays."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        b = _lib.ZswBatch()
+        b.bases = bases.ctypes.data
+        off = None
+        if offsets is not None:
+            off = np.ascontiguousarray(offsets, dtype=np.uint64)
+            b.offsets = off.ctypes.data
+        b.fixed_len = int(fixed_len)
+        b.n_reads = int(n_reads)
+        b.mem = _lib.MEM_HOST
+        score = np.zeros(max(n_reads, 1), dtype=np.uint32)
+        status = np.zeros(max(n_reads, 1), dtype=np.uint8)
+        tier = np.zeros(max(n_reads, 1), dtype=np.uint8)
+        self.check(self.lib.zsw_group_score_batch_from(self.h, C.byref(b), width, preset, score.ctypes.data, status.ctypes.data, tier.ctypes.data))
+        return score[:n_reads], status[:n_reads], tier[:n_reads]
+
+    def sw_score_from_device(self, shards: Sequence["ReadBatch"], width: int = 8, preset: int = 256):
+        """One device-resident ReadBatch per context; returns per device the (score, status) tensors of ALL reads in shard order."""
+        torch = _torch()
+        if len(shards) != len(self.devices):
+            raise ValueError("one shard per context")
+        total = sum(s.n_reads for s in shards)
+        arr = (_lib.ZswBatch * len(shards))(*[s.c_batch() for s in shards])
+        outs = [(torch.zeros(max(total, 1), dtype=torch.int32, device=s.bases.device), torch.zeros(max(total, 1), dtype=torch.uint8, device=s.bases.device))
+                for s in shards]
+        ps = (C.c_void_p * len(shards))(*[o[0].data_ptr() for o in outs])
+        pt = (C.c_void_p * len(shards))(*[o[1].data_ptr() for o in outs])
+        torch.cuda.synchronize()
+        self.check(self.lib.zsw_group_score_batch_from_device(self.h, arr, width, preset, ps, pt))
+        return [(o[0][:total], o[1][:total]) for o in outs]
+
+
 class ReadBatch:
     """Device-resident reads: `bases` uint8 (concatenated), and either `fixed_len` or `offsets` (int64[n+1])."""
 

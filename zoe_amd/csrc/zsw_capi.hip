@@ -49,6 +49,7 @@ struct zsw_context {
     DevBuf d_sc, d_ref, d_fb_list, d_fb_count, d_scratch, d_maxlen, d_bucket_items, d_bucket_counts, d_tile_buf, d_tile_state;
     size_t ref_len = 0;
     uint32_t scratch_len = 0;
+    size_t exact_slots = 0;
     // staging for host-memory batches
     DevBuf s_bases, s_offsets, s_score, s_status, s_tier, s_rend, s_qend;
     // alignment workspace (zsw_align.hip)
@@ -67,7 +68,8 @@ struct zsw_context {
 
 namespace {
 
-constexpr size_t EXACT_SLOTS = 64 * 256;
+constexpr size_t EXACT_SLOTS = 64 * 256;               // rows of the exact 32-bit kernel that run at once, at most
+constexpr size_t EXACT_SCRATCH_BUDGET = size_t(1) << 30;  // bytes of its H/E rows, at most (longer reads get fewer slots)
 constexpr uint32_t LONGEST_STRIP = 64 * 38;  // columns of the widest strip configuration (zsw_score_v2.hpp)
 
 zsw_error fail(zsw_context* ctx, zsw_error code, const char* what, hipError_t e = hipSuccess) {
@@ -80,6 +82,23 @@ zsw_error fail(zsw_context* ctx, zsw_error code, const char* what, hipError_t e 
     }
     return code;
 }
+
+// Makes the context's GPU current for the duration of a public call and puts the caller's device back afterwards: a
+// single-process multi-GPU host (zsw_group, or PyTorch with several devices) must not find its current device changed.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(const zsw_context* ctx) {
+        if (!ctx) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != ctx->device) (void)hipSetDevice(ctx->device);
+        else prev = -1;  // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 #define ZSW_HIP(ctx, call)                                                     \
     do {                                                                       \
@@ -256,8 +275,12 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     ZSW_HIP(ctx, ctx->d_bucket_counts.ensure(64 * 4));
     uint32_t need = std::max<uint32_t>(512, (st->max_len + 127) / 128 * 128);
     if (need > ctx->scratch_len || !ctx->d_scratch.p) {
-        ZSW_HIP(ctx, ctx->d_scratch.ensure(2 * EXACT_SLOTS * (size_t)need * sizeof(int32_t)));
+        // slots from a byte budget: 16,384 for reads up to 8 kb, down to 64 for genome-sized reads (2 rows of `need` ints per slot)
+        size_t slots = EXACT_SCRATCH_BUDGET / (2 * (size_t)need * sizeof(int32_t)) / 64 * 64;
+        slots = std::min(EXACT_SLOTS, std::max<size_t>(64, slots));
+        ZSW_HIP(ctx, ctx->d_scratch.ensure(2 * slots * (size_t)need * sizeof(int32_t)));
         ctx->scratch_len = need;
+        ctx->exact_slots = slots;
     }
     return ZSW_OK;
 }
@@ -265,7 +288,7 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
 ScoreWorkspace score_ws(zsw_context* ctx) {
     ScoreWorkspace w;
     w.scratch = ctx->d_scratch.as<int32_t>();
-    w.slots = EXACT_SLOTS;
+    w.slots = ctx->exact_slots;
     w.scratch_len = ctx->scratch_len;
     w.bucket_items = ctx->d_bucket_items.as<uint32_t>();
     w.bucket_counts = ctx->d_bucket_counts.as<uint32_t>();
@@ -294,6 +317,7 @@ constexpr uint32_t PIPE_CHUNK = 2'500'000;  // reads per chunk of the host-batch
 
 zsw_error run_score(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, bool want_ends, uint32_t* out_score,
                     uint8_t* out_status, uint8_t* out_tier, uint32_t* out_rend, uint32_t* out_qend, void* stream_) {
+    DeviceGuard device_guard(ctx);
     hipStream_t stream = (hipStream_t)stream_;
     Staged st;
     // fixed-length host batches of more than one chunk: the H2D copy of chunk k+1 overlaps the kernel of chunk k
@@ -437,6 +461,7 @@ zsw_error ranges_device(zsw_context* ctx, const Staged& st, const ResultRule& ru
 
 zsw_error run_ranges(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, uint32_t* out_score, uint32_t* out_rs,
                      uint32_t* out_re, uint32_t* out_qs, uint32_t* out_qe, uint8_t* out_status, uint8_t* out_tier, void* stream_) {
+    DeviceGuard device_guard(ctx);
     hipStream_t stream = (hipStream_t)stream_;
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     if (!reads || !out_score || !out_rs || !out_re || !out_qs || !out_qe || !out_status)
@@ -527,6 +552,7 @@ zsw_error finish_alignments(zsw_context* ctx, DevBuf* ws, uint32_t n, bool host,
 zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, int lanes_w8, int lanes_w16, int lanes_w32,
                     int invert, zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
                     uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream_) {
+    DeviceGuard device_guard(ctx);
     hipStream_t stream = (hipStream_t)stream_;
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     if (!reads || !out_aln || !out_status || !out_n_ciglets || (ciglet_cap && (!out_inc || !out_op)))
@@ -720,6 +746,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
 zsw_error run_threepass(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, int invert, zsw_alignment* out_aln,
                         uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap,
                         uint64_t* out_n_ciglets, void* stream_) {
+    DeviceGuard device_guard(ctx);
     hipStream_t stream = (hipStream_t)stream_;
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     if (!reads || !out_aln || !out_status || !out_n_ciglets || (ciglet_cap && (!out_inc || !out_op)))
@@ -907,6 +934,7 @@ zsw_error zsw_create(int device_id, zsw_context** out) {
 }
 
 void zsw_destroy(zsw_context* ctx) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state,
@@ -933,6 +961,7 @@ const char* zsw_last_error_string(const zsw_context* ctx) { return ctx ? ctx->er
 
 zsw_error zsw_set_scoring(zsw_context* ctx, const int8_t* weights, int S, const uint8_t* index_map, int gap_open,
                           int gap_extend) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !weights || !index_map) return ZSW_ERR_INVALID_ARGUMENT;
     if (S < 1 || S > MAX_S) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "S out of range");
     // validate_profile_args (profile.rs:32-44), sequence checks are per read
@@ -954,6 +983,8 @@ zsw_error zsw_set_scoring(zsw_context* ctx, const int8_t* weights, int S, const 
     s.gap_extend = -gap_extend;
     ctx->bias = -mn;  // WeightMatrix::get_bias / to_biased_matrix (matrices/mod.rs:452-491)
     ZSW_HIP(ctx, hipSetDevice(ctx->device));
+    // asynchronous score calls (on any stream, blocking or not) may still be reading the previous tables
+    if (ctx->scoring_set) ZSW_HIP(ctx, hipDeviceSynchronize());
     ZSW_HIP(ctx, ctx->d_sc.ensure(sizeof(ScoringDev)));
     ZSW_HIP(ctx, hipMemcpy(ctx->d_sc.p, &s, sizeof(ScoringDev), hipMemcpyHostToDevice));
     ctx->scoring_set = true;
@@ -961,9 +992,11 @@ zsw_error zsw_set_scoring(zsw_context* ctx, const int8_t* weights, int S, const 
 }
 
 zsw_error zsw_set_reference(zsw_context* ctx, const uint8_t* reference, size_t len, zsw_mem mem) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || (!reference && len)) return ZSW_ERR_INVALID_ARGUMENT;
     if (len > 0x7fffffffull) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "reference too long");
     ZSW_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->reference_set) ZSW_HIP(ctx, hipDeviceSynchronize());  // queued kernels may still read the previous reference
     ZSW_HIP(ctx, ctx->d_ref.ensure(len + 16));
     if (len)
         ZSW_HIP(ctx, hipMemcpy(ctx->d_ref.p, reference, len, mem == ZSW_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
@@ -1045,6 +1078,7 @@ zsw_error zsw_align_3pass_batch_from(zsw_context* ctx, const zsw_batch* reads, i
 
 zsw_error zsw_sneaky_snake_batch(zsw_context* ctx, const zsw_batch* reads, const uint32_t* ref_start, const uint32_t* ref_len,
                                  float threshold, uint8_t* out_pass, void* stream_) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     if (!ctx->reference_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "reference not set");
     if (!reads || !ref_start || !ref_len || !out_pass) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
@@ -1096,6 +1130,7 @@ zsw_error zsw_sneaky_snake_batch(zsw_context* ctx, const zsw_batch* reads, const
 
 zsw_error zsw_synth_reads(zsw_context* ctx, uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint8_t* out_device,
                           void* stream) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !out_device || len == 0) return ZSW_ERR_INVALID_ARGUMENT;
     if (!ctx->reference_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "reference not set");
     ZSW_HIP(ctx, hipSetDevice(ctx->device));
@@ -1108,6 +1143,7 @@ zsw_error zsw_synth_reads(zsw_context* ctx, uint64_t seed, uint64_t first, uint6
 
 zsw_error zsw_synth_reads_ragged(zsw_context* ctx, uint64_t seed, uint64_t first, uint64_t n, uint32_t min_len,
                                  uint32_t max_len, const uint64_t* offsets_device, uint8_t* out_device, void* stream) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !out_device || !offsets_device || min_len == 0 || max_len < min_len) return ZSW_ERR_INVALID_ARGUMENT;
     if (!ctx->reference_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "reference not set");
     ZSW_HIP(ctx, hipSetDevice(ctx->device));
@@ -1138,6 +1174,7 @@ void zsw_synth_reads_ragged_host(uint64_t seed, uint64_t first, uint64_t n, uint
 }
 
 zsw_error zsw_selftest(zsw_context* ctx) {
+    DeviceGuard device_guard(ctx);
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     ZSW_HIP(ctx, hipSetDevice(ctx->device));
     uint32_t* d = nullptr;
@@ -1172,6 +1209,7 @@ zsw_error zsw_timing_enable(zsw_context* ctx, int enable) {
 }
 
 zsw_error zsw_timing_read(zsw_context* ctx, double* seconds, uint64_t* launches) {
+    DeviceGuard device_guard(ctx);
     if (!ctx || !seconds || !launches) return ZSW_ERR_INVALID_ARGUMENT;
     ZSW_HIP(ctx, hipSetDevice(ctx->device));
     ZSW_HIP(ctx, ctx->timer.collect(seconds, launches));
