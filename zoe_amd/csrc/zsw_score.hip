@@ -128,7 +128,7 @@ struct Cfg {
 static const Cfg kCfgs[] = {ZSW_FOR_EACH_STRIP_CONFIG(ZSW_CFG_ENTRY)};
 #undef ZSW_CFG_ENTRY
 
-constexpr int N_ASCENDING_CFGS = 13;  // the rest of kCfgs is for small batches only (score_config_for_batch)
+constexpr int N_ASCENDING_CFGS = 20;  // the rest of kCfgs is for small batches only (score_config_for_batch)
 
 bool score_config_for(uint32_t max_len, int* G, int* C) {
     for (int k = 0; k < N_ASCENDING_CFGS; ++k) {
@@ -334,8 +334,8 @@ static hipError_t launch_table_cfg(const ScoreArgs& a, int G, int C, bool fast, 
 
 // ---- ragged batches: group the reads by the smallest strip configuration that holds them -------------------
 // class k < NCLS: kCfgs[kBucketCfg[k]]; class NCLS: longer than every table configuration (exact 32-bit kernel)
-static const int kBucketCfg[] = {0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12};  // (8,19) duplicates the capacity of (4,38)
-constexpr int NCLS = 12;
+static const int kBucketCfg[] = {0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19};  // (8,19) duplicates the capacity of (4,38)
+constexpr int NCLS = 19;
 
 struct BucketCaps {
     uint32_t cap[NCLS];

@@ -11,11 +11,14 @@ constexpr int NEUTRAL = 8;     // table row used outside [0, R): scores 0 for ev
 constexpr int PAD_K = 255;     // residue code of a padded query column
 
 // The strip configurations (G lanes per read pair x C columns per lane). Every launcher switch and the configuration table are
-// generated from this one list: thirteen of ascending capacity G*C, which the first-fit choice and the length classes of ragged
-// batches walk in order, then (32, 5), which only the batch-size-aware choice picks (short reads, too few of them to fill the
-// chip with four lanes per pair).
-#define ZSW_FOR_EACH_STRIP_CONFIG(X) \
-    X(4, 19) X(4, 25) X(4, 32) X(4, 38) X(8, 19) X(8, 25) X(8, 32) X(8, 38) X(16, 25) X(16, 32) X(16, 38) X(64, 19) X(64, 38) X(32, 5)
+// generated from this one list: twenty of ascending capacity G*C (the first-fit choice and the length classes of ragged batches
+// walk them in order; steps of 8-16 % between 76 and 400 columns keep the padded columns of a 75-400 bp batch near 6 %), then
+// (32, 5), which only the batch-size-aware choice picks (short reads, too few of them to fill the chip with four lanes per pair).
+// Measured and rejected: C = 41 / 44 with four and eight lanes instead of (8,19), (8,22), (16,22) — 8.5 instead of 9.0 TCUPS on
+// the 75-400 bp batch (the longer column loops sit at the 168-VGPR boundary of three waves per SIMD).
+#define ZSW_FOR_EACH_STRIP_CONFIG(X)                                                                                            \
+    X(4, 19) X(4, 22) X(4, 25) X(4, 28) X(4, 32) X(4, 35) X(4, 38) X(8, 19) X(8, 22) X(8, 25) X(8, 28) X(8, 32) X(8, 35) X(8, 38) \
+    X(16, 22) X(16, 25) X(16, 32) X(16, 38) X(64, 19) X(64, 38) X(32, 5)
 constexpr int WIDE_STRIDE = 36;  // bytes per table row of the WIDE kernels (9 dwords: rows start in different LDS banks)
 constexpr int WIDE_PAD = 32, WIDE_NEUTRAL = 32;
 
