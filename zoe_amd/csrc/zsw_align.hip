@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
                 return __hip_atomic_load(ring + (size_t)(rr % (int)a.W) * row_bytes + (size_t)(cc % (int)nv) * N + (size_t)(cc / (int)nv),
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
-            traceback_emit(a, id, item, len, rend, cend, best, cell);
+            traceback_emit(a, id, item, len, rend, cend, best, cell, (int)a.W);
         }
     }
 }
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(64) void align_kernel_x(AlignArgs a) {
                 return __hip_atomic_load(ring + (size_t)(rr % W) * row_bytes + (size_t)(cc / nv) * (size_t)NVQ * 4 + (size_t)(cc % nv),
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
-            traceback_emit(a, id, item, len, rend, cend, best, cell);
+            traceback_emit(a, id, item, len, rend, cend, best, cell, (int)a.W);
         }
     }
 }

@@ -37,12 +37,30 @@ struct AlignArgs {
 // span < L + L*maxw/gap_extend. Rows older than that bound cannot influence the rows whose flags are kept, so the recompute
 // may start that many rows before the first retained row with a zero state and still be bit-identical (gap_extend = 0: no
 // bound, start at row 0).
-__device__ __forceinline__ int warmup_rows(const int32_t* w, int S, int ge, int l_pad) {
-    if (ge <= 0) return 0x3fffffff;
+__device__ __forceinline__ int max_weight(const int32_t* w, int S) {
     int maxw = 0;
     for (int i = 0; i < S * S; ++i) maxw = max(maxw, w[i]);
+    return maxw;
+}
+
+__device__ __forceinline__ int warmup_rows(const int32_t* w, int S, int ge, int l_pad) {
+    if (ge <= 0) return 0x3fffffff;
+    const int maxw = max_weight(w, S);
     const long long b = (long long)l_pad + ((long long)l_pad * maxw) / ge + 2;
     return b > 0x3fffffff ? 0x3fffffff : (int)b;
+}
+
+// Rows of flags a read's traceback can visit, from its score. An alignment with d <= L diagonal steps and g > 0 deleted
+// reference bases scores at most d*maxw - gap_open - (g - 1)*gap_extend, so a read that scored `score` has
+// g <= (L*maxw - score - gap_open)/gap_extend + 1 and its walk spans at most L + g rows (+2: the terminating cell and the
+// row the walk looks at before it stops). A read with few edits keeps ~L rows of flags instead of the launch's window W.
+// The walk still checks the window it was given; a walk that leaves it falls back to the full-window rerun.
+__device__ __forceinline__ int flag_rows_needed(int W, int len, int maxw, int32_t score, int go, int ge) {
+    if (ge <= 0) return W;
+    long long g = ((long long)len * maxw - (long long)score - go) / ge + 1;
+    if (g < 0) g = 0;
+    const long long need = (long long)len + g + 2;
+    return need < W ? (int)need : W;
 }
 
 // bytes of one block's DP rows in the generic kernel: H, E (i32), residue codes and flags (u8) per vector and lane
@@ -68,7 +86,7 @@ __device__ __forceinline__ uint32_t read_len(const BatchDev& b, uint32_t id, uin
 // run by one lane per read. `cell(r, c)` returns the flag byte of DP cell (r, c) from the retained window.
 template <typename CellFn>
 __device__ __forceinline__ void traceback_emit(const AlignArgs& a, uint32_t id, uint32_t item, uint32_t len, int rend, int cend,
-                                               int32_t best, CellFn cell) {
+                                               int32_t best, CellFn cell, int window) {
     const uint64_t slot0 = a.pool_base + (uint64_t)(a.by_item ? item : id) * a.maxc;
     uint32_t* cig = a.cig + slot0;
     uint32_t ncig = 0, cur_op = 0, cur_inc = 0;
@@ -113,7 +131,7 @@ __device__ __forceinline__ void traceback_emit(const AlignArgs& a, uint32_t id, 
             if (!(cur_inc && cur_op == op)) ++n_nons;
             push(1, op);
             if (r > 0 && c > 0) {
-                if (r - 1 + (int)a.W <= rend) {  // the walk left the retained window
+                if (r - 1 + window <= rend) {  // the walk left the retained window
                     overflow = true;
                     break;
                 }

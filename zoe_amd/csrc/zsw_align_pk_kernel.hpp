@@ -107,6 +107,7 @@ __global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
     c.keep = li == 0 ? 0u : ~0u;
     asm volatile("v_mov_b32 %0, 0x10001" : "=v"(c.one));
     const long long warm = warmup_rows(a.sc->w, S, (int)c.ge, NV * N);
+    const int maxw = max_weight(a.sc->w, S);
     const size_t row_bytes = (size_t)N * NVQ * 4;
     const int W = (int)a.W;
     const uint32_t* plane = prof2 + lane;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
         // this lane group's two reads (halves 0 and 1 of every lane value)
         uint32_t id[2], len[2], item[2];
         uint64_t off[2];
-        int rend[2];
+        int rend[2], keep0[2], wrows[2];  // last row, first row whose flags the read keeps, rows kept
         int32_t best[2];
         bool active[2];
 #pragma unroll
@@ -134,6 +135,8 @@ __global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
             active[h] = valid && a.status[id[h]] == ZSW_STATUS_SOME && len[h] > 0 && (int)((len[h] + N - 1) / N) == NV;
             rend[h] = active[h] ? (int)a.ref_end[id[h]] - 1 : -1;
             best[h] = active[h] ? (int32_t)a.score[id[h]] : 0;
+            wrows[h] = flag_rows_needed(W, (int)len[h], maxw, best[h], (int)a.sc->gap_open, (int)c.ge);
+            keep0[h] = active[h] ? rend[h] - wrows[h] + 1 : 0x7fffffff;
         }
         // StripedProfile::new_unchecked (profile.rs:270-306): position q = v + lane*nv, padding scores 0 (the bias)
 #pragma unroll
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
         for (int v = 0; v < NV; ++v) st.H[v] = st.E[v] = 0;
         int cend[2] = {0x7fffffff, 0x7fffffff};
         int rmax_v = max(rend[0], rend[1]);
-        int rmin_v = min(active[0] ? rend[0] : 0x7fffffff, active[1] ? rend[1] : 0x7fffffff);
+        int rmin_v = min(keep0[0], keep0[1]);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             rmax_v = max(rmax_v, __shfl_xor(rmax_v, d, 64));
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
         }
         const int rmax = __builtin_amdgcn_readfirstlane(rmax_v);
         const int rmin = __builtin_amdgcn_readfirstlane(rmin_v);
-        const int rflag = (int)max(0ll, (long long)rmin - W + 1);  // first row whose flags some read of the wave keeps
-        const int r0 = (int)max(0ll, min((long long)rmin - (long long)W - warm, (long long)rmax));  // late start (warmup_rows)
+        const int rflag = max(0, rmin);  // first row whose flags some read of the wave keeps (rmin: the smallest keep0)
+        const int r0 = (int)max(0ll, min((long long)rmin - 1 - warm, (long long)rmax));  // late start (warmup_rows)
         uint8_t* ring0 = a.ring + ((size_t)blockIdx.x * RPW + (size_t)grp * 2) * (size_t)W * row_bytes;
         uint8_t* ring1 = ring0 + (size_t)W * row_bytes;
 
@@ -190,12 +193,12 @@ __global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
                     d0[vq] = __builtin_amdgcn_perm(x23, x01, 0x05040100u);  // read 0: the low halves
                     d1[vq] = __builtin_amdgcn_perm(x23, x01, 0x07060302u);  // read 1: the high halves
                 }
-                if (r <= rend[0] && r + W > rend[0]) {
+                if (r <= rend[0] && r >= keep0[0]) {
                     uint32_t* dst = reinterpret_cast<uint32_t*>(ring0 + (size_t)(r % W) * row_bytes) + (size_t)li * NVQ;
 #pragma unroll
                     for (int vq = 0; vq < NVQ; ++vq) dst[vq] = d0[vq];
                 }
-                if (r <= rend[1] && r + W > rend[1]) {
+                if (r <= rend[1] && r >= keep0[1]) {
                     uint32_t* dst = reinterpret_cast<uint32_t*>(ring1 + (size_t)(r % W) * row_bytes) + (size_t)li * NVQ;
 #pragma unroll
                     for (int vq = 0; vq < NVQ; ++vq) dst[vq] = d1[vq];
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
                     return __hip_atomic_load(ring + (size_t)(rr % W) * row_bytes + (size_t)(cc / NV) * (size_t)NVQ * 4 + (size_t)(cc % NV),
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 };
-                traceback_emit(a, id[h], item[h], len[h], rend[h], cend[h], best[h], cell);
+                traceback_emit(a, id[h], item[h], len[h], rend[h], cend[h], best[h], cell, wrows[h]);
             }
         }
     }
