@@ -1,8 +1,10 @@
 // zsw_group.hip — device-side grouping of the reads of an alignment call.
 //
 // Pass 2 of the alignment path runs one launch per <N lanes, nv vectors> instantiation and wants the reads of a launch
-// ordered by their reference end row (see zsw_align.hip). Both come from one radix sort of the composite key
-// (N, nv, ref_end) with the read index as value (hipCUB device radix sort — a utility step, not the hot path), followed
+// ordered by their reference end row and, among equal end rows, by score: the reads of a wavefront walk the reference rows
+// together, so their last rows should coincide, and the rows of flags a read keeps follow from its score
+// (flag_rows_needed, zsw_align_dev.hpp), so reads of similar score keep the same rows. Two stable radix sorts (hipCUB — a
+// utility step, not the hot path): by descending score, then by the composite key (N, packed/wide, nv, ref_end), followed
 // by a scan for the group boundaries. Only the small group table travels to the host.
 #include <hipcub/hipcub.hpp>
 
@@ -10,10 +12,19 @@
 
 namespace zsw {
 
-__global__ void group_keys_kernel(BatchDev b, const uint8_t* status, const uint8_t* tier, const uint32_t* ref_end, const uint32_t* score,
-                                  int lanes_w8, int lanes_w16, int lanes_w32, uint64_t* keys, uint32_t* vals) {
+__global__ void score_keys_kernel(uint32_t n, const uint8_t* status, const uint32_t* score, uint64_t* keys, uint32_t* vals) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.n_reads) return;
+    if (i >= n) return;
+    keys[i] = status[i] == ZSW_STATUS_SOME ? (uint64_t)(0xffffffffu - score[i]) : ~0ull;  // descending score
+    vals[i] = i;
+}
+
+// keys[j] for the read at position j of the score order (ids[j]); vals are the ids themselves
+__global__ void group_keys_kernel(BatchDev b, const uint32_t* ids, const uint8_t* status, const uint8_t* tier, const uint32_t* ref_end,
+                                  const uint32_t* score, int lanes_w8, int lanes_w16, int lanes_w32, uint64_t* keys) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= b.n_reads) return;
+    const uint32_t i = ids[j];
     uint64_t key = ~0ull;  // reads without an alignment sort to the end
     if (status[i] == ZSW_STATUS_SOME) {
         const uint32_t len = b.offsets ? (uint32_t)(b.offsets[i + 1] - b.offsets[i]) : b.fixed_len;
@@ -23,8 +34,7 @@ __global__ void group_keys_kernel(BatchDev b, const uint8_t* status, const uint8
         const uint64_t wide = score[i] > ALIGN_PK_MAX_SCORE ? 1u : 0u;
         key = ((uint64_t)N << 56) | (wide << 55) | ((uint64_t)(nv & 0x7fffffu) << 32) | ref_end[i];
     }
-    keys[i] = key;
-    vals[i] = i;
+    keys[j] = key;
 }
 
 __global__ void group_bounds_kernel(const uint64_t* sorted_keys, uint32_t n, uint32_t* table, uint32_t* table_count, uint32_t cap) {
@@ -56,9 +66,16 @@ hipError_t group_reads(const BatchDev& b, const uint8_t* d_status, const uint8_t
     const uint32_t n = b.n_reads;
     if (n == 0) return hipSuccess;
     const uint32_t grid = (n + 255) / 256;
-    hipLaunchKernelGGL(group_keys_kernel, dim3(grid), dim3(256), 0, stream, b, d_status, d_tier, d_ref_end, d_score, lanes_w8,
-                       lanes_w16, lanes_w32, keys_in, vals_in);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, items_out, (int)n, 0, 64, stream);
+    // 1. by descending score (32 key bits): items_out = read ids in that order
+    hipLaunchKernelGGL(score_keys_kernel, dim3(grid), dim3(256), 0, stream, n, d_status, d_score, keys_in, vals_in);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, items_out, (int)n, 0, 33, stream);
+    if (e != hipSuccess) return e;
+    // 2. stable sort of that order by (N, packed/wide, nv, ref_end): vals_in = final order, copied back to items_out
+    hipLaunchKernelGGL(group_keys_kernel, dim3(grid), dim3(256), 0, stream, b, items_out, d_status, d_tier, d_ref_end, d_score, lanes_w8,
+                       lanes_w16, lanes_w32, keys_in);
+    e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, items_out, vals_in, (int)n, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(items_out, vals_in, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(table_count, 0, 4, stream);
     if (e != hipSuccess) return e;
