@@ -121,9 +121,9 @@ static ZSW_PK_FN void lazy_rounds(const State<O, NV>& st, typename O::V Fend, co
 #pragma unroll 1
     for (int k = 0; k < N; ++k) {
         if (k) Fk = O::sub_sat(O::template shr1<N>(Fk, c.keep), c.nvge2);
-        // lanes that can still pass the test somewhere: Fk + go > P_{k-1}; reads that have left their loop take no part
-        const V am = nzmask<O>(O::sub_sat(O::add_sat(Fk, c.go2), Pb), one);
-        const V Fe = O::and_(O::and_(Fk, am), run);
+        // the test is Fk > Y(v) and Fk + go > P_{k-1}, i.e. Fk > max(Y(v), sat_sub(P_{k-1}, go)): a lane whose Fk does not exceed
+        // the second bound takes no part (Fe = 0 passes nowhere, Y >= 0). Reads that have left their loop carry Fk = 0.
+        const V Fe = O::mul(Fk, O::min_u(O::sub_sat(Fk, O::sub_sat(Pb, c.go2)), one));
         V m = O::splat(0);
 #pragma unroll
         for (int v = 0; v < NV; ++v) m = O::lshl_or(m, 1, O::min_u(O::sub_sat(Fe, Y[v]), one));
@@ -136,6 +136,7 @@ static ZSW_PK_FN void lazy_rounds(const State<O, NV>& st, typename O::V Fend, co
         Pb = O::bfi(upd, Pn, Pb);
         mfin = O::bfi(fin, m, mfin);
         run = upd;
+        Fk = O::and_(Fk, run);
         if (!O::any(run)) break;
     }
 }
@@ -164,7 +165,7 @@ static ZSW_PK_FN void fixup(State<O, NV>& st, typename O::V Pa, typename O::V Pb
         const V h = O::max_u(hm, M);
         st.H[v] = h;
         if constexpr (FLAGS) {
-            const V rs = O::min_u(O::sub_sat(O::add(M, one), O::max_u(hm, one)), one);  // 1 where M >= Hmain and M > 0
+            const V rs = O::sub_sat(O::min_u(M, one), O::sub(h, M));  // 1 where M >= Hmain (h == M) and M > 0
             V f = flg[v];
             const V fr = O::and_or(f, O::splat(UPX2), O::splat(LEFT2));
             f = O::mad(rs, O::sub(fr, f), f);
