@@ -310,6 +310,46 @@ def test_config5_mixed_lengths_30kb_reference(za, oracle, dna):
         assert (int(ends.status[i]), int(ends.score[i]), int(ends.ref_end[i]), int(ends.query_end[i])) == (st, s, re_, qe), i
 
 
+def test_config5_full_size_1m_mixed_reads_properties(za, oracle, dna, debug):
+    """BASELINE.json configs[4] at its full size (1 M reads of 75-400 bp vs a 30 kb reference, one launch per strip
+    configuration), through size-independent properties: the two independent kernels (v2 drift-domain / v1 saturating i16)
+    agree on every read, every length class is occupied, bounds hold, a second run is identical, and a random sample equals
+    the oracle."""
+    import torch
+
+    from zoe_amd import synth
+
+    ctx = za.SwContext.get(0)
+    ref = synth.reference_host(30000)
+    n = 1_000_000
+    rb = synth.reads_ragged_device(ctx, ref, 0, n, 75, 400)
+    lens = (rb.offsets[1:] - rb.offsets[:-1])
+    assert int(lens.min()) == 75 and int(lens.max()) == 400
+    prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
+    debug.set(0)
+    a = prof.sw_score_from_i8(ref)
+    s2, st2, t2 = a.score.clone(), a.status.clone(), a.tier.clone()
+    b = prof.sw_score_from_i8(ref)
+    assert torch.equal(b.score, s2) and torch.equal(b.status, st2)
+    debug.set(debug.SCORE_V1)
+    c = prof.sw_score_from_i8(ref)
+    debug.set(0)
+    assert torch.equal(c.score, s2) and torch.equal(c.status, st2) and torch.equal(c.tier, t2)  # v1 == v2 on all reads
+    assert int(s2.min()) >= 0 and bool((s2.to(torch.int64) <= 2 * lens).all())
+    assert torch.equal(st2 == 0, s2 > 0) and torch.equal(t2[st2 == 0] == 8, s2[st2 == 0] < 255)
+    sc = osc(oracle, dna, -10, -1)
+    rng = np.random.default_rng(9)
+    idx = np.sort(rng.choice(n, 400, replace=False))
+    off = rb.offsets.cpu().numpy()
+    bases = rb.bases.cpu().numpy()
+    sample = np.concatenate([bases[off[i] : off[i + 1]] for i in idx])
+    soff = np.concatenate([[0], np.cumsum([off[i + 1] - off[i] for i in idx])]).astype(np.uint64)
+    ws, wst, wt = oracle.batch_score_w256(8, sc, sample, ref, offsets=soff, threads=16)
+    sel = torch.from_numpy(idx).cuda()
+    assert np.array_equal(st2[sel].cpu().numpy(), wst) and np.array_equal(s2[sel].cpu().numpy().view(np.uint32), ws)
+    assert np.array_equal(t2[sel].cpu().numpy(), wt)
+
+
 def test_v1_and_v2_score_kernels_agree(za, oracle, dna, debug):
     """score_kernel_v2 (row-drifted domain + v_pk_maximum3_f16) and score_kernel (saturating packed i16) are both
     bit-exact: same 10k-read batch through each, scores / ends compared with the oracle."""
