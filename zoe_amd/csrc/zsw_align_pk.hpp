@@ -113,6 +113,9 @@ static ZSW_PK_FN void lazy_rounds(const State<O, NV>& st, typename O::V Fend, co
     V Y[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) Y[v] = O::add_sat(O::sub_sat(st.H[v], c.go2), vge2<O>(v, c.ge));
+    V Ymax = Y[0];  // a lane whose F exceeds it passes at every vector: the round is complete whatever the other lanes do
+#pragma unroll
+    for (int v = 1; v < NV; ++v) Ymax = O::max_u(Ymax, Y[v]);
     Pa = O::splat(0);
     Pb = O::splat(0);
     mfin = O::splat(ALL | (ALL << 16));  // never broke: every vector visited in every round
@@ -124,10 +127,16 @@ static ZSW_PK_FN void lazy_rounds(const State<O, NV>& st, typename O::V Fend, co
         // the test is Fk > Y(v) and Fk + go > P_{k-1}, i.e. Fk > max(Y(v), sat_sub(P_{k-1}, go)): a lane whose Fk does not exceed
         // the second bound takes no part (Fe = 0 passes nowhere, Y >= 0). Reads that have left their loop carry Fk = 0.
         const V Fe = O::mul(Fk, O::min_u(O::sub_sat(Fk, O::sub_sat(Pb, c.go2)), one));
-        V m = O::splat(0);
+        // Most rounds are carried by one lane whose F is far above everything in its segment (the F leaving the alignment's
+        // diagonal sweeps the lanes to its right): when every read that still runs has such a lane, the bit strings are all ones.
+        const V strong = nzmask<O>(O::template group_or<N>(O::sub_sat(Fe, Ymax)), one);
+        V m = O::and_(strong, O::splat(ALL | (ALL << 16)));
+        if (O::any(O::bfi(strong, O::splat(0), run))) {  // a running read without such a lane: one compare per cell
+            m = O::splat(0);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) m = O::lshl_or(m, 1, O::min_u(O::sub_sat(Fe, Y[v]), one));
-        m = O::template group_or<N>(m);
+            for (int v = 0; v < NV; ++v) m = O::lshl_or(m, 1, O::min_u(O::sub_sat(Fe, Y[v]), one));
+            m = O::template group_or<N>(m);
+        }
         const V brk = nzmask<O>(O::xor_(m, O::splat(ALL | (ALL << 16))), one);  // some vector without any lane passing
         const V Pn = O::max_u(Pb, Fk);
         const V fin = O::and_(run, brk);
