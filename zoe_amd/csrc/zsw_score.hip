@@ -605,7 +605,7 @@ __global__ void gtab_kernel(const uint8_t* ref, uint32_t n, const ScoringDev* sc
 
 template <int G, int C>
 static hipError_t launch_cfg_rev(const ScoreArgs& a, bool fast, hipStream_t stream) {
-    const uint32_t reads_per_block = BLOCK / G;
+    const uint32_t reads_per_block = 2 * (BLOCK / G);
     const uint32_t grid = (a.b.n_items + reads_per_block - 1) / reads_per_block;
     if (grid == 0) return hipSuccess;
     if (fast) hipLaunchKernelGGL((score_kernel<G, C, true, 2, true>), dim3(grid), dim3(BLOCK), 0, stream, a);

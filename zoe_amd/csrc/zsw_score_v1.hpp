@@ -36,8 +36,9 @@ struct ScoreArgs {
 // MODE 0: score; 1: score + ref_end; 2: score + ref_end + query_end
 // REV (with MODE 2): the second pass of sw_simd_score_ranges (striped.rs:355-388) — sw_simd_score_ends_reverse on
 // `reference[..ref_end]` with the profile of `reverse(read[..query_end])` (profile.rs:314-350). Every read has its own
-// reference prefix, so a lane carries ONE read (high half idle), takes its row table from HBM/L2 (gtab[ref_end-1-row])
-// and each wave runs only as many steps as its longest prefix needs. Outputs: ref_end/query_end receive the STARTS.
+// reference prefix: the two reads of a lane take their row tables separately from HBM/L2 (gtab[ref_end-1-row]; one v_perm per
+// half and a merge instead of one v_perm per column) and each wave runs only as many steps as its longest prefix needs.
+// Outputs: ref_end/query_end receive the STARTS.
 template <int G, int C, bool FAST, int MODE, bool REV = false, bool WIDE = false>
 __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreArgs a) {
     static_assert(!WIDE || (REV && FAST), "the WIDE table form exists for the reverse pass only (signed scores, no bias)");
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
     const int tid = threadIdx.x;
     const int g = tid & (G - 1);
     const uint32_t group = blockIdx.x * (BLOCK / G) + tid / G;
-    const uint32_t itemA = REV ? group : 2 * group, itemB = 2 * group + 1;
-    const bool validA = itemA < a.b.n_items, validB = !REV && itemB < a.b.n_items;
+    const uint32_t itemA = 2 * group, itemB = 2 * group + 1;
+    const bool validA = itemA < a.b.n_items, validB = itemB < a.b.n_items;
     const uint32_t idA = validA ? (a.b.items ? a.b.items[itemA] : itemA) : 0;
     const uint32_t idB = validB ? (a.b.items ? a.b.items[itemB] : itemB) : 0;
 
@@ -83,11 +84,13 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
             lenB = a.b.fixed_len;
         }
     }
-    int rev_re = 0;  // REV: this read's reference prefix length (forward ref_end) and query prefix length
+    int rev_reA = 0, rev_reB = 0;  // REV: the reads' reference prefix lengths (forward ref_end); lenA/lenB become the query prefixes
     if (REV) {
-        const uint32_t qe = validA ? a.rev_query_end[idA] : 0;
-        lenA = qe <= lenA ? qe : lenA;
-        rev_re = validA && lenA ? (int)a.rev_ref_end[idA] : 0;
+        const uint32_t qeA = validA ? a.rev_query_end[idA] : 0, qeB = validB ? a.rev_query_end[idB] : 0;
+        lenA = qeA <= lenA ? qeA : lenA;
+        lenB = qeB <= lenB ? qeB : lenB;
+        rev_reA = validA && lenA ? (int)a.rev_ref_end[idA] : 0;
+        rev_reB = validB && lenB ? (int)a.rev_ref_end[idB] : 0;
     }
 
     // per-column selectors: which table bytes v_perm picks for read A (low half) and read B (high half)
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
         const uint32_t q = (uint32_t)(g * C + c);
         uint32_t kA = PAD_K, kB = PAD_K;
         if (q < lenA) kA = lut[a.b.bases[REV ? offA + (lenA - 1 - q) : offA + q]];
-        if (q < lenB) kB = lut[a.b.bases[offB + q]];
+        if (q < lenB) kB = lut[a.b.bases[REV ? offB + (lenB - 1 - q) : offB + q]];
         uint32_t sA, sB;
         if (WIDE) {  // the residue itself: byte offset into the LDS table row
             sA = kA == PAD_K ? (uint32_t)WIDE_PAD : kA;
@@ -131,15 +134,18 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
     const int T = R + G - 1;
 
     // one DP row of this lane's strip; `w` = the row's table entry, `row` = its index (for the end tracking)
-    auto lookup = [&](const uint2 ww, const uint32_t sl) -> uint32_t {
+    // `ww`: the row's table entry for read A (REV: `wb` the one for read B — the reads walk different reference prefixes)
+    auto lookup = [&](const uint2 ww, const uint2 wb, const uint32_t sl) -> uint32_t {
         if constexpr (WIDE) {
-            const int sa = wt[ww.x + (sl & 0xffffu)], sb = wt[ww.x + (sl >> 16)];
+            const int sa = wt[ww.x + (sl & 0xffffu)], sb = wt[(REV ? wb.x : ww.x) + (sl >> 16)];
             return __builtin_amdgcn_perm((uint32_t)sb, (uint32_t)sa, 0x05040100u);
+        } else if constexpr (REV) {
+            return __builtin_amdgcn_perm(__builtin_amdgcn_perm(wb.y, wb.x, sl), __builtin_amdgcn_perm(ww.y, ww.x, sl), 0x07060100u);
         } else {
             return __builtin_amdgcn_perm(ww.y, ww.x, sl);
         }
     };
-    auto step = [&](const uint2 w, const int row) {
+    auto step = [&](const uint2 w, const uint2 wb, const int row) {
         uint32_t Fin = (uint32_t)__shfl_up((int)Fout, 1, G);
         uint32_t Hin = (uint32_t)__shfl_up((int)Hlast, 1, G);
         if (g == 0) {
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
         }
         // hd = H(r-1,c-1) + W(r,c) is formed one column ahead, so the previous row's H[c] is dead
         // before this row's H[c] is written (same register, no copy in the loop).
-        uint32_t hd = pk_adds(Hin_prev, lookup(w, sel[0]));
+        uint32_t hd = pk_adds(Hin_prev, lookup(w, wb, sel[0]));
         if (!FAST) hd = pk_subs(hd, bias2);
         Hin_prev = Hin;
         uint32_t F = Fin;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
         for (int c = 0; c < C; ++c) {
             uint32_t hd_next = 0;
             if (c + 1 < C) {
-                hd_next = pk_adds(H[c], lookup(w, sel[c + 1 < C ? c + 1 : c]));
+                hd_next = pk_adds(H[c], lookup(w, wb, sel[c + 1 < C ? c + 1 : c]));
                 if (!FAST) hd_next = pk_subs(hd_next, bias2);
             }
             if (MODE == 0) best = pk_max(best, hd);  // E, F never exceed an H already folded into best
@@ -201,17 +207,17 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
 #pragma unroll 1
             for (int t = base; t < tend; ++t) {
                 const uint2 wn = rp[REV ? 0 : t + 1 + joff];
-                step(w, t - g);
+                step(w, w, t - g);
                 w = wn;
             }
         }
     } else {
-        int tw = rev_re;
+        int tw = max(rev_reA, rev_reB);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) tw = max(tw, __shfl_xor(tw, d, 64));
         tw = tw ? tw + G - 1 : 0;  // steps of this wave: its longest reference prefix plus the strip skew
         const uint2 neutral = WIDE ? make_uint2(WIDE_NEUTRAL * WIDE_STRIDE, 0) : swt[NEUTRAL];
-        auto row_entry = [&](int row) {
+        auto row_entry = [&](int row, int rev_re) {
             const int rr = rev_re - 1 - row;
             return (row >= 0 && rr >= 0) ? a.gtab[rr] : neutral;
         };
@@ -219,20 +225,27 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
         // the FIRST row that holds the maximum: once a read's running maximum has reached the forward score, and every lane
         // of its group has walked past that row (G more steps), nothing later can change its answer. Checked every 8 steps;
         // the wave leaves when all of its reads are finished — about the alignment's own span instead of the whole prefix.
-        const int target = (validA && lenA) ? (int)a.rev_score[idA] - 32768 : 0x7fffffff;  // stored (offset) domain
-        int t_done = (validA && lenA && rev_re > 0) ? 0x3fffffff : -1000000;
-        uint2 w = row_entry(-g);
+        const int targetA = (validA && lenA) ? (int)a.rev_score[idA] - 32768 : 0x7fffffff;  // stored (offset) domain
+        const int targetB = (validB && lenB) ? (int)a.rev_score[idB] - 32768 : 0x7fffffff;
+        int t_doneA = (validA && lenA && rev_reA > 0) ? 0x3fffffff : -1000000;
+        int t_doneB = (validB && lenB && rev_reB > 0) ? 0x3fffffff : -1000000;
+        uint2 w = row_entry(-g, rev_reA), wb = row_entry(-g, rev_reB);
 #pragma unroll 1
         for (int t = 0; t < tw; ++t) {
-            const uint2 wn = row_entry(t + 1 - g);
-            step(w, t - g);
+            const uint2 wn = row_entry(t + 1 - g, rev_reA), wbn = row_entry(t + 1 - g, rev_reB);
+            step(w, wb, t - g);
             w = wn;
+            wb = wbn;
             if ((t & 7) == 7) {
-                int gm = (int)(int16_t)(best & 0xffffu);
+                int gmA = (int)(int16_t)(best & 0xffffu), gmB = (int)(int16_t)(best >> 16);
 #pragma unroll
-                for (int d = 1; d < G; d <<= 1) gm = max(gm, __shfl_xor(gm, d, G));
-                if (gm >= target && t_done > t) t_done = t;
-                if (__ballot(t < t_done + G) == 0) break;
+                for (int d = 1; d < G; d <<= 1) {
+                    gmA = max(gmA, __shfl_xor(gmA, d, G));
+                    gmB = max(gmB, __shfl_xor(gmB, d, G));
+                }
+                if (gmA >= targetA && t_doneA > t) t_doneA = t;
+                if (gmB >= targetB && t_doneB > t) t_doneB = t;
+                if (__ballot(t < max(t_doneA, t_doneB) + G) == 0) break;
             }
         }
     }
@@ -277,9 +290,9 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel(ScoreA
 
     // ---- outputs: regroup so that lane l of the wave owns the wave's l-th read (coalesced stores) ----
     const int lane = tid & 63;
-    constexpr int RW = REV ? 64 / G : 2 * (64 / G);  // reads per wave
-    const int src = REV ? lane * G : (lane >> 1) * G;  // first lane of the group that holds read `lane`
-    const bool hi = !REV && (lane & 1);
+    constexpr int RW = 2 * (64 / G);  // reads per wave
+    const int src = (lane >> 1) * G;  // first lane of the group that holds read `lane`
+    const bool hi = lane & 1;
     // both shuffles run with every lane active (a lane that sits out a divergent branch cannot be a shuffle source)
     auto pick = [&](int va, int vb) {
         const int xa = __shfl(va, src, 64), xb = __shfl(vb, src, 64);

@@ -43,9 +43,9 @@ hipError_t launch_tile_v2(const ScoreArgsV2& a, bool wide, int mode, hipStream_t
     return hipGetLastError();
 }
 
-// reverse pass of sw_simd_score_ranges for these alphabets (score_kernel<..., REV, WIDE>, one read per lane)
+// reverse pass of sw_simd_score_ranges for these alphabets (score_kernel<..., REV, WIDE>)
 hipError_t launch_cfg_rev_wide(const ScoreArgs& a, int G, int C, hipStream_t stream) {
-    const uint32_t reads_per_block = BLOCK / G;
+    const uint32_t reads_per_block = 2 * (BLOCK / G);
     const uint32_t grid = (a.b.n_items + reads_per_block - 1) / reads_per_block;
     if (grid == 0) return hipSuccess;
     switch (G * 100 + C) {
