@@ -403,3 +403,31 @@ def test_packed_and_32bit_alignment_kernels_agree(za, oracle, debug, N):
         assert a.key(i) == b.key(i), (N, i, len(reads[i]))
     for i in range(0, len(reads), 3):
         assert a.key(i) == okey(oracle.align("i16", N, sc, reads[i], ref)), (N, i)
+
+
+def test_scores_at_the_edge_of_the_packed_kernels_16_bit_lanes(za, oracle):
+    """align_kernel_pk keeps true scores in unsigned 16-bit halves and takes reads that scored at most 30,000; larger
+    scores form their own group for the 32-bit kernel. Extreme weights (match 127, gap penalties up to 127) put reads on
+    both sides of the limit into one batch; every CIGAR equals the oracle's at <i16, 16> (and <i32, 8> for the largest)."""
+    rng = np.random.default_rng(stable_seed("edge"))
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = bytes(rng.choice(alpha, 600))
+    for (ma, mi, go, ge) in ((127, -100, -127, -127), (127, -60, -90, -3), (120, -128, -10, -1)):
+        m = za.WeightMatrix.new_dna_matrix(ma, mi, b"N")
+        sc = osc(oracle, m, go, ge)
+        reads = []
+        for L in (225, 230, 234, 236, 237, 240, 250, 256):  # 236 x 127 = 29,972 <= 30,000 < 237 x 127
+            s0 = int(rng.integers(0, 600 - L))
+            r = bytearray(ref[s0 : s0 + L])
+            reads.append(bytes(r))
+            r2 = bytearray(r)
+            r2[L // 2] = ord("A") if r2[L // 2] != ord("A") else ord("C")
+            del r2[L // 3]
+            reads.append(bytes(r2))
+        got = za.StripedProfileBatch(reads, m, go, ge, "i16", 16).sw_align(za.SeqSrc.Reference(ref))
+        for i, rd in enumerate(reads):
+            assert got.key(i) == okey(oracle.align("i16", 16, sc, rd, ref)), (ma, mi, go, ge, i, len(rd))
+        assert max(int(got.records[i]["score"]) for i in range(len(reads))) > 30000
+        got32 = za.StripedProfileBatch(reads, m, go, ge, "i32", 8).sw_align(za.SeqSrc.Reference(ref))
+        for i, rd in enumerate(reads):
+            assert got32.key(i) == okey(oracle.align("i32", 8, sc, rd, ref)), (ma, mi, go, ge, i)
