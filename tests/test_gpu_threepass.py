@@ -160,3 +160,37 @@ def test_three_pass_with_a_25_letter_alphabet(za, oracle):
     for i, rd in enumerate(reads):
         want, tier, _ = oracle.cascade_align_3pass(8, 256, sc, rd, ref)
         assert got.key(i) == okey(want), i
+
+
+def test_long_reads_take_band_sized_slots(za, oracle):
+    """3 kb reads: the bounding box (9 MB of flags) is far beyond a first-launch slot, the banded attempts of reads with few
+    indels are not (rlen x (2*band + 1) bytes) and run there; a read with a 300-base deletion needs a wide band and goes to the
+    full-size rerun. Routes (how: 1 banded, 2 scalar) and alignments equal the oracle's."""
+    rng = np.random.default_rng(stable_seed("3pass-long"))
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = bytes(rng.choice(alpha, 9000))
+    m = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    go, ge = -10, -1
+    sc = osc(oracle, m, go, ge)
+    reads = []
+    for k in range(10):
+        s0 = int(rng.integers(0, 5500))
+        r = bytearray(ref[s0 : s0 + 3000])
+        for _ in range(6):
+            j = int(rng.integers(10, len(r) - 10))
+            t = rng.random()
+            if t < 0.4:
+                r[j] = int(rng.choice(alpha))
+            elif t < 0.7:
+                del r[j]
+            else:
+                r.insert(j, int(rng.choice(alpha)))
+        reads.append(bytes(r))
+    reads.append(ref[1000:2500] + ref[2800:4300])  # one 300-base deletion
+    got = za.StripedProfileBatch(reads, m, go, ge, "i32", 8).sw_align_3pass(za.SeqSrc.Reference(ref))
+    hows = set()
+    for i, rd in enumerate(reads):
+        want, how = oracle.align_3pass("i32", 8, sc, rd, ref)
+        hows.add(how)
+        assert got.key(i) == okey(want), (i, how)
+    assert 1 in hows

@@ -7,7 +7,8 @@
 //     it reproduces the score; else sw_scalar_align (scalar.rs:173-271) on the box;
 //   * the outer soft clips are then added exactly as the reference does (prepend_soft_clip / soft_clip merge with the inner
 //     alignment's own clips, three_pass.rs:85-92).
-// Flag bytes and the two DP rows of a read live in a per-thread slot of HBM scratch (a 150 x 160 box is 24 KB).
+// Flag bytes and the two DP rows of a read live in a per-thread slot of HBM scratch (a 150 x 160 box is 24 KB); a slot is
+// sized for the attempt in progress (band first), see the DP pass.
 #include "zsw_align.hpp"
 
 namespace zsw {
@@ -153,7 +154,13 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                 continue;
             }
         } else {
-            if (slot_need(rlen, qlen) > a.slot_bytes) {  // does not fit this launch's slots: larger-slot rerun
+            // The slot holds the two DP rows and the flag bytes of the attempt in progress: rlen * (2*band + 1) for a banded
+            // attempt, rlen * qlen only for the scalar fallback. An attempt that does not fit sends the read to the rerun with
+            // full-size slots (which starts over and takes the same decisions), so long reads with few indels — a narrow
+            // band — are served by this launch's many small slots instead of a handful of box-sized ones.
+            const uint64_t rows_bytes = ((8ull * qlen + 15) & ~15ull) + 32;
+            bool too_big = rows_bytes > a.slot_bytes;
+            if (too_big) {
                 const uint32_t k = atomicAdd(a.fb_count, 1u);
                 a.fb_list[k] = id;
                 continue;
@@ -171,6 +178,10 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
             while (!have && band <= max_band) {
                 // sw_banded_align (banded.rs:40-133)
                 const uint32_t full = 2 * band + 1;
+                if (rows_bytes + (uint64_t)rlen * full > a.slot_bytes) {
+                    too_big = true;
+                    break;
+                }
                 for (uint32_t c = 0; c < qlen; ++c) {
                     h_row[c] = 0;
                     e_row[c] = go;
@@ -232,6 +243,12 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                     }
                 }
                 if (!have) band *= 2;
+            }
+            if (!have && !too_big && rows_bytes + (uint64_t)rlen * qlen > a.slot_bytes) too_big = true;
+            if (too_big) {
+                const uint32_t k = atomicAdd(a.fb_count, 1u);
+                a.fb_list[k] = id;
+                continue;
             }
             if (!have) {
                 // sw_scalar_align on the box (scalar.rs:173-271)
