@@ -15,6 +15,9 @@ LIB = os.path.join(HERE, "libzoe_sw_hip.so")
 SOURCES = ["zsw_capi.hip", "zsw_score.hip", "zsw_align.hip", "zsw_align_pk8.hip", "zsw_align_pk16.hip", "zsw_align_pk32.hip", "zsw_align_pk64.hip", "zsw_group.hip", "zsw_threepass.hip", "zsw_filter.hip", "zsw_score_wide.hip", "zsw_score_w32.hip", "zsw_multi.hip"]
 HEADERS = ["zsw_internal.hpp", "zsw_align_dev.hpp", "zsw_align_pk.hpp", "zsw_align_pk_kernel.hpp", "zsw_score_v1.hpp", "zsw_score_v2.hpp", "zsw_align.hpp", "zsw_timer.hpp", "zsw_synth.h", os.path.join("..", "..", "include", "zoe_sw.h")]
 ARCH = "gfx950"
+# per-file code generation flags. Measured and rejected for zsw_align_pk*.hip: -mllvm -amdgpu-sched-strategy=max-ilp
+# (s_nop between dependent packed instructions 206 -> 92 in the <16,10> kernel, but 190 VGPRs = two waves per SIMD: 46 instead of 41 ms)
+EXTRA_FLAGS = {}
 
 
 def _hipcc() -> str:
@@ -43,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             continue
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+               "-Wall", "-Wno-unused-function", "-Wno-unused-result"] + EXTRA_FLAGS.get(s, [])
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
