@@ -4,7 +4,7 @@
 // plain-C meaning of the gfx950 instruction the device build uses (v_pk_*_u16/i16, v_lshl_or_b32, v_bfi_b32, DPP shifts),
 // so the kernel's arithmetic runs on the CPU exactly as written and is compared, cell by cell and row by row, with the
 // oracle's literal restatement of sw_simd_align (oracle/zoe_oracle.hpp, flags_out): 2*64/N different reads per "wavefront"
-// (different lengths with equal nv, different last rows), all N, all nv <= 16, random scoring schemes, and with the first
+// (different lengths with equal nv, different last rows), all N, vector counts 1..32, random scoring schemes, and with the first
 // rows run through the flag-less scan path. Exit code 0 = identical everywhere.
 #include <cstdint>
 #include <cstdio>
@@ -237,7 +237,7 @@ template <int N>
 bool check_all_nv(std::mt19937_64& rng, int iter) {
     return check<N, 1>(rng, iter) && check<N, 2>(rng, iter) && check<N, 3>(rng, iter) && check<N, 4>(rng, iter) &&
            check<N, 5>(rng, iter) && check<N, 7>(rng, iter) && check<N, 10>(rng, iter) && check<N, 13>(rng, iter) &&
-           check<N, 16>(rng, iter);
+           check<N, 16>(rng, iter) && check<N, 17>(rng, iter) && check<N, 25>(rng, iter) && check<N, 32>(rng, iter);
 }
 
 }  // namespace
@@ -249,6 +249,6 @@ int main(int argc, char** argv) {
         if (!check_all_nv<8>(rng, it) || !check_all_nv<16>(rng, it) || !check_all_nv<32>(rng, it) || !check_all_nv<64>(rng, it) ||
             !check_all_nv<4>(rng, it) || !check_all_nv<2>(rng, it))
             return 1;
-    printf("packed row update (zsw_align_pk.hpp) == oracle flags on %d x 6 lane counts x 9 vector counts x 2 runs\n", iters);
+    printf("packed row update (zsw_align_pk.hpp) == oracle flags on %d x 6 lane counts x 12 vector counts x 2 runs\n", iters);
     return 0;
 }

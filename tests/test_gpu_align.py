@@ -368,7 +368,7 @@ def test_profiles_too_long_for_lds_keep_their_rows_in_hbm(za, oracle):
 def test_packed_and_32bit_alignment_kernels_agree(za, oracle, debug, N):
     """align_kernel_pk (two reads per lane group in 16-bit halves, lazy-F in closed form; the default for up to 16 vectors)
     and align_kernel_x / align_kernel (one read per lane group, Zoe's loop step by step) give identical records and CIGARs
-    for every read of a ragged batch that covers every vector count 1..16 and beyond (17.. go to the 32-bit kernels either
+    for every read of a ragged batch that covers every vector count 1..32 and beyond (33.. go to the 32-bit kernels either
     way), and both equal the oracle at the same <i16, N>."""
     rng = np.random.default_rng(stable_seed("pk", N))
     alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -378,7 +378,7 @@ def test_packed_and_32bit_alignment_kernels_agree(za, oracle, debug, N):
     sc = osc(oracle, m, go, ge)
     reads = []
     for k in range(700):
-        L = int(rng.integers(1, min(18 * N, 700)))
+        L = int(rng.integers(1, min(34 * N, 700)))
         s = int(rng.integers(0, 900 - L)) if L < 900 else 0
         r = bytearray(ref[s : s + L])
         for _ in range(int(rng.integers(0, 2 + L // 25))):

@@ -658,7 +658,7 @@ static size_t align_pk_lds(uint32_t nv, int S) { return (size_t)S * nv * 64 * 4 
 
 bool align_pk_supported(int N, uint32_t nv, int S) {
     // at least two wavefronts' profiles per CU
-    return (N == 8 || N == 16 || N == 32 || N == 64) && nv >= 1 && nv <= 16 && align_pk_lds(nv, S) <= 72 * 1024;
+    return (N == 8 || N == 16 || N == 32 || N == 64) && nv >= 1 && nv <= 32 && align_pk_lds(nv, S) <= 72 * 1024;
 }
 
 uint32_t align_pk_grid(int N, uint32_t nv, int S, uint32_t count, uint32_t cu_count) {

@@ -18,7 +18,7 @@ hipError_t align_finalize(zsw_alignment* d_aln, const uint8_t* d_status, uint32_
                           uint32_t* out_inc, uint8_t* out_op, uint64_t cap, bool count_only, hipStream_t stream);
 
 // The packed kernel (zsw_align_pk_kernel.hpp): two reads per lane group in 16-bit halves. It takes groups of 8..64 lanes and
-// up to 16 vectors whose striped profile fits LDS, and reads whose score leaves head-room below 2^15 for Y = H - go + v*ge.
+// up to 32 vectors whose striped profile fits LDS, and reads whose score stays below 2^15 with head-room (signed packed max).
 constexpr uint32_t ALIGN_PK_MAX_SCORE = 30000;
 bool align_pk_supported(int N, uint32_t nv, int S);
 uint32_t align_pk_grid(int N, uint32_t nv, int S, uint32_t count, uint32_t cu_count);  // blocks that fill the chip once

@@ -102,14 +102,23 @@ static ZSW_PK_FN void main_pass(State<O, NV>& st, const typename O::V (&p)[NV], 
     Fend = F;
 }
 
+// Bit strings over the vectors, 16 per register half: chunk j holds vectors 16*j .. 16*j + bits(j) - 1, first vector in the
+// highest used bit.
+template <int NV>
+struct Chunks {
+    static constexpr int NM = (NV + 15) / 16;
+    static constexpr int bits(int j) { return j + 1 < NM ? 16 : NV - 16 * (NM - 1); }
+    static constexpr uint32_t all(int j) { return ((1u << bits(j)) - 1u) * ONE2; }
+};
+
 // Break position of the lazy-F loop. Fend must be 0 in the halves of reads that are past their last row.
-// Returns Pa = P_kb, Pb = P_{kb-1} and, per half, the bit string of the breaking round (bit NV-1-v set: vector v visited).
+// Returns Pa = P_kb, Pb = P_{kb-1} and, per half, the bit strings of the breaking round (set: vector visited).
 template <class O, int N, int NV>
 static ZSW_PK_FN void lazy_rounds(const State<O, NV>& st, typename O::V Fend, const Consts<O, NV>& c, typename O::V& Pa,
-                               typename O::V& Pb, typename O::V& mfin) {
+                               typename O::V& Pb, typename O::V (&mfin)[Chunks<NV>::NM]) {
     using V = typename O::V;
+    using CH = Chunks<NV>;
     const V one = c.one;
-    constexpr uint32_t ALL = (1u << NV) - 1u;
     V Y[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) Y[v] = O::add_sat(O::sub_sat(st.H[v], c.go2), vge2<O>(v, c.ge));
@@ -118,7 +127,8 @@ static ZSW_PK_FN void lazy_rounds(const State<O, NV>& st, typename O::V Fend, co
     for (int v = 1; v < NV; ++v) Ymax = O::max_u(Ymax, Y[v]);
     Pa = O::splat(0);
     Pb = O::splat(0);
-    mfin = O::splat(ALL | (ALL << 16));  // never broke: every vector visited in every round
+#pragma unroll
+    for (int j = 0; j < CH::NM; ++j) mfin[j] = O::splat(CH::all(j));  // never broke: every vector visited in every round
     V run = O::splat(0xffffffffu);
     V Fk = O::template shr1<N>(Fend, c.keep);
 #pragma unroll 1
@@ -130,33 +140,51 @@ static ZSW_PK_FN void lazy_rounds(const State<O, NV>& st, typename O::V Fend, co
         // Most rounds are carried by one lane whose F is far above everything in its segment (the F leaving the alignment's
         // diagonal sweeps the lanes to its right): when every read that still runs has such a lane, the bit strings are all ones.
         const V strong = nzmask<O>(O::template group_or<N>(O::sub_sat(Fe, Ymax)), one);
-        V m = O::and_(strong, O::splat(ALL | (ALL << 16)));
-        if (O::any(O::bfi(strong, O::splat(0), run))) {  // a running read without such a lane: one compare per cell
-            m = O::splat(0);
+        V m[CH::NM];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) m = O::lshl_or(m, 1, O::min_u(O::sub_sat(Fe, Y[v]), one));
-            m = O::template group_or<N>(m);
+        for (int j = 0; j < CH::NM; ++j) m[j] = O::and_(strong, O::splat(CH::all(j)));
+        if (O::any(O::bfi(strong, O::splat(0), run))) {  // a running read without such a lane: one compare per cell
+#pragma unroll
+            for (int j = 0; j < CH::NM; ++j) {
+                V x = O::splat(0);
+#pragma unroll
+                for (int v = 16 * j; v < 16 * j + CH::bits(j); ++v) x = O::lshl_or(x, 1, O::min_u(O::sub_sat(Fe, Y[v]), one));
+                m[j] = O::template group_or<N>(x);
+            }
         }
-        const V brk = nzmask<O>(O::xor_(m, O::splat(ALL | (ALL << 16))), one);  // some vector without any lane passing
+        V diff = O::xor_(m[0], O::splat(CH::all(0)));
+#pragma unroll
+        for (int j = 1; j < CH::NM; ++j) diff = O::and_or(O::xor_(m[j], O::splat(CH::all(j))), O::splat(0xffffffffu), diff);
+        const V brk = nzmask<O>(diff, one);  // some vector without any lane passing
         const V Pn = O::max_u(Pb, Fk);
         const V fin = O::and_(run, brk);
         const V upd = O::xor_(run, fin);
         Pa = O::bfi(run, Pn, Pa);
         Pb = O::bfi(upd, Pn, Pb);
-        mfin = O::bfi(fin, m, mfin);
+#pragma unroll
+        for (int j = 0; j < CH::NM; ++j) mfin[j] = O::bfi(fin, m[j], mfin[j]);
         run = upd;
         Fk = O::and_(Fk, run);
         if (!O::any(run)) break;
     }
 }
 
-// per half: number of leading ones of the NV-bit string (bit NV-1 first) = vectors visited in the breaking round
+// per half: vectors visited in the breaking round = leading ones of the concatenated bit strings
 template <class O, int NV>
-static ZSW_PK_FN typename O::V visited(typename O::V mfin) {
+static ZSW_PK_FN typename O::V visited(const typename O::V (&mfin)[Chunks<NV>::NM]) {
     using V = typename O::V;
-    const V lo = O::lead_ones(O::and_(mfin, O::splat(0xffffu)), NV);
-    const V hi = O::lead_ones(O::shr(mfin, 16), NV);
-    return O::lshl_or(hi, 16, lo);
+    using CH = Chunks<NV>;
+    V total = O::splat(0);
+    V open = O::splat(ONE2);  // 1 while every earlier chunk was all ones
+#pragma unroll
+    for (int j = 0; j < CH::NM; ++j) {
+        const V lo = O::lead_ones(O::and_(mfin[j], O::splat(0xffffu)), CH::bits(j));
+        const V hi = O::lead_ones(O::shr(mfin[j], 16), CH::bits(j));
+        const V n = O::lshl_or(hi, 16, lo);
+        total = O::mad(open, n, total);
+        if (j + 1 < CH::NM) open = O::mul(open, O::sub_sat(O::add(n, O::splat(ONE2)), O::splat((uint32_t)CH::bits(j) * ONE2)));  // stays 1 iff n == bits(j)
+    }
+    return total;
 }
 
 // H and the flags after the lazy-F loop (striped.rs:528-553 in closed form, see the header).
@@ -210,7 +238,7 @@ static ZSW_PK_FN void row(State<O, NV>& st, const typename O::V (&p)[NV], typena
     main_pass<O, N, NV, FLAGS>(st, p, c, Fend, flg);
     Fend = O::and_(Fend, act2);
     if constexpr (FLAGS) {
-        V Pa, Pb, mfin;
+        V Pa, Pb, mfin[Chunks<NV>::NM];
         lazy_rounds<O, N, NV>(st, Fend, c, Pa, Pb, mfin);
         next_row();
         if (O::any(Pa)) fixup<O, N, NV, true>(st, Pa, Pb, visited<O, NV>(mfin), c, flg);

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
     __shared__ uint8_t lut[256];
     constexpr int RPW = 2 * 64 / N;
     constexpr int NVQ = (NV + 3) / 4;
+    constexpr bool PREFETCH = NV <= 16;  // the next row's profile dwords in a second register set
     const int lane = threadIdx.x;
     const int li = lane % N, grp = lane / N;
     const int S = a.sc->S;
@@ -175,13 +176,19 @@ __global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
             uint32_t pc[NV], flg[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) pc[v] = p[v];
-            {  // the next row's profile dwords travel while this row computes
+            if constexpr (PREFETCH) {  // the next row's profile dwords travel while this row computes
                 const uint32_t* nrow = plane + next_off;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) p[v] = nrow[v * 64];
             }
             const uint32_t act2 = (r <= rend[0] ? 0xffffu : 0u) | (r <= rend[1] ? 0xffff0000u : 0u);
-            zsw_pk::row<O, N, NV, FLAGS>(st, pc, act2, c, flg, [] {});
+            zsw_pk::row<O, N, NV, FLAGS>(st, pc, act2, c, flg, [&]() __attribute__((always_inline)) {
+                if constexpr (!PREFETCH) {  // more than 16 vectors: no second register set, the row's scores are loaded once they are dead
+                    const uint32_t* nrow = plane + next_off;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) p[v] = nrow[v * 64];
+                }
+            });
             if constexpr (FLAGS) {
                 // one byte per cell and read: bytes 4*vq .. 4*vq+3 of the lane's row slice
                 uint32_t d0[NVQ], d1[NVQ], fp[NVQ * 4];
@@ -280,7 +287,9 @@ static hipError_t pk_launch(const AlignArgs& a, uint32_t grid, size_t lds, hipSt
     return hipGetLastError();
 }
 
-#define ZSW_PK_FOR_NV(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#define ZSW_PK_FOR_NV(X)                                                                                                  \
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) \
+    X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 
 template <int N>
 static hipError_t pk_occupancy_n(uint32_t nv, size_t lds, int* out) {

@@ -653,7 +653,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
         return W ? W : 1u;
     };
     // the packed kernel (two reads per lane group, zsw_align_pk_kernel.hpp) answers the groups it covers; the 32-bit kernels
-    // take scores beyond 16-bit lanes, more than 16 vectors, large alphabets and the full-window reruns
+    // take scores beyond 16-bit lanes, more than 32 vectors, large alphabets and the full-window reruns
     auto packed = [&](const GroupRun& g, bool full) {
         return !full && !g.wide && !(ctx->debug & ZSW_DEBUG_ALIGN_NO_PACKED) && align_pk_supported(g.N, g.nv, S);
     };
