@@ -19,7 +19,7 @@ def _build(tmp_path, name):
 def test_closed_form_lazy_f_equals_the_literal_loop(tmp_path, seed):
     """T = (round, vector) of the loop's break from per-round bit strings, flags and H from M(v, lane): identical striped
     backtrack matrices for N = 2..64, ten scoring schemes (gap_open = 0, gap_extend = 0 and equal gaps among them)."""
-    out = subprocess.run([_build(tmp_path, "align_closed_form"), "120", str(seed)], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([_build(tmp_path, "align_closed_form"), "80", str(seed)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
 
 
@@ -27,5 +27,5 @@ def test_closed_form_lazy_f_equals_the_literal_loop(tmp_path, seed):
 def test_packed_row_update_twin_equals_the_oracle(tmp_path, seed):
     """zsw_align_pk.hpp compiled for the host (64 explicit lanes, the plain-C meaning of each gfx950 instruction): 2*64/N reads
     per wavefront with different lengths and last rows, the first rows through the flag-less scan path."""
-    out = subprocess.run([_build(tmp_path, "align_pk_twin"), "6", str(seed)], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([_build(tmp_path, "align_pk_twin"), "3", str(seed)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
