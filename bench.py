@@ -34,8 +34,8 @@ ALGO_BYTES_PER_READ = READ_LEN + 4  # read bytes in + u32 score out (SURVEY.md Â
 # HBM bytes per read measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 fetch correction):
 # 1.500 GB read + 0.060 GB written per 10 M-read launch (status and tier bytes included). A CONSTANT from that profile,
 # not a measurement of this run (the bench line says so).
-PMC_HBM_BYTES_PER_READ = 156.0
-PMC_PROFILE = "profiles/r01_score_v2_final_summary.txt"
+PMC_HBM_BYTES_PER_READ = 159.4
+PMC_PROFILE = "profiles/r02_score_v2_summary.txt"  # 1.534 GB read + 0.060 GB written per 10 M-read launch (r01: 1.500 + 0.060)
 VALU_PEAK_SOURCE = "profiles/r01_valu_issue_rates_ubench.txt"  # this repo's micro-benchmark (tools/ubench.hip), not a figure of the guide
 TOTAL_READS_MULTI_GPU = 500_000_000  # BASELINE.json configs[3]
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
@@ -456,7 +456,7 @@ def main():
                 "traffic": PMC_HBM_BYTES_PER_READ * n_local / per_launch_s / 1e9 if per_launch_s > 0 else None,
                 "traffic_bytes_per_launch": PMC_HBM_BYTES_PER_READ * n_local,
                 "traffic_measured_in_this_run": False,
-                "traffic_source": "constant 156 B/read from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of the same kernel and workload: " + file_tag(PMC_PROFILE),
+                "traffic_source": "constant 159.4 B/read from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of the same kernel and workload: " + file_tag(PMC_PROFILE),
                 "kernel": "zsw::score_kernel_v2<4,38,0>",
                 "kernel_ms": per_launch_s * 1e3,
                 "kernel_ms_source": "HIP events recorded around the kernel on its stream, inside this run",
