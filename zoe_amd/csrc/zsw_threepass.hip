@@ -49,7 +49,8 @@ __device__ __forceinline__ uint32_t tp_read_len(const BatchDev& b, uint32_t id, 
     return b.fixed_len;
 }
 
-__device__ __forceinline__ uint64_t slot_need(uint32_t rlen, uint32_t qlen) { return (uint64_t)rlen * qlen + 8ull * qlen + 32; }
+// bytes of a slot that holds the two DP rows (16-byte aligned) and the flag bytes of the scalar alignment of the whole box
+__device__ __forceinline__ uint64_t slot_need(uint32_t rlen, uint32_t qlen) { return (uint64_t)rlen * qlen + ((8ull * qlen + 15) & ~15ull) + 32; }
 
 // BackTrackable::to_alignment (backtrack.rs:290-342) over a cell functor; emits into `w` in traceback order, including the outer
 // clips of three_pass.rs:85-92. Returns false when the reference would index outside its banded matrix.
