@@ -194,3 +194,31 @@ def test_long_reads_take_band_sized_slots(za, oracle):
         hows.add(how)
         assert got.key(i) == okey(want), (i, how)
     assert 1 in hows
+
+
+def test_box_sized_rerun_slot_counts_the_row_padding(za, oracle):
+    """Regression (found by tools/fuzz_gpu.py): the rerun's slots are sized from the largest box; the two DP rows are
+    16-byte aligned inside a slot, so an odd query range needs 8 bytes more than rlen*qlen + 8*qlen + 32. Boxes are chosen
+    so that the unpadded size, rounded to the launch's 64-byte slot granularity, would be too small."""
+    rng = np.random.default_rng(stable_seed("3pass-pad"))
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = bytes(rng.choice(alpha, 1500))
+    m = za.WeightMatrix.new_dna_matrix(3, -4, b"N")
+    go, ge = -5, 0  # free extension: one long deletion inside the alignment
+    sc = osc(oracle, m, go, ge)
+    picks = []
+    for gap in range(500, 900):
+        for b1 in range(40, 70):
+            qlen, rlen = 2 * b1 + 1, 2 * b1 + 1 + gap
+            old = rlen * qlen + 8 * qlen + 32
+            new = rlen * qlen + ((8 * qlen + 15) & ~15) + 32
+            if (old + 63) // 64 * 64 < new and rlen * qlen > 96 * 1024:
+                picks.append((b1, gap))
+        if len(picks) >= 3:
+            break
+    assert picks
+    reads = [ref[100 : 100 + b1] + ref[100 + b1 + gap : 100 + b1 + gap + b1 + 1] for b1, gap in picks[:3]]
+    got = za.StripedProfileBatch(reads, m, go, ge, "i16", 16).sw_align_3pass(za.SeqSrc.Reference(ref))
+    for i, rd in enumerate(reads):
+        want, how = oracle.align_3pass("i16", 16, sc, rd, ref)
+        assert got.key(i) == okey(want), (i, how, picks[i])
