@@ -279,9 +279,12 @@ class SwGroup:
         self.h = h
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             self.lib.zsw_group_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        self.close()
 
     def check(self, rc: int):
         if rc == 0:

@@ -920,7 +920,10 @@ zsw_error zsw_create(int device_id, zsw_context** out) {
         g_create_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950";
         return ZSW_ERR_NO_DEVICE;
     }
-    e = hipSetDevice(device_id);
+    int prev_device = -1;
+    (void)hipGetDevice(&prev_device);
+    e = hipSetDevice(device_id);  // fails here, not in the first batch call, if the device cannot be used
+    if (prev_device >= 0 && prev_device != device_id) (void)hipSetDevice(prev_device);  // the caller's current device stays
     if (e != hipSuccess) {
         g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
         return ZSW_ERR_NO_DEVICE;

@@ -69,6 +69,17 @@ struct zsw_group {
 
 namespace {
 
+// puts the calling thread's current device back when a call that visited the group's devices returns
+struct RestoreDevice {
+    int prev = -1;
+    RestoreDevice() {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    }
+    ~RestoreDevice() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 zsw_error gfail(zsw_group* g, zsw_error code, const std::string& what) {
     if (g) g->err = what;
     return code;
@@ -194,6 +205,7 @@ zsw_error zsw_group_score_batch_from_device(zsw_group* g, const zsw_batch* shard
     if (!g) return ZSW_ERR_INVALID_ARGUMENT;
     if (!shards || !out_score || !out_status) return gfail(g, ZSW_ERR_INVALID_ARGUMENT, "null argument");
     const int G = (int)g->ctx.size();
+    RestoreDevice restore;
     std::vector<uint64_t> first((size_t)G + 1, 0);
     for (int i = 0; i < G; ++i) {
         if (shards[i].mem != ZSW_MEM_DEVICE || !out_score[i] || !out_status[i])
