@@ -246,10 +246,11 @@ def test_align_degenerate_batches(za, oracle):
     assert s.score.numel() == 0
 
 
-def test_config3_large_batch_properties(za, oracle):
+def test_config3_large_batch_properties(za, oracle, debug):
     """BASELINE.json configs[2] at its full size (10 M reads x 150 bp vs 2 kb, full traceback), through size-independent properties: every CIGAR consumes exactly the
     read and its reference range, scores and ends agree with the (independent) score+ends kernel for every read, and a
-    random sample is bit-identical to the oracle and re-scores to its own score."""
+    random sample is bit-identical to the oracle and re-scores to its own score; the first 2 M reads are also aligned by the
+    32-bit step-by-step kernel, which must give the same records and the same ciglet arrays for every one of them."""
     import torch
 
     from zoe_amd import synth
@@ -284,10 +285,23 @@ def test_config3_large_batch_properties(za, oracle):
     assert (inc > 0).all() and set(np.unique(op)) <= set(b"MIDS")
     same_owner = owner[1:] == owner[:-1]
     assert not (same_owner & (op[1:] == op[:-1])).any()
+    # the two independent pass-2 kernels (packed, closed-form lazy-F / 32-bit, Zoe's loop step by step) on the first 2 M reads
+    m2 = 2_000_000
+    sub = za.ReadBatch.from_fixed(rb.bases[: m2 * 150], 150)
+    p2 = za.into_local_profile(sub, dna, -10, -1)
+    debug.set(0)
+    x = p2.sw_align_from_i8(za.SeqSrc.Reference(ref))
+    debug.set(debug.ALIGN_NO_PACKED)
+    y = p2.sw_align_from_i8(za.SeqSrc.Reference(ref))
+    debug.set(0)
+    assert np.array_equal(x.status, y.status) and np.array_equal(x.records, y.records)
+    assert np.array_equal(x.inc, y.inc) and np.array_equal(x.op, y.op)
+    assert np.array_equal(x.records, rec[:m2]) and np.array_equal(x.inc, a.inc[: len(x.inc)])
+    del x, y, p2, sub
     # sample vs oracle + sw_score_from_path
     sc = osc(oracle, dna, -10, -1)
     rng = np.random.default_rng(4)
-    idx = np.sort(rng.choice(n, 1500, replace=False))
+    idx = np.sort(rng.choice(n, 3000, replace=False))
     host = rb.bases.view(n, 150)[torch.from_numpy(idx).cuda()].cpu().numpy()
     for k, i in enumerate(idx):
         want, tier = oracle.cascade_align(8, 256, sc, host[k], ref)
