@@ -85,7 +85,7 @@ struct DevOps {
 };
 
 template <int N, int NV>
-__global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
+__global__ __launch_bounds__(64, NV <= 10 ? 3 : 1) void align_kernel_pk(AlignArgs a) {
     using O = DevOps;
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ uint8_t lut[256];
@@ -251,15 +251,127 @@ __global__ __launch_bounds__(64) void align_kernel_pk(AlignArgs a) {
         __threadfence_block();  // this wave's ring stores are visible to its own traceback loads
 
         // lane 0 of the group walks read 0, lane 1 read 1
-        if (li < 2) {
-            const int h = li;
-            if (active[h]) {
-                const uint8_t* ring = h ? ring1 : ring0;
-                auto cell = [&](int rr, int cc) -> uint32_t {
-                    return __hip_atomic_load(ring + (size_t)(rr % W) * row_bytes + (size_t)(cc / NV) * (size_t)NVQ * 4 + (size_t)(cc % NV),
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                };
-                traceback_emit(a, id[h], item[h], len[h], rend[h], cend[h], best[h], cell, wrows[h]);
+        // ---- traceback (backtrack.rs:290-342), one walker lane per read, helped by the other lanes of its group ----
+        // Lanes 0 and 1 of a group walk reads 0 and 1. A walk is a chain of dependent loads from the flag ring (HBM / L2: most
+        // of a microsecond each), and nearly all of its steps are diagonal, so the group's lanes fetch the walker's current
+        // cell and the N/2 - 1 cells up-left of it in ONE round trip (lane 2k+h loads the cell k steps up the diagonal of
+        // read h); the walker consumes them while its steps stay on that diagonal and asks for a new batch after a gap step
+        // or after N/2 steps. Same decisions, same order, same ciglets as traceback_emit (zsw_align_dev.hpp).
+        {
+            constexpr int KB = N / 2;                 // cells per batch and read
+            const int h = li & 1, kk = li >> 1;       // this lane helps read h with the cell kk steps up the diagonal
+            const int grp0 = lane - li;               // first lane of the group
+            const bool walker = li < 2 && active[h];  // (li < 2: h == li)
+            const uint8_t* ringh = h ? ring1 : ring0;
+            const uint32_t idw = id[h], lenw = len[h];
+            const int rendw = rend[h], window = wrows[h];
+            uint32_t* cig = a.cig + a.pool_base + (uint64_t)(a.by_item ? item[h] : idw) * a.maxc;
+            uint32_t ncig = 0, cur_op = 0, cur_inc = 0, n_nons = 0, op = 0;
+            bool overflow = walker && cend[h] == 0x7fffffff;
+            auto push = [&](uint32_t inc, uint32_t o) {
+                if (inc == 0) return;
+                if (cur_inc && cur_op == o) {
+                    cur_inc += inc;
+                    return;
+                }
+                if (cur_inc) {
+                    if (ncig < a.maxc) cig[ncig] = (cur_inc << 8) | cur_op;
+                    else overflow = true;
+                    ++ncig;
+                }
+                cur_op = o;
+                cur_inc = inc;
+            };
+            int r = rendw + 1, c = (walker && !overflow) ? cend[h] + 1 : 0;
+            bool walking = walker && !overflow;  // inside the while loop of to_alignment
+            if (walking) push(lenw - (uint32_t)c, 'S');
+            int cr = rendw, cc = c - 1;  // the cell the walker looks at next
+            int idx = 0;                 // its position in the current batch
+            bool need = true;            // a new batch is needed
+            uint32_t pre = 0;            // this lane's cell of its read's current batch (kept while the walker still consumes it)
+#pragma unroll 1
+            while (__ballot(walking) != 0) {
+                // anchors of the two walkers of the group, and one load per lane
+                const int src = grp0 + h;
+                const int ar = __shfl(cr, src, 64), ac = __shfl(cc, src, 64);
+                const bool want = __shfl((int)(walking && need), src, 64) != 0;
+                if (want && kk < KB && ar - kk >= 0 && ac - kk >= 0)
+                    pre = __hip_atomic_load(ringh + (size_t)((ar - kk) % W) * row_bytes + (size_t)((ac - kk) / NV) * (size_t)NVQ * 4 + (size_t)((ac - kk) % NV),
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (walking && need) {
+                    idx = 0;
+                    need = false;
+                }
+                // consume
+#pragma unroll 1
+                for (int s = 0; s < KB; ++s) {
+                    if (__ballot(walking && !need) == 0) break;  // every walker of the wave waits for a new batch (or is done)
+                    const uint32_t fv = (uint32_t)__shfl((int)pre, grp0 + 2 * idx + h, 64);
+                    if (walking && !need) {
+                        const uint32_t f = fv;
+                        if ((f & BT_STOP) || r <= 0 || c <= 0) {
+                            walking = false;
+                        } else {
+                            bool diag = false;
+                            if (op == 'D' && (f & BT_UP_EXT)) {
+                                r -= 1;
+                            } else if (op == 'I' && (f & BT_LEFT_EXT)) {
+                                c -= 1;
+                            } else if (f & BT_UP) {
+                                op = 'D';
+                                r -= 1;
+                            } else if (f & BT_LEFT) {
+                                op = 'I';
+                                c -= 1;
+                            } else {
+                                op = 'M';
+                                r -= 1;
+                                c -= 1;
+                                diag = true;
+                            }
+                            if (!(cur_inc && cur_op == op)) ++n_nons;
+                            push(1, op);
+                            if (r > 0 && c > 0) {
+                                if (r - 1 + window <= rendw) {  // the walk left the retained window
+                                    overflow = true;
+                                    walking = false;
+                                } else {
+                                    cr = r - 1;
+                                    cc = c - 1;
+                                    if (diag && idx + 1 < KB) ++idx;
+                                    else need = true;
+                                }
+                            } else {
+                                walking = false;
+                            }
+                        }
+                    }
+                }
+            }
+            if (walker) {
+                if (!(cend[h] == 0x7fffffff)) {
+                    push((uint32_t)c, 'S');
+                    push(1, 0);  // flush the pending ciglet (the sentinel op 0 itself is never stored)
+                }
+                if (overflow || ncig > a.maxc) {
+                    const uint32_t k = atomicAdd(a.fb_count, 1u);
+                    a.fb_list[k] = idw;
+                } else {
+                    zsw_alignment out;
+                    out.score = (uint32_t)best[h];
+                    out.ref_start = (uint32_t)r;
+                    out.ref_end = (uint32_t)(rendw + 1);
+                    out.query_start = (uint32_t)c;
+                    out.query_end = (uint32_t)(cend[h] + 1);
+                    out.ref_len = a.ref_len;
+                    out.query_len = lenw;
+                    // forward count; inverted: clips re-derived from ref_range (output.rs:399-414)
+                    out.n_ciglets = a.invert ? n_nons + (r > 0 ? 1u : 0u) + (a.ref_len > (uint32_t)(rendw + 1) ? 1u : 0u) : ncig;
+                    out.ciglet_offset = 0;  // filled by write_ciglets_kernel
+                    a.aln[idw] = out;
+                    a.cig_start[idw] = (uint64_t)(uintptr_t)cig;
+                    a.cig_raw[idw] = ncig;
+                }
             }
         }
     }
