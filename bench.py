@@ -156,7 +156,7 @@ def file_tag(rel: str) -> str:
 WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4  # wave64 VALU instructions/s: 1,024 SIMDs, one per 4 cycles at 2.4 GHz (VALU_PEAK_SOURCE)
 # VALU wave-instructions per read of the pass-2 / score kernels, from committed rocprofv3 --pmc SQ_INSTS_VALU passes
 # (constants from those profiles, not measured in the bench run): see profiles/r02_align_pk_pmc.txt
-ALIGN_PK_VALU_PER_READ = 23_113
+ALIGN_PK_VALU_PER_READ = 21_279
 ALIGN_PK_PROFILE = "profiles/r02_align_pk_pmc.txt"
 
 
