@@ -15,7 +15,9 @@ constexpr int PAD_K = 255;     // residue code of a padded query column
 // walk them in order; steps of 8-16 % between 76 and 400 columns keep the padded columns of a 75-400 bp batch near 6 %), then
 // (32, 5), which only the batch-size-aware choice picks (short reads, too few of them to fill the chip with four lanes per pair).
 // Measured and rejected: C = 41 / 44 with four and eight lanes instead of (8,19), (8,22), (16,22) — 8.5 instead of 9.0 TCUPS on
-// the 75-400 bp batch (the longer column loops sit at the 168-VGPR boundary of three waves per SIMD).
+// the 75-400 bp batch (the longer column loops sit at the 168-VGPR boundary of three waves per SIMD); thirty configurations
+// (capacity steps of 4-8 %, padded cells 1.035x): 8.4-8.5 TCUPS — ten more launches of smaller grids cost more than the padding
+// they save; eight side streams instead of four: no change.
 #define ZSW_FOR_EACH_STRIP_CONFIG(X)                                                                                            \
     X(4, 19) X(4, 22) X(4, 25) X(4, 28) X(4, 32) X(4, 35) X(4, 38) X(8, 19) X(8, 22) X(8, 25) X(8, 28) X(8, 32) X(8, 35) X(8, 38) \
     X(16, 22) X(16, 25) X(16, 32) X(16, 38) X(64, 19) X(64, 38) X(32, 5)
