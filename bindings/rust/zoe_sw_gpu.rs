@@ -114,6 +114,8 @@ unsafe extern "C" {
     fn zsw_group_set_scoring(group: *mut ZswGroup, weights: *const i8, s: i32, index_map: *const u8, gap_open: i32, gap_extend: i32) -> i32;
     fn zsw_group_set_reference(group: *mut ZswGroup, reference: *const u8, len: usize) -> i32;
     fn zsw_group_score_batch_from(group: *mut ZswGroup, reads: *const ZswBatch, from_width: i32, preset_bits: i32, out_score: *mut u32, out_status: *mut u8, out_tier: *mut u8) -> i32;
+    fn zsw_group_align_batch_from(group: *mut ZswGroup, reads: *const ZswBatch, from_width: i32, preset_bits: i32, invert: i32, out_aln: *mut ZswAlignment, out_status: *mut u8, out_tier: *mut u8, out_inc: *mut u32, out_op: *mut u8, ciglet_cap: u64, out_n_ciglets: *mut u64) -> i32;
+    fn zsw_group_align_3pass_batch_from(group: *mut ZswGroup, reads: *const ZswBatch, from_width: i32, preset_bits: i32, invert: i32, out_aln: *mut ZswAlignment, out_status: *mut u8, out_tier: *mut u8, out_inc: *mut u32, out_op: *mut u8, ciglet_cap: u64, out_n_ciglets: *mut u64) -> i32;
     fn zsw_group_score_batch_from_device(group: *mut ZswGroup, shards: *const ZswBatch, from_width: i32, preset_bits: i32, out_score: *const *mut u32, out_status: *const *mut u8) -> i32;
     fn zsw_synth_reads(ctx: *mut ZswContext, seed: u64, first: u64, n: u64, len: u32, out_device: *mut u8, stream: *mut c_void) -> i32;
     fn zsw_synth_reads_ragged(ctx: *mut ZswContext, seed: u64, first: u64, n: u64, min_len: u32, max_len: u32, offsets_device: *const u64, out_device: *mut u8, stream: *mut c_void) -> i32;
@@ -626,13 +628,8 @@ impl GpuGroup {
     pub fn sw_score_from_batch<const S: usize, Q: AsRef<[u8]>>(
         &self, reads: &[Q], reference: &[u8], scoring: &Scoring<'_, S>, cascade: Cascade,
     ) -> Result<Vec<(Result<MaybeAligned<u32>, ProfileError>, u8)>, GpuError> {
-        let w = scoring.flat_weights();
-        let map = scoring.index_map();
+        self.configure(scoring, reference)?;
         let (go, ge) = (scoring.gap_open, scoring.gap_extend);
-        // SAFETY: pointers valid for the duration of the calls
-        self.check(unsafe { zsw_group_set_scoring(self.raw, w.as_ptr(), S as i32, map.as_ptr(), i32::from(go), i32::from(ge)) }, go, ge)?;
-        let p = if reference.is_empty() { [0u8].as_ptr() } else { reference.as_ptr() };
-        self.check(unsafe { zsw_group_set_reference(self.raw, p, reference.len()) }, go, ge)?;
         let batch = HostBatch::new(reads);
         let n = reads.len();
         let (mut score, mut status, mut tier) = (vec![0u32; n.max(1)], vec![0u8; n.max(1)], vec![0u8; n.max(1)]);
@@ -642,6 +639,51 @@ impl GpuGroup {
         };
         self.check(code, go, ge)?;
         Ok((0..n).map(|i| (maybe(status[i], || score[i]), tier[i])).collect())
+    }
+
+    fn configure<const S: usize>(&self, scoring: &Scoring<'_, S>, reference: &[u8]) -> Result<(), GpuError> {
+        let w = scoring.flat_weights();
+        let map = scoring.index_map();
+        let (go, ge) = (scoring.gap_open, scoring.gap_extend);
+        // SAFETY: pointers valid for the duration of the calls
+        self.check(unsafe { zsw_group_set_scoring(self.raw, w.as_ptr(), S as i32, map.as_ptr(), i32::from(go), i32::from(ge)) }, go, ge)?;
+        let p = if reference.is_empty() { [0u8].as_ptr() } else { reference.as_ptr() };
+        self.check(unsafe { zsw_group_set_reference(self.raw, p, reference.len()) }, go, ge)
+    }
+
+    /// Per read: `profiles.sw_align_from_i{from_width}(seq)` (or its `_3pass` form), the batch sharded over the
+    /// group's GPUs; the second vector is the width that answered.
+    pub fn sw_align_from_batch<const S: usize, Q: AsRef<[u8]>>(
+        &self, reads: &[Q], reference: &[u8], scoring: &Scoring<'_, S>, cascade: Cascade, other: OtherSeq, three_pass: bool,
+    ) -> Result<(Vec<Result<MaybeAligned<Alignment<u32>>, ProfileError>>, Vec<u8>), GpuError> {
+        self.configure(scoring, reference)?;
+        let batch = HostBatch::new(reads);
+        let c = batch.as_c();
+        let invert = i32::from(other == OtherSeq::Query);
+        let n = reads.len();
+        let m = n.max(1);
+        let (mut recs, mut status, mut tier) = (vec![ZswAlignment::default(); m], vec![0u8; m], vec![0u8; m]);
+        let mut cap = (4 * n).max(16);
+        loop {
+            let (mut inc, mut op, mut needed) = (vec![0u32; cap], vec![0u8; cap], 0u64);
+            // SAFETY: the arrays hold n records / cap ciglets
+            let code = unsafe {
+                if three_pass {
+                    zsw_group_align_3pass_batch_from(self.raw, &c, cascade.from_width, cascade.preset_bits, invert, recs.as_mut_ptr(),
+                        status.as_mut_ptr(), tier.as_mut_ptr(), inc.as_mut_ptr(), op.as_mut_ptr(), cap as u64, &mut needed)
+                } else {
+                    zsw_group_align_batch_from(self.raw, &c, cascade.from_width, cascade.preset_bits, invert, recs.as_mut_ptr(),
+                        status.as_mut_ptr(), tier.as_mut_ptr(), inc.as_mut_ptr(), op.as_mut_ptr(), cap as u64, &mut needed)
+                }
+            };
+            if code == -1 && needed as usize > cap {
+                cap = needed as usize; // capacity too small: the required size came back
+                continue;
+            }
+            self.check(code, scoring.gap_open, scoring.gap_extend)?;
+            let out = (0..n).map(|i| maybe(status[i], || alignment_of(&recs[i], &inc, &op))).collect();
+            return Ok((out, tier));
+        }
     }
 
     /// Device-resident shards (one per GPU, `mem = ZSW_MEM_DEVICE`) with the results gathered on every

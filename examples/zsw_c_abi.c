@@ -18,6 +18,7 @@ int main(void) {
         (fn)zsw_group_create, (fn)zsw_group_destroy, (fn)zsw_group_size, (fn)zsw_group_context,
         (fn)zsw_group_last_error_string, (fn)zsw_group_set_scoring, (fn)zsw_group_set_reference,
         (fn)zsw_group_score_batch_from, (fn)zsw_group_score_batch_from_device,
+        (fn)zsw_group_align_batch_from, (fn)zsw_group_align_3pass_batch_from,
     };
     zsw_context* ctx = NULL;
     zsw_batch b;

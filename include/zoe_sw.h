@@ -206,7 +206,19 @@ zsw_error zsw_group_set_reference(zsw_group* group, const uint8_t* reference, si
 zsw_error zsw_group_score_batch_from(zsw_group* group, const zsw_batch* reads, int from_width, int preset_bits,
                                      uint32_t* out_score, uint8_t* out_status, uint8_t* out_tier);
 
-/* The same with reads and results in DEVICE memory: shards[i] is the batch of context i on device_ids[i]; out_score[i] and
+/* ProfileSets::sw_align_from_i{from_width} (src/alignment/profile_set.rs:124-179) and sw_align_from_i{from_width}_3pass
+ * (:212-283) for a batch in HOST memory spread over the group's GPUs; arguments as in zsw_align_batch_from /
+ * zsw_align_3pass_batch_from. The shards are aligned in parallel; records, statuses and tiers land in read order and the
+ * ciglets of the shards are laid out one after the other (ciglet_offset indexes the caller's arrays). If ciglet_cap is too
+ * small the call returns ZSW_ERR_INVALID_ARGUMENT with the required size in *out_n_ciglets. Synchronous. */
+zsw_error zsw_group_align_batch_from(zsw_group* group, const zsw_batch* reads, int from_width, int preset_bits, int invert,
+                                     zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
+                                     uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets);
+zsw_error zsw_group_align_3pass_batch_from(zsw_group* group, const zsw_batch* reads, int from_width, int preset_bits, int invert,
+                                           zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
+                                           uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets);
+
+/* zsw_group_score_batch_from with reads and results in DEVICE memory: shards[i] is the batch of context i on device_ids[i]; out_score[i] and
  * out_status[i] are arrays on device i with room for ALL reads (sum of the shards' n_reads). Context i writes its slice in
  * place and one RCCL all-gather over xGMI (grouped broadcasts: the shards need not be equal) completes the arrays on every
  * device, in shard order. librccl is opened at the first call; without it the call returns ZSW_ERR_UNSUPPORTED. Synchronous. */

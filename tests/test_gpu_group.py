@@ -62,6 +62,56 @@ def test_two_contexts_on_one_gpu_equal_one_context(za, fixed, n):
     assert np.array_equal(t[some], one.tier.cpu().numpy()[some])
 
 
+@pytest.mark.parametrize("three_pass", [False, True])
+@pytest.mark.parametrize("fixed", [True, False])
+@pytest.mark.parametrize("n", [0, 1, 5003])
+def test_group_alignments_equal_one_context(za, fixed, n, three_pass):
+    """zsw_group_align_batch_from / _3pass_batch_from: records in read order, the shards' ciglets back to back."""
+    import torch
+
+    ref, bases, off, L = _reference_and_reads(n, fixed)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    g = za.SwGroup([0, 0, 0])
+    try:
+        g.configure(dna, -10, -1, ref)
+        got = g.sw_align_from_host(bases, n, fixed_len=L, offsets=off, three_pass=three_pass)
+        if n:
+            tiny = g.lib.zsw_group_align_batch_from  # capacity too small: the required size comes back, nothing is written
+            b = za._lib.ZswBatch()
+            b.bases, b.fixed_len, b.n_reads, b.mem = bases.ctypes.data, L, n, za._lib.MEM_HOST
+            o64 = None
+            if off is not None:
+                o64 = np.ascontiguousarray(off, dtype=np.uint64)
+                b.offsets = o64.ctypes.data
+            import ctypes as C
+
+            rec = np.zeros(n, dtype=za.alignment.ALN_DTYPE)
+            st = np.zeros(n, dtype=np.uint8)
+            total = C.c_uint64(0)
+            one_inc, one_op = np.zeros(1, np.uint32), np.zeros(1, np.uint8)
+            rc = tiny(g.h, C.byref(b), 8, 256, 0, rec.ctypes.data, st.ctypes.data, None, one_inc.ctypes.data, one_op.ctypes.data,
+                      1 if len(got.inc) > 1 else 0, C.byref(total))
+            if len(got.inc) > 1:
+                assert rc == -1 and total.value == len(got.inc)
+                assert b"capacity" in g.lib.zsw_group_last_error_string(g.h)
+    finally:
+        g.close()
+    if n == 0:
+        assert len(got.status) == 0 and len(got.inc) == 0
+        return
+    if fixed:
+        rb = za.ReadBatch.from_fixed(torch.from_numpy(bases).cuda(), 150)
+    else:
+        rb = za.ReadBatch(torch.from_numpy(bases).cuda(), n, offsets=torch.from_numpy(off.astype(np.int64)).cuda())
+    prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
+    seq = za.SeqSrc.Reference(ref)
+    one = prof.sw_align_from_i8_3pass(seq) if three_pass else prof.sw_align_from_i8(seq)
+    assert np.array_equal(got.status, one.status)
+    assert np.array_equal(got.tier, one.tier)
+    for i in range(n):
+        assert got.result(i) == one.result(i), i
+
+
 def test_device_shards_and_the_rccl_gather_at_world_size_one(za, oracle):
     """Device-memory form: the context writes its slice of the device's result arrays and the grouped RCCL broadcast completes
     them (world size 1 here: the collective is issued and must leave the results intact); checked against the oracle."""

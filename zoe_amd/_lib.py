@@ -35,7 +35,8 @@ SYMBOLS = [
     "zsw_synth_reads", "zsw_synth_reads_ragged", "zsw_synth_length", "zsw_synth_reference_host", "zsw_synth_reads_host",
     "zsw_synth_reads_ragged_host", "zsw_selftest", "zsw_timing_enable", "zsw_timing_read", "zsw_debug_set",
     "zsw_group_create", "zsw_group_destroy", "zsw_group_size", "zsw_group_context", "zsw_group_last_error_string", "zsw_group_set_scoring",
-    "zsw_group_set_reference", "zsw_group_score_batch_from", "zsw_group_score_batch_from_device",
+    "zsw_group_set_reference", "zsw_group_score_batch_from", "zsw_group_score_batch_from_device", "zsw_group_align_batch_from",
+    "zsw_group_align_3pass_batch_from",
 ]
 
 
@@ -130,5 +131,7 @@ def load() -> C.CDLL:
     lib.zsw_group_set_reference.argtypes = [vp, vp, C.c_size_t]
     lib.zsw_group_score_batch_from.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, vp, vp, vp]
     lib.zsw_group_score_batch_from_device.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]
+    lib.zsw_group_align_batch_from.argtypes = [vp, C.POINTER(ZswBatch), C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.zsw_group_align_3pass_batch_from.argtypes = lib.zsw_group_align_batch_from.argtypes
     _lib = lib
     return lib

@@ -322,6 +322,39 @@ class SwGroup:
         self.check(self.lib.zsw_group_score_batch_from(self.h, C.byref(b), width, preset, score.ctypes.data, status.ctypes.data, tier.ctypes.data))
         return score[:n_reads], status[:n_reads], tier[:n_reads]
 
+    def sw_align_from_host(self, bases: np.ndarray, n_reads: int, fixed_len: int = 0, offsets: Optional[np.ndarray] = None,
+                           width: int = 8, preset: int = 256, invert: bool = False, three_pass: bool = False) -> "AlignmentBatch":
+        """ProfileSets::sw_align_from_i{width} (or its _3pass form) for a batch in host memory, sharded over the group."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        b = _lib.ZswBatch()
+        b.bases = bases.ctypes.data
+        off = None
+        if offsets is not None:
+            off = np.ascontiguousarray(offsets, dtype=np.uint64)
+            b.offsets = off.ctypes.data
+        b.fixed_len = int(fixed_len)
+        b.n_reads = int(n_reads)
+        b.mem = _lib.MEM_HOST
+        n = int(n_reads)
+        rec = np.zeros(max(n, 1), dtype=ALN_DTYPE)
+        status = np.zeros(max(n, 1), dtype=np.uint8)
+        tier = np.zeros(max(n, 1), dtype=np.uint8)
+        fn = self.lib.zsw_group_align_3pass_batch_from if three_pass else self.lib.zsw_group_align_batch_from
+        cap = max(8 * n, 64)
+        total = C.c_uint64(0)
+        while True:
+            inc = np.zeros(cap, dtype=np.uint32)
+            op = np.zeros(cap, dtype=np.uint8)
+            rc = fn(self.h, C.byref(b), width, preset, int(invert), rec.ctypes.data, status.ctypes.data, tier.ctypes.data,
+                    inc.ctypes.data, op.ctypes.data, cap, C.byref(total))
+            if rc == -1 and total.value > cap:
+                cap = int(total.value)
+                continue
+            self.check(rc)
+            break
+        t = int(total.value)
+        return AlignmentBatch(status[:n], rec[:n], inc[:t], op[:t], tier[:n])
+
     def sw_score_from_device(self, shards: Sequence["ReadBatch"], width: int = 8, preset: int = 256):
         """One device-resident ReadBatch per context; returns per device the (score, status) tensors of ALL reads in shard order."""
         torch = _torch()

@@ -200,6 +200,112 @@ zsw_error zsw_group_score_batch_from(zsw_group* g, const zsw_batch* reads, int f
     });
 }
 
+}  // extern "C"
+
+// Shared by the alignment entry points: one shard per context into shard-local arrays (sized from the count the library
+// reports back), then the ciglets are laid out shard after shard in the caller's arrays and the records' offsets rebased.
+namespace {
+
+struct ShardAlign {
+    std::vector<zsw_alignment> aln;
+    std::vector<uint8_t> status, tier, op;
+    std::vector<uint32_t> inc;
+    uint64_t n_ciglets = 0;
+};
+
+template <typename Call>  // call(ctx, batch, aln, status, tier, inc, op, cap, n_ciglets)
+zsw_error group_align(zsw_group* g, const zsw_batch* reads, zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier,
+                      uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, Call call) {
+    if (!reads || !out_aln || !out_status || !out_n_ciglets || (ciglet_cap && (!out_inc || !out_op)))
+        return gfail(g, ZSW_ERR_INVALID_ARGUMENT, "null argument");
+    if (reads->mem != ZSW_MEM_HOST) return gfail(g, ZSW_ERR_INVALID_ARGUMENT, "the group alignment calls take host memory");
+    const int G = (int)g->ctx.size();
+    const uint64_t n = reads->n_reads;
+    std::vector<ShardAlign> sh((size_t)G);
+    zsw_error e = for_each_context(g, [&](int i) -> zsw_error {
+        uint64_t first, count;
+        shard_of(n, i, G, &first, &count);
+        if (count == 0) return ZSW_OK;
+        zsw_batch b = *reads;
+        b.n_reads = count;
+        std::vector<uint64_t> rebased;
+        if (reads->offsets) {
+            rebased.resize(count + 1);
+            const uint64_t base = reads->offsets[first];
+            for (uint64_t k = 0; k <= count; ++k) rebased[k] = reads->offsets[first + k] - base;
+            b.bases = reads->bases + base;
+            b.offsets = rebased.data();
+        } else {
+            b.bases = reads->bases + first * reads->fixed_len;
+        }
+        ShardAlign& s = sh[(size_t)i];
+        s.aln.resize(count);
+        s.status.resize(count);
+        s.tier.resize(count);
+        uint64_t cap = 4 * count + 16;
+        for (;;) {
+            s.inc.resize(cap);
+            s.op.resize(cap);
+            const zsw_error rc = call(g->ctx[(size_t)i], &b, s.aln.data(), s.status.data(), s.tier.data(), s.inc.data(), s.op.data(), cap, &s.n_ciglets);
+            if (rc == ZSW_ERR_INVALID_ARGUMENT && s.n_ciglets > cap) {  // capacity too small: the required size came back
+                cap = s.n_ciglets;
+                continue;
+            }
+            return rc;
+        }
+    });
+    if (e != ZSW_OK) return e;
+    uint64_t total = 0;
+    for (const ShardAlign& s : sh) total += s.n_ciglets;
+    *out_n_ciglets = total;
+    if (total > ciglet_cap) return gfail(g, ZSW_ERR_INVALID_ARGUMENT, "ciglet capacity too small; required size returned");
+    uint64_t base = 0;
+    for (int i = 0; i < G; ++i) {
+        uint64_t first, count;
+        shard_of(n, i, G, &first, &count);
+        const ShardAlign& s = sh[(size_t)i];
+        for (uint64_t k = 0; k < count; ++k) {
+            zsw_alignment a = s.aln[k];
+            a.ciglet_offset += base;
+            out_aln[first + k] = a;
+            out_status[first + k] = s.status[k];
+            if (out_tier) out_tier[first + k] = s.tier[k];
+        }
+        for (uint64_t k = 0; k < s.n_ciglets; ++k) {
+            out_inc[base + k] = s.inc[k];
+            out_op[base + k] = s.op[k];
+        }
+        base += s.n_ciglets;
+    }
+    return ZSW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+zsw_error zsw_group_align_batch_from(zsw_group* g, const zsw_batch* reads, int from_width, int preset_bits, int invert,
+                                     zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
+                                     uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets) {
+    if (!g) return ZSW_ERR_INVALID_ARGUMENT;
+    return group_align(g, reads, out_aln, out_status, out_tier, out_inc, out_op, ciglet_cap, out_n_ciglets,
+                       [&](zsw_context* c, const zsw_batch* b, zsw_alignment* aln, uint8_t* st, uint8_t* tier, uint32_t* inc, uint8_t* op,
+                           uint64_t cap, uint64_t* nc) {
+                           return zsw_align_batch_from(c, b, from_width, preset_bits, invert, aln, st, tier, inc, op, cap, nc, nullptr);
+                       });
+}
+
+zsw_error zsw_group_align_3pass_batch_from(zsw_group* g, const zsw_batch* reads, int from_width, int preset_bits, int invert,
+                                           zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
+                                           uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets) {
+    if (!g) return ZSW_ERR_INVALID_ARGUMENT;
+    return group_align(g, reads, out_aln, out_status, out_tier, out_inc, out_op, ciglet_cap, out_n_ciglets,
+                       [&](zsw_context* c, const zsw_batch* b, zsw_alignment* aln, uint8_t* st, uint8_t* tier, uint32_t* inc, uint8_t* op,
+                           uint64_t cap, uint64_t* nc) {
+                           return zsw_align_3pass_batch_from(c, b, from_width, preset_bits, invert, aln, st, tier, inc, op, cap, nc, nullptr);
+                       });
+}
+
 zsw_error zsw_group_score_batch_from_device(zsw_group* g, const zsw_batch* shards, int from_width, int preset_bits,
                                             uint32_t* const* out_score, uint8_t* const* out_status) {
     if (!g) return ZSW_ERR_INVALID_ARGUMENT;
