@@ -1,0 +1,39 @@
+"""Ad-hoc check of the column-pruned score pass against the default pass: parity and time (python tools/try_prune.py N)."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+import zoe_amd
+from zoe_amd import _lib, synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+ref = synth.reference_host(2000)
+ctx = zoe_amd.SwContext.get(0)
+dna = zoe_amd.WeightMatrix.new_dna_matrix(2, -5, b"N")
+rb = synth.reads_device(ctx, ref, 0, n, 150)
+prof = zoe_amd.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
+
+
+def run(flags, reps=3):
+    ctx.debug_set(flags)
+    out = prof.sw_score_from_i8(ref)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = prof.sw_score_from_i8(ref)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return out, dt
+
+
+base, t_base = run(0)
+pr, t_pr = run(_lib.DEBUG_SCORE_PRUNE)
+ctx.debug_set(0)
+same = bool((base.score == pr.score).all() and (base.status == pr.status).all() and (base.tier == pr.tier).all())
+fails = int(torch.frombuffer(bytearray(4), dtype=torch.int32)[0])
+print(f"n={n}: default {t_base*1e3:.2f} ms ({n/t_base/1e6:.1f} M/s), pruned {t_pr*1e3:.2f} ms ({n/t_pr/1e6:.1f} M/s), identical={same}")
+if not same:
+    bad = torch.nonzero(base.score != pr.score).flatten()[:10].cpu().numpy()
+    print("first differences (id, default, pruned):", [(int(i), int(base.score[i]), int(pr.score[i])) for i in bad], "of", int((base.score != pr.score).sum()))

@@ -10,6 +10,7 @@
 
 #include "zsw_align.hpp"
 #include "zsw_internal.hpp"
+#include "zsw_score_prune.hpp"
 #include "zsw_synth.h"
 #include "zsw_timer.hpp"
 
@@ -47,6 +48,8 @@ struct zsw_context {
     ScoringDev h_sc{};
     int bias = 0;
     DevBuf d_sc, d_ref, d_fb_list, d_fb_count, d_scratch, d_maxlen, d_bucket_items, d_bucket_counts, d_tile_buf, d_tile_state;
+    DevBuf d_prune, d_prune_list, d_prune_count;  // column-pruned score pass
+    uint32_t prune_chunk = 0;
     size_t ref_len = 0;
     uint32_t scratch_len = 0;
     size_t exact_slots = 0;
@@ -273,6 +276,15 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
         ZSW_HIP(ctx, ctx->d_tile_state.ensure((size_t)n * 16 + 16));
     }
     ZSW_HIP(ctx, ctx->d_bucket_counts.ensure(64 * 4));
+    ctx->prune_chunk = 0;
+    if ((ctx->debug & ZSW_DEBUG_SCORE_PRUNE) && !want_ends && !reads->offsets && n > 0 && st->max_len > (uint32_t)PR_CP + 40 &&
+        st->max_len <= (uint32_t)(PR_CP + PR_G2 * PR_C2) && ctx->ref_len > 0 && ctx->ref_len <= 2048) {
+        const uint32_t chunk = std::min<uint32_t>((uint32_t)n, PR_CHUNK_READS);
+        ZSW_HIP(ctx, ctx->d_prune.ensure(prune_workspace_bytes(chunk, (uint32_t)ctx->ref_len)));
+        ZSW_HIP(ctx, ctx->d_prune_list.ensure((size_t)n * 4 + 4));
+        ZSW_HIP(ctx, ctx->d_prune_count.ensure(4));
+        ctx->prune_chunk = chunk;
+    }
     uint32_t need = std::max<uint32_t>(512, (st->max_len + 127) / 128 * 128);
     if (need > ctx->scratch_len || !ctx->d_scratch.p) {
         // slots from a byte budget: 16,384 for reads up to 8 kb, down to 64 for genome-sized reads (2 rows of `need` ints per slot)
@@ -297,6 +309,13 @@ ScoreWorkspace score_ws(zsw_context* ctx) {
     w.tile_state = ctx->d_tile_state.as<uint4>();
     w.side = ctx->side;
     w.debug = ctx->debug;
+    if (ctx->prune_chunk) {
+        w.prune_work = ctx->d_prune.as<uint8_t>();
+        w.prune_bytes = ctx->d_prune.cap;
+        w.prune_chunk = ctx->prune_chunk;
+        w.prune_fail_list = ctx->d_prune_list.as<uint32_t>();
+        w.prune_fail_count = ctx->d_prune_count.as<uint32_t>();
+    }
     return w;
 }
 
@@ -940,7 +959,7 @@ void zsw_destroy(zsw_context* ctx) {
     DeviceGuard device_guard(ctx);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state,
+    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state, &ctx->d_prune, &ctx->d_prune_list, &ctx->d_prune_count,
                       &ctx->s_bases, &ctx->s_offsets, &ctx->s_score, &ctx->s_status, &ctx->s_tier, &ctx->s_rend, &ctx->s_qend};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->a_ws) b.release();

@@ -88,6 +88,13 @@ struct ScoreWorkspace {
     size_t tile_bytes = 0;
     uint4* tile_state = nullptr;
     SideStreams* side = nullptr;  // null: the length classes run one after the other on the caller's stream
+    // column-pruned score-only pass (zsw_score_prune.hip): workspace of prune_workspace_bytes(prune_chunk, ref_len) and a
+    // worklist of n_reads entries + counter for the reads it hands back; null when the batch does not qualify
+    uint8_t* prune_work = nullptr;
+    size_t prune_bytes = 0;
+    uint32_t prune_chunk = 0;
+    uint32_t* prune_fail_list = nullptr;
+    uint32_t* prune_fail_count = nullptr;
     uint32_t debug = 0;           // ZSW_DEBUG_* bits of the context (zsw_debug_set): kernel-selection overrides for tests
 };
 

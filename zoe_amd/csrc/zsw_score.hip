@@ -26,6 +26,7 @@
 
 #include "zsw_internal.hpp"
 #include "zsw_score_v1.hpp"
+#include "zsw_score_prune.hpp"
 #include "zsw_score_v2.hpp"
 #include "zsw_timer.hpp"
 
@@ -586,10 +587,41 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
             if (e != hipSuccess) return e;
             return finish_worklist();
         }
-        if (timer) timer->begin(stream);
-        e = launch_one(b, G, C);
-        if (timer) timer->end(stream);
-        if (e != hipSuccess) return e;
+        // Score only, short reads, a reference that fits one row table: the column-pruned pass; the reads it hands back
+        // (a check failed: some uncomputed cell might matter) are scored over all their cells, on the device-side list.
+        ScoreArgsV2 ap = a2;
+        bool pruned = false;
+        if (mode == 0 && use_v2 && !b.items && ws.prune_work && (ws.debug & ZSW_DEBUG_SCORE_PRUNE) && build_tables_v2(h_sc, 1, &ap)) {
+            const uint32_t floor_strip = ap.floor0, limit_strip = ap.limit;
+            if (build_tables_v2(h_sc, PR_G2, &ap) && prune_applicable(h_sc, max_len, ref_len, std::min(limit_strip, ap.limit))) {
+                if (timer) timer->begin(stream);
+                ap.b = b;
+                e = launch_score_pruned(ap, floor_strip, ap.floor0, h_sc, ws.prune_work, ws.prune_bytes, ws.prune_chunk, ws.prune_fail_list,
+                                        ws.prune_fail_count, stream);
+                if (e == hipSuccess) {
+                    pruned = true;
+                    if (build_tables_v2(h_sc, G, &a2)) {
+                        a2.b = b;
+                        a2.b.items = ws.prune_fail_list;
+                        a2.n_items_dev = ws.prune_fail_count;
+                        e = launch_table_cfg_v2(a2, G, C, mode, stream);
+                        a2.n_items_dev = nullptr;
+                    } else {
+                        e = hipErrorInvalidValue;
+                    }
+                } else if (e == hipErrorNotSupported) {
+                    e = hipSuccess;
+                }
+                if (timer && pruned) timer->end(stream);
+                if (e != hipSuccess) return e;
+            }
+        }
+        if (!pruned) {
+            if (timer) timer->begin(stream);
+            e = launch_one(b, G, C);
+            if (timer) timer->end(stream);
+            if (e != hipSuccess) return e;
+        }
     }
     return finish_worklist();
 }

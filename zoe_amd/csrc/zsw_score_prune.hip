@@ -1,0 +1,483 @@
+// zsw_score_prune.hip — the score-only pass with exact column pruning (sw_simd_score, striped.rs:65-142: only the maximum
+// of the DP matrix is returned, so cells that provably cannot lie on a path scoring more than a score already found need not
+// be computed).
+//
+// Two kernels replace score_kernel_v2 for batches of short reads against a reference that fits one LDS row table:
+//   1. prune_strip_kernel: query columns [0, CP) against EVERY reference row, one read pair per lane. Exact for these columns
+//      (nothing flows into them from the right). It leaves, per read, the strip's own maximum, the boundary stream
+//      (H[r][CP-1], F[r][CP]) of every row r — everything the columns to the right ever receive from the strip — the maxima of
+//      the two per block of PR_BLK rows, and the row of the largest boundary H (the anchor: where the read's alignment
+//      crosses column CP).
+//   2. prune_window_kernel: columns [CP, L) for a window of rows around the anchor only (reads sorted by anchor, two per
+//      lane group), fed with the exact boundary stream, starting from a zero state. Every value it computes is the score of a
+//      real alignment, so S' = max(strip maximum, window maximum) is a lower bound of the read's score, and it is THE score
+//      if no path that leaves the computed region can beat S'. A path through cell (r, c) scores at most H[r][c] +
+//      maxw * (columns left of the read), which gives three checks, all against S':
+//        V1  a path that starts right of the strip outside the window scores at most maxw * (len - CP);
+//        V2  a path that crosses from the strip to the right in a row outside the window scores at most
+//            max(H[r][CP-1] + maxw * (len - CP), F[r][CP] + maxw * (len - CP - 1)) — checked per block of rows;
+//        V3  a path that leaves the window through its last rows scores at most max(H, E) + maxw * (len - c - 1) of the cell
+//            it leaves from.
+//      A read that fails a check goes to a list and is scored by score_kernel_v2 over all its cells, so the results are
+//      those of the full pass for every input; the checks only decide how much work a read costs.
+// On the synthetic 150 bp reads 95 % pass with CP = 24 and windows of ~190 rows: 24/150 of the columns over all rows plus
+// 126/150 over a tenth of the rows.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+
+#include "zsw_score_prune.hpp"
+#include "zsw_score_v2.hpp"
+
+namespace zsw {
+
+namespace {
+
+struct PruneArgs {
+    BatchDev b;
+    const uint8_t* ref;
+    uint32_t ref_len;
+    const ScoringDev* sc;
+    uint32_t wtab[9][2];
+    uint32_t ge2, gd2, floor0, K;
+    ResultRule rule;
+    ScoreOut out;
+    uint32_t first;    // first read of the chunk
+    uint32_t n;        // reads of the chunk
+    uint32_t n_pairs;  // (n + 1) / 2
+    uint32_t maxw;
+    uint32_t nblk;     // blocks of PR_BLK rows
+    uint2* bnd;        // [pair][ref_len]: (H[r][CP-1], F[r][CP]), true scores, read A in the low halves
+    uint2* blk;        // [pair][nblk]: maxima of the two per block of rows
+    uint32_t* best0;   // [pair]: the strip's own maximum
+    uint32_t* anchor;  // [read of the chunk]: row of the largest boundary H
+    const uint32_t* order;  // window kernel: reads of the chunk sorted by anchor
+    uint32_t* fail_list;    // global read ids
+    uint32_t* fail_count;
+};
+
+__device__ __forceinline__ void read_span(const BatchDev& b, uint32_t id, uint64_t* off, uint32_t* len) {
+    if (b.offsets) {
+        *off = b.offsets[id];
+        *len = (uint32_t)(b.offsets[id + 1] - *off);
+    } else {
+        *off = (uint64_t)id * b.fixed_len;
+        *len = b.fixed_len;
+    }
+}
+
+// selector of query column q of reads A and B for the v_perm lookup (zsw_score_v2.hpp (3))
+__device__ __forceinline__ uint32_t column_selector(const BatchDev& b, const uint8_t* lut, uint32_t q, uint64_t offA, uint32_t lenA,
+                                                    uint64_t offB, uint32_t lenB) {
+    uint32_t kA = PAD_K, kB = PAD_K;
+    if (q < lenA) kA = lut[b.bases[offA + q]];
+    if (q < lenB) kB = lut[b.bases[offB + q]];
+    const uint32_t sA = kA < 4 ? (2 * kA + 1) | ((8 + kA) << 8) : (kA == PAD_K ? 0x0c00u : (2 * (kA - 3)) | 0x0c00u);
+    const uint32_t sB = kB < 4 ? (2 * kB + 1) | ((8 + kB) << 8) : (kB == PAD_K ? 0x0c00u : (2 * (kB - 3)) | 0x0c00u);
+    return sA | (sB << 16);
+}
+
+template <int C>
+__global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_strip_kernel(PruneArgs a) {
+    __shared__ uint2 rp[CH];
+    __shared__ uint2 swt[9];
+    __shared__ uint32_t lut32[64];
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut32);
+    const int tid = threadIdx.x;
+    const uint32_t pair = blockIdx.x * BLOCK + tid;
+    const bool valid = pair < a.n_pairs;
+    const bool validB = valid && 2 * pair + 1 < a.n;
+    if (tid < 64) lut32[tid] = reinterpret_cast<const uint32_t*>(a.sc->index_map)[tid];
+    if (tid < 9) swt[tid] = make_uint2(a.wtab[tid][0], a.wtab[tid][1]);
+    __syncthreads();
+    uint64_t offA = 0, offB = 0;
+    uint32_t lenA = 0, lenB = 0;
+    if (valid) read_span(a.b, a.first + 2 * pair, &offA, &lenA);
+    if (validB) read_span(a.b, a.first + 2 * pair + 1, &offB, &lenB);
+    uint32_t sel[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) sel[c] = column_selector(a.b, lut, (uint32_t)c, offA, lenA, offB, lenB);
+
+    const uint32_t ge2 = a.ge2, gd2 = a.gd2;
+    const uint32_t ge1 = ge2 & 0xffffu;
+    const uint32_t K = a.K;
+    const uint32_t Kge2 = (K * ge1) * 0x00010001u;
+    uint32_t Dr = (a.floor0 - ge1) * 0x00010001u;  // D of row -1
+    uint32_t H[C], E[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        H[c] = Dr;
+        E[c] = pk_addu(Dr, ge2);
+    }
+    uint32_t best = 0, mH = 0, mF = 0, ancH = 0;
+    uint32_t ancA = 0, ancB = 0;
+    const int R = (int)a.ref_len;
+    uint2* bnd = a.bnd + (size_t)(valid ? pair : 0) * (size_t)R;
+    uint2* blk = a.blk + (size_t)(valid ? pair : 0) * (size_t)a.nblk;
+
+    for (int base = 0; base < R; base += CH) {
+        __syncthreads();
+        for (int j = tid; j < CH; j += BLOCK) {
+            const int row = base + j;
+            rp[j] = swt[row < R ? (int)lut[a.ref[row]] : NEUTRAL];
+        }
+        __syncthreads();
+        const int tend = (R < base + CH) ? R : base + CH;
+        uint2 w = rp[0];
+#pragma unroll 1
+        for (int t = base; t < tend; ++t) {
+            const uint2 wn = rp[(t + 1 - base) & (CH - 1)];
+            if (ge1 != 0 && t > 0 && (t & (int)(K - 1)) == 0) {  // re-base (every lane is in the same row)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    H[c] = pk_subu(H[c], Kge2);
+                    E[c] = pk_subu(E[c], Kge2);
+                }
+                Dr = pk_subu(Dr, Kge2);
+            }
+            const uint32_t Dp = Dr;         // D_{r-1}: the (zero) H left of column 0 in the previous row
+            Dr = pk_addu(Dr, ge2);          // D_r
+            const uint32_t Dn = pk_addu(Dr, ge2);
+            uint32_t hd = pk_addu(Dp, __builtin_amdgcn_perm(w.y, w.x, sel[0]));
+            uint32_t F = Dr;
+            uint32_t rmax = 0x04000400u;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                uint32_t hd_next = 0;
+                if (c + 1 < C) hd_next = pk_addu(H[c], __builtin_amdgcn_perm(w.y, w.x, sel[c + 1 < C ? c + 1 : c]));
+                const uint32_t h = pk_max3(hd, E[c], F);
+                H[c] = h;
+                const uint32_t hg = h - gd2;
+                E[c] = pk_max3(E[c], hg, Dn);
+                F = pk_max3(F, hg, Dn) - ge2;
+                if (c & 1) rmax = pk_max3(rmax, H[c - (c & 1)], h);
+                else if (c == C - 1) rmax = pk_max3(rmax, h, h);
+                hd = hd_next;
+            }
+            const uint32_t tH = pk_subu(H[C - 1], Dr), tF = pk_subu(F, Dr);  // true scores leaving the strip in this row
+            if (valid) bnd[t] = make_uint2(tH, tF);
+            mH = pk_maxu(mH, tH);
+            mF = pk_maxu(mF, tF);
+            const uint32_t na = pk_maxu(ancH, tH);
+            const uint32_t ch = na ^ ancH;
+            if (ch & 0xffffu) ancA = (uint32_t)t;
+            if (ch >> 16) ancB = (uint32_t)t;
+            ancH = na;
+            best = pk_maxu(best, pk_subu(rmax, Dr));
+            if ((t & (PR_BLK - 1)) == PR_BLK - 1 || t == R - 1) {
+                if (valid) blk[t / PR_BLK] = make_uint2(mH, mF);
+                mH = 0;
+                mF = 0;
+            }
+            w = wn;
+        }
+    }
+    if (valid) {
+        a.best0[pair] = best;
+        a.anchor[2 * pair] = ancA;
+        if (validB) a.anchor[2 * pair + 1] = ancB;
+    }
+}
+
+template <int CP, int C>
+__global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_window_kernel(PruneArgs a) {
+    constexpr int G = PR_G2;
+    __shared__ uint2 rp[CH + G];
+    __shared__ uint2 swt[9];
+    __shared__ uint32_t lut32[64];
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut32);
+    const int tid = threadIdx.x;
+    const int g = tid & (G - 1);
+    const uint32_t group = blockIdx.x * (BLOCK / G) + tid / G;
+    const uint32_t itemA = 2 * group, itemB = 2 * group + 1;
+    const bool validA = itemA < a.n, validB = itemB < a.n;
+    const uint32_t ridA = validA ? a.order[itemA] : 0;      // read of the chunk
+    const uint32_t ridB = validB ? a.order[itemB] : ridA;   // an absent B mirrors A's boundary; its columns are padding
+    const int R = (int)a.ref_len;
+    if (tid < 64) lut32[tid] = reinterpret_cast<const uint32_t*>(a.sc->index_map)[tid];
+    if (tid < 9) swt[tid] = make_uint2(a.wtab[tid][0], a.wtab[tid][1]);
+    __syncthreads();
+    for (int j = tid; j < R + G; j += BLOCK) {  // the whole reference; entry j = row j - (G - 1), the last entry is neutral
+        const int row = j - (G - 1);
+        rp[j] = swt[(row >= 0 && row < R && j < R + G - 1) ? (int)lut[a.ref[row]] : NEUTRAL];
+    }
+    __syncthreads();
+
+    uint64_t offA = 0, offB = 0;
+    uint32_t lenA = 0, lenB = 0;
+    if (validA) read_span(a.b, a.first + ridA, &offA, &lenA);
+    if (validB) read_span(a.b, a.first + ridB, &offB, &lenB);
+    uint32_t sel[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) sel[c] = column_selector(a.b, lut, (uint32_t)(CP + g * C + c), offA, lenA, offB, lenB);
+
+    // the window: blocks of rows around the two anchors
+    const int rsA = validA ? (int)a.anchor[ridA] : 0, rsB = validB ? (int)a.anchor[ridB] : rsA;
+    const int lo = min(rsA, rsB), hi = max(rsA, rsB);
+    const int maxlen = (int)max(lenA, lenB);
+    const int Rup = (R + PR_BLK - 1) / PR_BLK * PR_BLK;
+    const int a0 = max(0, lo - PR_M1) / PR_BLK * PR_BLK;
+    const int b0 = min(Rup, (hi + 1 + max(0, maxlen - CP) + PR_M2 + PR_BLK - 1) / PR_BLK * PR_BLK);
+    int Tw = validA ? b0 - a0 : 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) Tw = max(Tw, __shfl_xor(Tw, d, 64));  // the wavefront's groups walk equally many rows
+    const int b1 = min(Rup, a0 + Tw);
+
+    // the boundary streams of the two reads
+    const uint2* bA = a.bnd + (size_t)(ridA >> 1) * (size_t)R;
+    const uint2* bB = a.bnd + (size_t)(ridB >> 1) * (size_t)R;
+    const uint32_t selH = ((ridA & 1) ? 0x0302u : 0x0100u) | (((ridB & 1) ? 0x0706u : 0x0504u) << 16);
+
+    const uint32_t ge2 = a.ge2, gd2 = a.gd2;
+    const uint32_t ge1 = ge2 & 0xffffu;
+    const uint32_t K = a.K;
+    const uint32_t Kge2 = (K * ge1) * 0x00010001u;
+    uint32_t Dr = (a.floor0 - (uint32_t)(g + 1) * ge1) * 0x00010001u;
+    uint32_t H[C], E[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        H[c] = Dr;
+        E[c] = pk_addu(Dr, ge2);
+    }
+    uint32_t best = 0;
+    uint32_t Fout = Dr, Hlast = Dr, Hin_prev = Dr;
+    uint2 ldA = make_uint2(0u, 0u), ldB = make_uint2(0u, 0u);
+    if (g == 0 && validA && a0 < R) {
+        ldA = bA[a0];
+        ldB = bB[a0];
+    }
+    const int T = Tw + G - 1;
+    const int jmax = R + G - 1;
+    uint2 w = rp[min(a0 - g + (G - 1), jmax)];
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        const uint2 wn = rp[min(a0 + t + 1 - g + (G - 1), jmax)];
+        const int row = t - g;  // row of the window
+        const bool rebase = ge1 != 0 && row > 0 && (row & (int)(K - 1)) == 0;
+        if (__ballot(rebase) != 0) {
+            const uint32_t adj = rebase ? Kge2 : 0u;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                H[c] = pk_subu(H[c], adj);
+                E[c] = pk_subu(E[c], adj);
+            }
+            Hin_prev = pk_subu(Hin_prev, adj);
+            Dr = pk_subu(Dr, adj);
+        }
+        Dr = pk_addu(Dr, ge2);
+        const uint32_t Dn = pk_addu(Dr, ge2);
+        uint32_t Fin = (uint32_t)__shfl_up((int)Fout, 1, G);
+        uint32_t Hin = (uint32_t)__shfl_up((int)Hlast, 1, G);
+        if (g == 0) {
+            const int grow = a0 + t;  // reference row
+            Fin = Dr;
+            Hin = Dr;
+            if (validA && grow < R) {
+                Hin = pk_addu(Dr, __builtin_amdgcn_perm(ldB.x, ldA.x, selH));
+                Fin = pk_addu(Dr, __builtin_amdgcn_perm(ldB.y, ldA.y, selH));
+            }
+            if (validA && grow + 1 < R) {
+                ldA = bA[grow + 1];
+                ldB = bB[grow + 1];
+            }
+        }
+        uint32_t hd = pk_addu(Hin_prev, __builtin_amdgcn_perm(w.y, w.x, sel[0]));
+        Hin_prev = Hin;
+        uint32_t F = Fin;
+        uint32_t rmax = 0x04000400u;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            uint32_t hd_next = 0;
+            if (c + 1 < C) hd_next = pk_addu(H[c], __builtin_amdgcn_perm(w.y, w.x, sel[c + 1 < C ? c + 1 : c]));
+            const uint32_t h = pk_max3(hd, E[c], F);
+            H[c] = h;
+            const uint32_t hg = h - gd2;
+            E[c] = pk_max3(E[c], hg, Dn);
+            F = pk_max3(F, hg, Dn) - ge2;
+            if (c & 1) rmax = pk_max3(rmax, H[c - (c & 1)], h);
+            else if (c == C - 1) rmax = pk_max3(rmax, h, h);
+            hd = hd_next;
+        }
+        Fout = F;
+        Hlast = H[C - 1];
+        best = pk_maxu(best, pk_subu(rmax, Dr));
+        w = wn;
+    }
+
+    // ---- the read's score so far, and the three checks ----
+    int bA2 = (int)(best & 0xffffu), bB2 = (int)(best >> 16);
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) {
+        bA2 = max(bA2, __shfl_xor(bA2, d, G));
+        bB2 = max(bB2, __shfl_xor(bB2, d, G));
+    }
+    const uint32_t s0A = validA ? a.best0[ridA >> 1] : 0, s0B = validB ? a.best0[ridB >> 1] : 0;
+    const int SA = max(bA2, (int)((ridA & 1) ? s0A >> 16 : s0A & 0xffffu));
+    const int SB = max(bB2, (int)((ridB & 1) ? s0B >> 16 : s0B & 0xffffu));
+    const int maxw = (int)a.maxw;
+    const int remA = max(0, (int)lenA - CP), remB = max(0, (int)lenB - CP);
+    // V3: what can still leave this lane's last row (E holds the next row's E; Fout moves right into the next lane's columns)
+    int v3A = 0, v3B = 0;
+    if (a0 + Tw < R) {
+        const int dA = (int)(Dr & 0xffffu), dB = (int)(Dr >> 16);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int col = CP + g * C + c;
+            const uint32_t he = pk_maxu(H[c], pk_subu(E[c], ge2));
+            v3A = max(v3A, (int)(he & 0xffffu) - dA + maxw * max(0, (int)lenA - col - 1));
+            v3B = max(v3B, (int)(he >> 16) - dB + maxw * max(0, (int)lenB - col - 1));
+        }
+        const int colr = CP + (g + 1) * C;
+        v3A = max(v3A, (int)(Fout & 0xffffu) - dA + maxw * max(0, (int)lenA - colr - 1));
+        v3B = max(v3B, (int)(Fout >> 16) - dB + maxw * max(0, (int)lenB - colr - 1));
+    }
+    // V2: crossings in rows outside the window, block by block
+    int v2A = 0, v2B = 0;
+    if (validA) {
+        const uint2* kA = a.blk + (size_t)(ridA >> 1) * (size_t)a.nblk;
+        const uint2* kB = a.blk + (size_t)(ridB >> 1) * (size_t)a.nblk;
+        const int k0 = a0 / PR_BLK, k1 = b1 / PR_BLK;  // blocks [k0, k1) are the window
+        for (int k = g; k < (int)a.nblk; k += G) {
+            if (k >= k0 && k < k1) continue;
+            const uint2 xA = kA[k], xB = kB[k];
+            const int hA = (int)((ridA & 1) ? xA.x >> 16 : xA.x & 0xffffu), fA = (int)((ridA & 1) ? xA.y >> 16 : xA.y & 0xffffu);
+            const int hB = (int)((ridB & 1) ? xB.x >> 16 : xB.x & 0xffffu), fB = (int)((ridB & 1) ? xB.y >> 16 : xB.y & 0xffffu);
+            if (remA > 0) v2A = max(v2A, max(hA + maxw * remA, fA + maxw * (remA - 1)));
+            if (remB > 0) v2B = max(v2B, max(hB + maxw * remB, fB + maxw * (remB - 1)));
+        }
+    }
+    int wA = max(v2A, v3A), wB = max(v2B, v3B);
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) {
+        wA = max(wA, __shfl_xor(wA, d, G));
+        wB = max(wB, __shfl_xor(wB, d, G));
+    }
+    wA = max(wA, maxw * remA);  // V1
+    wB = max(wB, maxw * remB);
+    if (g < 2) {
+        const bool second = g == 1;
+        const bool v = second ? validB : validA;
+        if (v) {
+            const uint32_t id = a.first + (second ? ridB : ridA);
+            const uint32_t len = second ? lenB : lenA;
+            const int S = second ? SB : SA, bound = second ? wB : wA;
+            if (len == 0) {
+                a.out.score[id] = 0;
+                a.out.status[id] = ZSW_STATUS_EMPTY;
+                if (a.out.tier) a.out.tier[id] = 0;
+            } else if (bound > S) {  // something outside the computed cells could still score more: all cells for this read
+                const uint32_t k = atomicAdd(a.fail_count, 1u);
+                a.fail_list[k] = id;
+            } else {
+                uint32_t score;
+                uint8_t status, tier;
+                apply_rule(a.rule, (uint64_t)S, &score, &status, &tier);
+                a.out.score[id] = score;
+                a.out.status[id] = status;
+                if (a.out.tier) a.out.tier[id] = tier;
+            }
+        }
+    }
+}
+
+__global__ void iota32_kernel(uint32_t* v, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
+size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+size_t prune_sort_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                             (uint32_t*)nullptr, (int)n, 0, 32, (hipStream_t)0);
+    return bytes;
+}
+
+size_t prune_workspace_bytes(uint32_t chunk_reads, uint32_t ref_len) {
+    const size_t pairs = ((size_t)chunk_reads + 1) / 2, nblk = ((size_t)ref_len + PR_BLK - 1) / PR_BLK;
+    return round256(pairs * ref_len * sizeof(uint2)) + round256(pairs * nblk * sizeof(uint2)) + round256(pairs * 4) +
+           4 * round256((size_t)chunk_reads * 4 + 8) + round256(prune_sort_temp_bytes(chunk_reads)) + 256;
+}
+
+bool prune_applicable(const ScoringDev& s, uint32_t max_len, uint32_t ref_len, uint32_t limit) {
+    int maxw = 0;
+    for (int i = 0; i < s.S * s.S; ++i) maxw = std::max(maxw, (int)s.w[i]);
+    if (maxw <= 0) return false;
+    if (ref_len == 0 || ref_len > (uint32_t)CH) return false;
+    if (max_len <= (uint32_t)PR_CP + 40 || max_len > (uint32_t)(PR_CP + PR_G2 * PR_C2)) return false;
+    return (uint64_t)maxw * max_len + 8 < limit;  // no score can leave the packed range
+}
+
+// Scores reads [0, b.n_reads) of a fixed-length or ragged batch without an item list; reads that fail a check are appended to
+// fail_list (device count in fail_count, zeroed here). `a2` carries the v2 tables and drift constants for G = 1 and G = 4
+// (the constants do not depend on G below 16 rows of slack, see the caller).
+hipError_t launch_score_pruned(const ScoreArgsV2& a2, uint32_t floor_strip, uint32_t floor_window, const ScoringDev& h_sc, uint8_t* work,
+                               size_t work_bytes, uint32_t chunk_reads, uint32_t* fail_list, uint32_t* fail_count, hipStream_t stream) {
+    const uint32_t n = a2.b.n_reads, R = a2.ref_len;
+    if (n == 0) return hipSuccess;
+    if (work_bytes < prune_workspace_bytes(chunk_reads, R)) return hipErrorNotSupported;
+    PruneArgs a;
+    a.b = a2.b;
+    a.ref = a2.ref;
+    a.ref_len = R;
+    a.sc = a2.sc;
+    for (int r = 0; r < 9; ++r) {
+        a.wtab[r][0] = a2.wtab[r][0];
+        a.wtab[r][1] = a2.wtab[r][1];
+    }
+    a.ge2 = a2.ge2;
+    a.gd2 = a2.gd2;
+    a.K = a2.K;
+    a.rule = a2.rule;
+    a.out = a2.out;
+    int maxw = 0;
+    for (int i = 0; i < h_sc.S * h_sc.S; ++i) maxw = std::max(maxw, (int)h_sc.w[i]);
+    a.maxw = (uint32_t)maxw;
+    a.nblk = (R + PR_BLK - 1) / PR_BLK;
+    a.fail_list = fail_list;
+    a.fail_count = fail_count;
+    const size_t pairs_cap = ((size_t)chunk_reads + 1) / 2;
+    uint8_t* p = work;
+    a.bnd = reinterpret_cast<uint2*>(p);
+    p += round256(pairs_cap * R * sizeof(uint2));
+    a.blk = reinterpret_cast<uint2*>(p);
+    p += round256(pairs_cap * a.nblk * sizeof(uint2));
+    a.best0 = reinterpret_cast<uint32_t*>(p);
+    p += round256(pairs_cap * 4);
+    const size_t per = round256((size_t)chunk_reads * 4 + 8);
+    a.anchor = reinterpret_cast<uint32_t*>(p);
+    uint32_t* keys_out = reinterpret_cast<uint32_t*>(p + per);
+    uint32_t* ids_in = reinterpret_cast<uint32_t*>(p + 2 * per);
+    uint32_t* ids_out = reinterpret_cast<uint32_t*>(p + 3 * per);
+    p += 4 * per;
+    void* temp = p;
+    size_t temp_bytes = prune_sort_temp_bytes(chunk_reads);
+    int key_bits = 1;
+    while ((1u << key_bits) < R + 1 && key_bits < 32) ++key_bits;
+
+    hipError_t e = hipMemsetAsync(fail_count, 0, 4, stream);
+    if (e != hipSuccess) return e;
+    for (uint32_t first = 0; first < n; first += chunk_reads) {
+        a.first = first;
+        a.n = std::min<uint32_t>(chunk_reads, n - first);
+        a.n_pairs = (a.n + 1) / 2;
+        a.floor0 = floor_strip;
+        hipLaunchKernelGGL((prune_strip_kernel<PR_CP>), dim3((a.n_pairs + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, a);
+        hipLaunchKernelGGL(iota32_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, ids_in, a.n);
+        e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t*)a.anchor, keys_out, (const uint32_t*)ids_in, ids_out,
+                                               (int)a.n, 0, key_bits, stream);
+        if (e != hipSuccess) return e;
+        a.order = ids_out;
+        a.floor0 = floor_window;
+        const uint32_t groups = (a.n + 1) / 2, per_block = BLOCK / PR_G2;
+        hipLaunchKernelGGL((prune_window_kernel<PR_CP, PR_C2>), dim3((groups + per_block - 1) / per_block), dim3(BLOCK), 0, stream, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace zsw

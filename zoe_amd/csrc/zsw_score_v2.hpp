@@ -86,6 +86,9 @@ struct ScoreArgsV2 {
     // takes part from row ref_len - rev_ref_end[id] on with reverse(read[..rev_query_end[id]]), and the outputs are the starts.
     const uint32_t* rev_ref_end;
     const uint32_t* rev_query_end;
+    // non-null: the number of items is read from the device (a worklist filled by an earlier kernel of the stream); the grid
+    // is sized for b.n_items, blocks past the list return at once
+    const uint32_t* n_items_dev = nullptr;
 };
 
 template <int G, int C, int MODE, bool WIDE = false, bool TILED = false>
@@ -101,7 +104,9 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
     const int g = tid & (G - 1);
     const uint32_t group = blockIdx.x * (BLOCK / G) + tid / G;
     const uint32_t itemA = 2 * group, itemB = 2 * group + 1;
-    const bool validA = itemA < a.b.n_items, validB = itemB < a.b.n_items;
+    const uint32_t n_items = a.n_items_dev ? min(*a.n_items_dev, a.b.n_items) : a.b.n_items;
+    if (2 * blockIdx.x * (BLOCK / G) >= n_items) return;
+    const bool validA = itemA < n_items, validB = itemB < n_items;
     const uint32_t idA = validA ? (a.b.items ? a.b.items[itemA] : itemA) : 0;
     const uint32_t idB = validB ? (a.b.items ? a.b.items[itemB] : itemB) : 0;
 
