@@ -127,6 +127,7 @@ unsafe extern "C" {
     fn zsw_timing_enable(ctx: *mut ZswContext, enable: i32) -> i32;
     fn zsw_timing_read(ctx: *mut ZswContext, seconds: *mut f64, launches: *mut u64) -> i32;
     fn zsw_debug_set(ctx: *mut ZswContext, flags: u32) -> i32;
+    fn zsw_prune_rescored(ctx: *mut ZswContext, out_reads: *mut u64) -> i32;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -560,6 +561,14 @@ impl GpuContext {
     pub fn debug_set(&self, flags: u32) -> Result<(), GpuError> {
         // SAFETY: live context
         self.check(unsafe { zsw_debug_set(self.raw, flags) }, 0, 0)
+    }
+
+    /// `zsw_prune_rescored`: reads of the last column-pruned score call that were rescored over all their cells.
+    pub fn prune_rescored(&self) -> Result<u64, GpuError> {
+        let mut n = 0u64;
+        // SAFETY: live context, valid out-pointer
+        self.check(unsafe { zsw_prune_rescored(self.raw, &mut n) }, 0, 0)?;
+        Ok(n)
     }
 }
 

@@ -269,6 +269,10 @@ typedef enum zsw_debug_flag {
 } zsw_debug_flag;
 zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags);
 
+/* Reads of the context's last column-pruned score call that failed a bound check and were scored over all their cells
+ * (0 if the last score call did not take the pruned pass). Synchronises the device. Diagnostics for tests and bench.py. */
+zsw_error zsw_prune_rescored(zsw_context* ctx, uint64_t* out_reads);
+
 #ifdef __cplusplus
 }
 #endif

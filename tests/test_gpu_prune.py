@@ -1,0 +1,204 @@
+"""GPU parity tests of the column-pruned score-only pass (zsw_score_prune.hip, ZSW_DEBUG_SCORE_PRUNE).
+
+The pruned pass must return exactly what the full pass returns — for every input, because a read whose bound checks fail
+is rescored over all its cells. Checker: oracle/ (CPU restatement) on every case, plus the default GPU path on the large
+batch. The cases are built to hit both outcomes: reads that pass the checks (the fast path) and reads that cannot (repeats,
+long gaps, chimeras, junk ends, low scores), and `prune_rescored()` shows which happened.
+"""
+import numpy as np
+import pytest
+
+from conftest import stable_seed
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def za():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests need an MI355X")
+    import zoe_amd
+
+    return zoe_amd
+
+
+@pytest.fixture
+def pruned(za):
+    from zoe_amd import _lib
+
+    ctx = za.SwContext.get(0)
+    ctx.debug_set(_lib.DEBUG_SCORE_PRUNE)
+    yield ctx
+    ctx.debug_set(0)
+
+
+def _score(za, reads2d, matrix, go, ge, ref):
+    import torch
+
+    n, L = reads2d.shape
+    rb = za.ReadBatch.from_fixed(torch.from_numpy(np.ascontiguousarray(reads2d).reshape(-1)).cuda(), L)
+    out = za.LocalProfilesBatch.new_with_w256(rb, matrix, go, ge).sw_score_from_i8(ref)
+    return out.score.cpu().numpy().view(np.uint32), out.status.cpu().numpy(), out.tier.cpu().numpy()
+
+
+def _check(za, oracle, reads2d, matrix, go, ge, ref, ctx):
+    sc = oracle.Scoring(matrix.signed_weights(), matrix.mapping.index_map, go, ge)
+    want_s, want_st, want_tier = oracle.batch_score_w256(8, sc, reads2d, ref, fixed_len=reads2d.shape[1], threads=8)
+    s, st, tier = _score(za, reads2d, matrix, go, ge, ref)
+    rescored = ctx.prune_rescored()
+    assert np.array_equal(st, want_st)
+    assert np.array_equal(s, want_s)
+    assert np.array_equal(tier, want_tier)
+    return rescored
+
+
+def _mutate(rng, seq, subs=0.01, indel=0.002):
+    out = []
+    for b in seq:
+        u = rng.random()
+        if u < indel:
+            continue
+        if u < 2 * indel:
+            out.append(rng.choice(list(b"ACGT")))
+        out.append(rng.choice(list(b"ACGT")) if rng.random() < subs else b)
+    return out
+
+
+def _fit(rng, seq, L):
+    seq = list(seq)[:L]
+    while len(seq) < L:
+        seq.append(rng.choice(list(b"ACGT")))
+    return np.array(seq, dtype=np.uint8)
+
+
+@pytest.mark.parametrize("L", [65, 100, 150, 151, 152])
+@pytest.mark.parametrize("n", [1, 2, 3, 513, 4001])
+def test_pruned_pass_equals_oracle_on_synthetic_reads(za, oracle, pruned, L, n):
+    from zoe_amd import synth
+
+    ref = synth.reference_host(2000)
+    reads = synth.reads_host(ref, stable_seed(L, n) % 100000, n, L)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    rescored = _check(za, oracle, reads, dna, -10, -1, ref, pruned)
+    if n >= 513:
+        assert rescored < n // 2  # most synthetic reads pass the checks
+
+
+def test_lengths_outside_the_pruned_range_take_the_full_pass(za, oracle, pruned):
+    from zoe_amd import synth
+
+    ref = synth.reference_host(2000)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    for L in (64, 153, 200):
+        reads = synth.reads_host(ref, 5, 300, L)
+        assert _check(za, oracle, reads, dna, -10, -1, ref, pruned) == 0
+    long_ref = synth.reference_host(2049)
+    assert _check(za, oracle, synth.reads_host(long_ref, 5, 300, 150), dna, -10, -1, long_ref, pruned) == 0
+
+
+@pytest.mark.parametrize("R", [1, 10, 31, 32, 33, 150, 500, 2047, 2048])
+def test_reference_lengths(za, oracle, pruned, R):
+    from zoe_amd import synth
+
+    ref = synth.reference_host(R)
+    big = synth.reference_host(2000)
+    reads = synth.reads_host(big, 9, 600, 150)  # sampled from another reference: partial and no hits
+    if R >= 150:
+        reads[:300] = synth.reads_host(ref, 9, 300, 150)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    _check(za, oracle, reads, dna, -10, -1, ref, pruned)
+
+
+def _adversarial_reads(rng, ref, L):
+    """Reads that stress each bound check: second copies elsewhere, gaps longer than the window margin, chimeras, junk at
+    either end, reads hanging over the reference ends, low complexity, N runs, no hit at all."""
+    R = len(ref)
+    refl = list(ref)
+    rows = []
+
+    def sample(p, k):
+        return refl[p : p + k]
+
+    for _ in range(60):  # plain
+        p = int(rng.integers(0, R - L))
+        rows.append(_fit(rng, _mutate(rng, sample(p, L)), L))
+    for _ in range(60):  # long deletion (reference bases skipped) / long insertion
+        p = int(rng.integers(0, R - 2 * L))
+        cut = int(rng.integers(20, L - 20))
+        gap = int(rng.integers(5, 80))
+        rows.append(_fit(rng, sample(p, cut) + sample(p + cut + gap, L - cut), L))
+        ins = [rng.choice(list(b"ACGT")) for _ in range(gap % 40 + 3)]
+        rows.append(_fit(rng, sample(p, cut) + ins + sample(p + cut, L), L))
+    for _ in range(60):  # chimeras: two far-apart pieces, in either order
+        p1, p2 = int(rng.integers(0, R - L)), int(rng.integers(0, R - L))
+        cut = int(rng.integers(10, L - 10))
+        rows.append(_fit(rng, sample(p1, cut) + sample(p2, L - cut), L))
+    for _ in range(60):  # junk prefix / junk suffix of every size
+        p = int(rng.integers(0, R - L))
+        j = int(rng.integers(1, L))
+        junk = [rng.choice(list(b"ACGT")) for _ in range(j)]
+        rows.append(_fit(rng, junk + sample(p + j, L - j), L))
+        rows.append(_fit(rng, sample(p, L - j) + junk, L))
+    for k in range(1, L, 7):  # hanging over the ends of the reference
+        rows.append(_fit(rng, sample(R - k, k), L))
+        rows.append(_fit(rng, [rng.choice(list(b"ACGT")) for _ in range(L - k)] + sample(0, k), L))
+    for unit in (b"A", b"AC", b"ACG", b"AACCGGTT"):  # low complexity
+        rows.append(_fit(rng, list(unit * L), L))
+    rows.append(np.full(L, ord("N"), dtype=np.uint8))
+    rows.append(_fit(rng, list(b"N" * 40) + sample(100, L), L))
+    for _ in range(40):  # no hit
+        rows.append(_fit(rng, [], L))
+    for _ in range(40):  # heavily mutated
+        p = int(rng.integers(0, R - L))
+        rows.append(_fit(rng, _mutate(rng, sample(p, L), subs=0.15, indel=0.03), L))
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("scheme", [(2, -5, -10, -1), (1, -1, -2, -1), (5, -4, -12, -2), (3, -2, -4, 0), (1, -3, -5, -2)])
+@pytest.mark.parametrize("kind", ["random", "two_copies", "tandem", "low_complexity"])
+def test_adversarial_reads_and_references(za, oracle, pruned, scheme, kind):
+    from zoe_amd import synth
+
+    rng = np.random.default_rng(stable_seed(scheme, kind))
+    base = synth.reference_host(2000)
+    if kind == "two_copies":  # every read has two equally good homes (one with a few differences)
+        half = bytearray(base[:1000])
+        other = bytearray(half)
+        for i in range(0, 1000, 97):
+            other[i] = ord("A") if other[i] != ord("A") else ord("C")
+        ref = bytes(half + other)
+    elif kind == "tandem":
+        unit = base[:37]
+        ref = bytes((unit * 60)[:2000])
+    elif kind == "low_complexity":
+        ref = bytes((b"A" * 300 + base[:400] + b"AC" * 200 + base[400:800] + b"T" * 100)[:2000])
+    else:
+        ref = base
+    m, x, go, ge = scheme
+    matrix = za.WeightMatrix.new_dna_matrix(m, x, b"N")
+    reads = _adversarial_reads(rng, ref, 150)
+    rescored = _check(za, oracle, reads, matrix, go, ge, ref, pruned)
+    if kind == "random":
+        assert 0 < rescored < len(reads)  # both outcomes occur
+
+
+def test_large_batch_equals_the_full_pass_and_is_mostly_pruned(za, pruned):
+    """2.5 M reads (more than one round of the two kernels): bit-identical to the full pass."""
+    import torch
+
+    from zoe_amd import synth
+
+    n = 2_500_000
+    ref = synth.reference_host(2000)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    rb = synth.reads_device(pruned, ref, 0, n, 150)
+    prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
+    got = prof.sw_score_from_i8(ref)
+    rescored = pruned.prune_rescored()
+    pruned.debug_set(0)
+    want = prof.sw_score_from_i8(ref)
+    assert pruned.prune_rescored() == 0
+    assert torch.equal(got.score, want.score) and torch.equal(got.status, want.status) and torch.equal(got.tier, want.tier)
+    assert 0 < rescored < n // 10

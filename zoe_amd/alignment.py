@@ -254,6 +254,12 @@ class SwContext:
         """zsw_debug_set: kernel-selection overrides (_lib.DEBUG_*) for the parity tests; 0 restores the defaults."""
         self.check(self.lib.zsw_debug_set(self.h, int(flags)))
 
+    def prune_rescored(self) -> int:
+        """zsw_prune_rescored: reads of the last column-pruned score call that were rescored over all their cells."""
+        v = C.c_uint64(0)
+        self.check(self.lib.zsw_prune_rescored(self.h, C.byref(v)))
+        return int(v.value)
+
     def timing_enable(self, on: bool):
         self.check(self.lib.zsw_timing_enable(self.h, int(on)))
 

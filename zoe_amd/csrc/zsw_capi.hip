@@ -283,6 +283,7 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
         ZSW_HIP(ctx, ctx->d_prune.ensure(prune_workspace_bytes(chunk, (uint32_t)ctx->ref_len)));
         ZSW_HIP(ctx, ctx->d_prune_list.ensure((size_t)n * 4 + 4));
         ZSW_HIP(ctx, ctx->d_prune_count.ensure(4));
+        ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 4, stream));
         ctx->prune_chunk = chunk;
     }
     uint32_t need = std::max<uint32_t>(512, (st->max_len + 127) / 128 * 128);
@@ -1220,6 +1221,18 @@ zsw_error zsw_selftest(zsw_context* ctx) {
 zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags) {
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     ctx->debug = flags;
+    return ZSW_OK;
+}
+
+zsw_error zsw_prune_rescored(zsw_context* ctx, uint64_t* out_reads) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx || !out_reads) return ZSW_ERR_INVALID_ARGUMENT;
+    *out_reads = 0;
+    if (!ctx->prune_chunk || !ctx->d_prune_count.p) return ZSW_OK;
+    uint32_t cnt = 0;
+    ZSW_HIP(ctx, hipDeviceSynchronize());
+    ZSW_HIP(ctx, hipMemcpy(&cnt, ctx->d_prune_count.p, 4, hipMemcpyDeviceToHost));
+    *out_reads = cnt;
     return ZSW_OK;
 }
 
