@@ -265,7 +265,8 @@ typedef enum zsw_debug_flag {
     ZSW_DEBUG_NO_SIDE_STREAMS = 16,  /* score: length classes of a ragged batch run one after the other */
     ZSW_DEBUG_NO_PIPELINE = 32,      /* score: host batches are copied whole before the kernel */
     ZSW_DEBUG_ALIGN_NO_PACKED = 64,  /* align: the 32-bit one-read-per-lane-group kernel answers every group */
-    ZSW_DEBUG_SCORE_PRUNE = 128      /* score: fixed-length short-read batches take the column-pruned pass (zsw_score_prune.hip) */
+    ZSW_DEBUG_SCORE_PRUNE = 128,     /* score: fixed-length short-read batches of 65,536 reads or more take the column-pruned pass (zsw_score_prune.hip) */
+    ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE = 256 /* with SCORE_PRUNE: batches of every size do (the full pass is faster for small ones; tests) */
 } zsw_debug_flag;
 zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags);
 

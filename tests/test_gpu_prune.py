@@ -29,7 +29,7 @@ def pruned(za):
     from zoe_amd import _lib
 
     ctx = za.SwContext.get(0)
-    ctx.debug_set(_lib.DEBUG_SCORE_PRUNE)
+    ctx.debug_set(_lib.DEBUG_SCORE_PRUNE | _lib.DEBUG_SCORE_PRUNE_ANY_SIZE)
     yield ctx
     ctx.debug_set(0)
 
@@ -202,3 +202,56 @@ def test_large_batch_equals_the_full_pass_and_is_mostly_pruned(za, pruned):
     assert pruned.prune_rescored() == 0
     assert torch.equal(got.score, want.score) and torch.equal(got.status, want.status) and torch.equal(got.tier, want.tier)
     assert 0 < rescored < n // 10
+
+
+def _tensors(x):
+    return [getattr(x, f) for f in ("score", "status", "tier", "ref_start", "ref_end", "query_start", "query_end") if getattr(x, f, None) is not None]
+
+
+@pytest.mark.parametrize("kind", ["synthetic", "adversarial", "two_copies"])
+def test_ends_ranges_and_alignments_with_the_pruned_first_pass(za, oracle, pruned, kind):
+    """Score + ends (MODE 1, 2 of the window kernel: first row holding the maximum, then first column) behind sw_score_ends,
+    sw_score_ranges, the alignment's first pass and the 3-pass alignment: identical to the full pass, and to the oracle."""
+    import torch
+
+    from zoe_amd import _lib, synth
+
+    rng = np.random.default_rng(stable_seed("ends", kind))
+    base = synth.reference_host(2000)
+    if kind == "two_copies":  # two identical homes: the tie rule picks the first row
+        ref = bytes(base[:1000] + base[:1000])
+    else:
+        ref = base
+    reads = synth.reads_host(ref, 3, 3000, 150) if kind == "synthetic" else _adversarial_reads(rng, ref, 150)
+    n = len(reads)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    rb = za.ReadBatch.from_fixed(torch.from_numpy(np.ascontiguousarray(reads).reshape(-1)).cuda(), 150)
+    direct = za.StripedProfileBatch(rb, dna, -10, -1, "i16", 16)
+    casc = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
+    seq = za.SeqSrc.Reference(ref)
+
+    def run_all():
+        return (direct.sw_score_ends(seq), direct.sw_score_ranges(seq), casc.sw_score_ranges_from_i8(seq), casc.sw_align_from_i8(seq),
+                casc.sw_align_from_i8_3pass(seq))
+
+    got = run_all()
+    rescored = pruned.prune_rescored()
+    pruned.debug_set(0)
+    want = run_all()
+    pruned.debug_set(_lib.DEBUG_SCORE_PRUNE | _lib.DEBUG_SCORE_PRUNE_ANY_SIZE)
+    for g, w in zip(got[:3], want[:3]):
+        for tg, tw in zip(_tensors(g), _tensors(w)):
+            assert torch.equal(tg, tw)
+    for g, w in zip(got[3:], want[3:]):
+        assert np.array_equal(g.status, w.status)
+        for i in range(n):
+            assert g.key(i) == w.key(i), i
+    sc = oracle.Scoring(dna.signed_weights(), dna.mapping.index_map, -10, -1)
+    rg = got[1]
+    for i in range(0, n, max(1, n // 150)):
+        st, s, rr, qr = oracle.score_ranges("i16", 16, sc, reads[i], ref)
+        assert int(rg.status[i]) == st, i
+        if st == 0:
+            assert (int(rg.score[i]), (int(rg.ref_start[i]), int(rg.ref_end[i])), (int(rg.query_start[i]), int(rg.query_end[i]))) == (s, rr, qr), i
+    if kind == "synthetic":
+        assert 0 < rescored < n // 2  # the pruned first pass ran (the 2 % random reads always go back), and mostly pruned

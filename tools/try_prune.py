@@ -37,3 +37,26 @@ print(f"n={n}: default {t_base*1e3:.2f} ms ({n/t_base/1e6:.1f} M/s), pruned {t_p
 if not same:
     bad = torch.nonzero(base.score != pr.score).flatten()[:10].cpu().numpy()
     print("first differences (id, default, pruned):", [(int(i), int(base.score[i]), int(pr.score[i])) for i in bad], "of", int((base.score != pr.score).sum()))
+
+
+def timed(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+if n <= 2_000_000:
+    seq = zoe_amd.SeqSrc.Reference(ref)
+    direct = zoe_amd.StripedProfileBatch(rb, dna, -10, -1, "i16", 16)
+    for name, fn in (("sw_score_ranges", lambda: direct.sw_score_ranges(seq)), ("sw_align_from_i8", lambda: prof.sw_align_from_i8(seq)),
+                     ("sw_align_from_i8_3pass", lambda: prof.sw_align_from_i8_3pass(seq))):
+        ctx.debug_set(0)
+        t0 = timed(fn)
+        ctx.debug_set(_lib.DEBUG_SCORE_PRUNE)
+        t1 = timed(fn)
+        ctx.debug_set(0)
+        print(f"{name}: default {t0*1e3:.1f} ms ({n/t0/1e6:.1f} M/s), pruned first pass {t1*1e3:.1f} ms ({n/t1/1e6:.1f} M/s)")

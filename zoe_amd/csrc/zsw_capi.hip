@@ -277,7 +277,8 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     }
     ZSW_HIP(ctx, ctx->d_bucket_counts.ensure(64 * 4));
     ctx->prune_chunk = 0;
-    if ((ctx->debug & ZSW_DEBUG_SCORE_PRUNE) && !want_ends && !reads->offsets && n > 0 && st->max_len > (uint32_t)PR_CP + 40 &&
+    if ((ctx->debug & ZSW_DEBUG_SCORE_PRUNE) && !reads->offsets && n > 0 &&
+        (n >= PR_MIN_READS || (ctx->debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) && st->max_len > (uint32_t)PR_CP + 40 &&
         st->max_len <= (uint32_t)(PR_CP + PR_G2 * PR_C2) && ctx->ref_len > 0 && ctx->ref_len <= 2048) {
         const uint32_t chunk = std::min<uint32_t>((uint32_t)n, PR_CHUNK_READS);
         ZSW_HIP(ctx, ctx->d_prune.ensure(prune_workspace_bytes(chunk, (uint32_t)ctx->ref_len)));

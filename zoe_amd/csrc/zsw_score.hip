@@ -587,17 +587,17 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
             if (e != hipSuccess) return e;
             return finish_worklist();
         }
-        // Score only, short reads, a reference that fits one row table: the column-pruned pass; the reads it hands back
+        // Short reads, a reference that fits one row table: the column-pruned pass; the reads it hands back
         // (a check failed: some uncomputed cell might matter) are scored over all their cells, on the device-side list.
         ScoreArgsV2 ap = a2;
         bool pruned = false;
-        if (mode == 0 && use_v2 && !b.items && ws.prune_work && (ws.debug & ZSW_DEBUG_SCORE_PRUNE) && build_tables_v2(h_sc, 1, &ap)) {
+        if (use_v2 && !b.items && (b.n_items >= PR_MIN_READS || (ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) && ws.prune_work && (ws.debug & ZSW_DEBUG_SCORE_PRUNE) && build_tables_v2(h_sc, 1, &ap)) {
             const uint32_t floor_strip = ap.floor0, limit_strip = ap.limit;
             if (build_tables_v2(h_sc, PR_G2, &ap) && prune_applicable(h_sc, max_len, ref_len, std::min(limit_strip, ap.limit))) {
                 if (timer) timer->begin(stream);
                 ap.b = b;
                 e = launch_score_pruned(ap, floor_strip, ap.floor0, h_sc, ws.prune_work, ws.prune_bytes, ws.prune_chunk, ws.prune_fail_list,
-                                        ws.prune_fail_count, stream);
+                                        ws.prune_fail_count, mode, stream);
                 if (e == hipSuccess) {
                     pruned = true;
                     if (build_tables_v2(h_sc, G, &a2)) {

@@ -198,8 +198,8 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_strip_kernel(Pru
     }
 }
 
-template <int CP, int C>
-__global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_window_kernel(PruneArgs a) {
+template <int CP, int C, int MODE>
+__global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel(PruneArgs a) {
     constexpr int G = PR_G2;
     __shared__ uint2 rp[CH + G];
     __shared__ uint2 swt[9];
@@ -259,6 +259,13 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_window_kernel(Pr
         E[c] = pk_addu(Dr, ge2);
     }
     uint32_t best = 0;
+    uint32_t snap[MODE == 2 ? C : 1];  // MODE 2: the H row of each read's latest rise (as in score_kernel_v2)
+    if (MODE == 2) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) snap[MODE == 2 ? c : 0] = 0;
+    }
+    uint32_t snapD = 0;
+    int rA = 0, rB = 0;  // window row of the lane's latest rise
     uint32_t Fout = Dr, Hlast = Dr, Hin_prev = Dr;
     uint2 ldA = make_uint2(0u, 0u), ldB = make_uint2(0u, 0u);
     if (g == 0 && validA && a0 < R) {
@@ -319,20 +326,64 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_window_kernel(Pr
         }
         Fout = F;
         Hlast = H[C - 1];
-        best = pk_maxu(best, pk_subu(rmax, Dr));
+        const uint32_t nb = pk_maxu(best, pk_subu(rmax, Dr));
+        if (MODE != 0) {
+            const uint32_t ch = nb ^ best;
+            if (ch & 0xffffu) rA = row;
+            if (ch >> 16) rB = row;
+            if (MODE == 2) {
+                const uint32_t m = ((ch & 0xffffu) ? 0xffffu : 0u) | ((ch >> 16) ? 0xffff0000u : 0u);
+#pragma unroll
+                for (int c = 0; c < C; ++c) snap[MODE == 2 ? c : 0] = (H[c] & m) | (snap[MODE == 2 ? c : 0] & ~m);
+                snapD = (Dr & m) | (snapD & ~m);
+            }
+        }
+        best = nb;
         w = wn;
     }
 
     // ---- the read's score so far, and the three checks ----
-    int bA2 = (int)(best & 0xffffu), bB2 = (int)(best >> 16);
+    const int lbA = (int)(best & 0xffffu), lbB = (int)(best >> 16);
+    int bA2 = lbA, bB2 = lbB;
 #pragma unroll
     for (int d = 1; d < G; d <<= 1) {
         bA2 = max(bA2, __shfl_xor(bA2, d, G));
         bB2 = max(bB2, __shfl_xor(bB2, d, G));
     }
+    // ends (MODE 1, 2): first row holding the window's maximum, then the first column of that row (striped.rs:296-321)
+    uint32_t reA = 0, reB = 0, qeA = 0, qeB = 0;
+    if (MODE != 0) {
+        int kA = (lbA == bA2) ? rA : 0x7fffffff, kB = (lbB == bB2) ? rB : 0x7fffffff;
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) {
+            kA = min(kA, __shfl_xor(kA, d, G));
+            kB = min(kB, __shfl_xor(kB, d, G));
+        }
+        reA = (uint32_t)(a0 + kA) + 1;
+        reB = (uint32_t)(a0 + kB) + 1;
+        if (MODE == 2) {
+            int cA = 0x7fffffff, cB = 0x7fffffff;
+            const int sdA = (int)(snapD & 0xffffu), sdB = (int)(snapD >> 16);
+#pragma unroll
+            for (int c = C - 1; c >= 0; --c) {
+                const uint32_t sv = snap[MODE == 2 ? c : 0];
+                if ((int)(sv & 0xffffu) - sdA == bA2) cA = CP + g * C + c;
+                if ((int)(sv >> 16) - sdB == bB2) cB = CP + g * C + c;
+            }
+            if (!(lbA == bA2 && rA == kA)) cA = 0x7fffffff;
+            if (!(lbB == bB2 && rB == kB)) cB = 0x7fffffff;
+#pragma unroll
+            for (int d = 1; d < G; d <<= 1) {
+                cA = min(cA, __shfl_xor(cA, d, G));
+                cB = min(cB, __shfl_xor(cB, d, G));
+            }
+            qeA = (uint32_t)cA + 1;
+            qeB = (uint32_t)cB + 1;
+        }
+    }
     const uint32_t s0A = validA ? a.best0[ridA >> 1] : 0, s0B = validB ? a.best0[ridB >> 1] : 0;
-    const int SA = max(bA2, (int)((ridA & 1) ? s0A >> 16 : s0A & 0xffffu));
-    const int SB = max(bB2, (int)((ridB & 1) ? s0B >> 16 : s0B & 0xffffu));
+    const int stripA = (int)((ridA & 1) ? s0A >> 16 : s0A & 0xffffu), stripB = (int)((ridB & 1) ? s0B >> 16 : s0B & 0xffffu);
+    const int SA = max(bA2, stripA), SB = max(bB2, stripB);
     const int maxw = (int)a.maxw;
     const int remA = max(0, (int)lenA - CP), remB = max(0, (int)lenB - CP);
     // V3: what can still leave this lane's last row (E holds the next row's E; Fout moves right into the next lane's columns)
@@ -380,11 +431,17 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_window_kernel(Pr
             const uint32_t id = a.first + (second ? ridB : ridA);
             const uint32_t len = second ? lenB : lenA;
             const int S = second ? SB : SA, bound = second ? wB : wA;
+            // score only: a path outside the computed cells matters if it can score MORE than S. With ends it also matters
+            // if it can score S (it could end in an earlier row), and the maximum has to lie right of the strip, whose cells keep
+            // no coordinates.
+            const bool redo = MODE == 0 ? bound > S : (bound >= S || (second ? stripB : stripA) >= S);
             if (len == 0) {
                 a.out.score[id] = 0;
                 a.out.status[id] = ZSW_STATUS_EMPTY;
                 if (a.out.tier) a.out.tier[id] = 0;
-            } else if (bound > S) {  // something outside the computed cells could still score more: all cells for this read
+                if (MODE != 0 && a.out.ref_end) a.out.ref_end[id] = 0;
+                if (MODE == 2 && a.out.query_end) a.out.query_end[id] = 0;
+            } else if (redo) {  // all cells for this read
                 const uint32_t k = atomicAdd(a.fail_count, 1u);
                 a.fail_list[k] = id;
             } else {
@@ -394,6 +451,9 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_window_kernel(Pr
                 a.out.score[id] = score;
                 a.out.status[id] = status;
                 if (a.out.tier) a.out.tier[id] = tier;
+                const bool some = status == ZSW_STATUS_SOME;
+                if (MODE != 0 && a.out.ref_end) a.out.ref_end[id] = some ? (second ? reB : reA) : 0;
+                if (MODE == 2 && a.out.query_end) a.out.query_end[id] = some ? (second ? qeB : qeA) : 0;
             }
         }
     }
@@ -434,7 +494,7 @@ bool prune_applicable(const ScoringDev& s, uint32_t max_len, uint32_t ref_len, u
 // fail_list (device count in fail_count, zeroed here). `a2` carries the v2 tables and drift constants for G = 1 and G = 4
 // (the constants do not depend on G below 16 rows of slack, see the caller).
 hipError_t launch_score_pruned(const ScoreArgsV2& a2, uint32_t floor_strip, uint32_t floor_window, const ScoringDev& h_sc, uint8_t* work,
-                               size_t work_bytes, uint32_t chunk_reads, uint32_t* fail_list, uint32_t* fail_count, hipStream_t stream) {
+                               size_t work_bytes, uint32_t chunk_reads, uint32_t* fail_list, uint32_t* fail_count, int mode, hipStream_t stream) {
     const uint32_t n = a2.b.n_reads, R = a2.ref_len;
     if (n == 0) return hipSuccess;
     if (work_bytes < prune_workspace_bytes(chunk_reads, R)) return hipErrorNotSupported;
@@ -493,7 +553,10 @@ hipError_t launch_score_pruned(const ScoreArgsV2& a2, uint32_t floor_strip, uint
         a.order = ids_out;
         a.floor0 = floor_window;
         const uint32_t groups = (a.n + 1) / 2, per_block = BLOCK / PR_G2;
-        hipLaunchKernelGGL((prune_window_kernel<PR_CP, PR_C2>), dim3((groups + per_block - 1) / per_block), dim3(BLOCK), 0, stream, a);
+        const dim3 wgrid((groups + per_block - 1) / per_block);
+        if (mode == 0) hipLaunchKernelGGL((prune_window_kernel<PR_CP, PR_C2, 0>), wgrid, dim3(BLOCK), 0, stream, a);
+        else if (mode == 1) hipLaunchKernelGGL((prune_window_kernel<PR_CP, PR_C2, 1>), wgrid, dim3(BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((prune_window_kernel<PR_CP, PR_C2, 2>), wgrid, dim3(BLOCK), 0, stream, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
