@@ -25,6 +25,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -57,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=2048, help="reads checked against the oracle after the timed region")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short config-3 / config-5 measurements")
+    ap.add_argument("--no-pruned", action="store_true", help="skip the run of the headline workload with the opt-in column-pruned pass")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on a one-GPU box together with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -174,6 +177,47 @@ def rooflines(algo_bytes: float, kernel_s: float, valu_instr: float = None, sour
     return out
 
 
+def pruned_headline(zoe_amd, ctx, profiles, reference, full, n_reads, steps):
+    """The headline workload again with the opt-in column-pruned pass (zsw_debug_set(ZSW_DEBUG_SCORE_PRUNE),
+    zoe_amd/csrc/zsw_score_prune.hip): every score, status and tier must equal the full pass's (`full`), all n_reads of them.
+    Not part of `value`: `value` is the default path, which computes every cell."""
+    import torch
+
+    from zoe_amd import _lib
+
+    ctx.debug_set(_lib.DEBUG_SCORE_PRUNE)
+    try:
+        got = profiles.sw_score_from_i8(reference)  # warm-up: workspace allocation
+        torch.cuda.synchronize()
+        ctx.timing_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            got = profiles.sw_score_from_i8(reference)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ks, launches = ctx.timing_read()
+        ctx.timing_enable(False)
+        rescored = ctx.prune_rescored()
+    finally:
+        ctx.debug_set(0)
+    same = bool(torch.equal(got.score, full.score) and torch.equal(got.status, full.status) and torch.equal(got.tier, full.tier))
+    if not same:
+        raise SystemExit("PARITY FAILURE: the column-pruned pass differs from the full pass")
+    return {
+        "reads_per_s": n_reads * steps / dt,
+        "ms_per_step": dt / steps * 1e3,
+        "kernels_ms_per_step": ks / max(launches, 1) * 1e3,
+        "identical_to_the_full_pass": f"all {n_reads} scores, statuses and tiers compared in this run",
+        "reads_rescored_over_all_cells": rescored,
+        "rescored_fraction": rescored / n_reads,
+        "how": "a 24-column strip over every reference row (prune_strip_kernel) + the other 126 columns in a window of rows around "
+               "the read's anchor (prune_window_kernel); three upper-bound checks per read decide whether any uncomputed cell could "
+               "matter; reads that fail are rescored by score_kernel_v2 over all their cells. Exact for every input; opt-in "
+               "(zsw_debug_set(ZSW_DEBUG_SCORE_PRUNE)); see DESIGN.md 4.1d",
+        "work": "cells computed / cells of the full pass = 0.29 on this workload (profiles/r02_prune_summary.txt)",
+    }
+
+
 def secondary_configs(zoe_amd, synth, ctx, matrix):
     """Measurements of the other BASELINE.json configs on this GPU (after the timed region; not part of `value`):
     configs[2] full traceback at its full size (10 M reads) and configs[4] mixed lengths vs a 30 kb reference (1 M reads),
@@ -194,6 +238,16 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
         ks, _ = ctx.timing_read()
         return r, dt, ks
 
+    def with_pruning(fn):
+        """the same call with the opt-in column-pruned first pass (bit-identical)"""
+        from zoe_amd import _lib
+
+        ctx.debug_set(_lib.DEBUG_SCORE_PRUNE)
+        try:
+            return timed(fn)
+        finally:
+            ctx.debug_set(0)
+
     ctx.timing_enable(True)
     # configs[2]: 10 M reads, sw_simd_align with CIGAR, bit-exact vs the CPU path of the same <T, N>
     n_full = 10_000_000
@@ -208,6 +262,11 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
              "kernel": "zsw::align_kernel_pk<16,10> (+ <32,5> for the reads that answer at i8x32); pass 1 = score_kernel_v2<4,38,1>"}
     # algorithmic bytes: read in, record out (score, 4 coordinates, 2 lengths, count, offset = 40 B), 5 B per ciglet
     entry.update(rooflines(n_full * (READ_LEN + 4.0) + n_some * 40.0 + n_cig * 5.0, ks, ALIGN_PK_VALU_PER_READ * n_full, ALIGN_PK_PROFILE))
+    ap, dtp, _ = with_pruning(lambda: prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref2k)))
+    entry["with_pruned_first_pass"] = {"reads_per_s_end_to_end_incl_d2h": n_full / dtp,
+                                       "identical": bool(np.array_equal(ap.status, a.status) and np.array_equal(ap.records, a.records)
+                                                         and np.array_equal(ap.inc, a.inc) and np.array_equal(ap.op, a.op))}
+    del ap
     out["align_full_traceback_10M_x_150bp_vs_2kb"] = entry
     del a, prof, rb
     torch.cuda.empty_cache()
@@ -218,13 +277,22 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     entry = {"reads_per_s_end_to_end_incl_d2h": 1_000_000 / dt, "kernels_ms": ks * 1e3, "ciglets": int(len(a3.inc)),
              "call": "into_local_profile(..).sw_align_from_i8_3pass(SeqSrc::Reference(ref)) (three_pass.rs: ranges, then no-gaps / banded / scalar in the box)"}
     entry.update(rooflines(1e6 * (READ_LEN + 4.0) + float((a3.status == 0).sum()) * 40.0 + len(a3.inc) * 5.0, ks))
+    ap, dtp, _ = with_pruning(lambda: prof.sw_align_from_i8_3pass(zoe_amd.SeqSrc.Reference(ref2k)))
+    entry["with_pruned_first_pass"] = {"reads_per_s_end_to_end_incl_d2h": 1_000_000 / dtp,
+                                       "identical": bool(np.array_equal(ap.status, a3.status) and np.array_equal(ap.records, a3.records)
+                                                         and np.array_equal(ap.inc, a3.inc) and np.array_equal(ap.op, a3.op))}
     out["align_3pass_1M_x_150bp_vs_2kb"] = entry
-    del a3
+    del a3, ap
     # score + ranges (striped.rs:355-388) and the sneaky_snake filter on the window each read maps to
     sp = zoe_amd.StripedProfileBatch(rb, matrix, -10, -1, T="i16", N=16, device=ctx.device)
     rg, dt, ks = timed(lambda: sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k)))
     entry = {"reads_per_s": 1_000_000 / dt, "kernels_ms": ks * 1e3, "call": "StripedProfile::<i16,16,5>::sw_score_ranges(SeqSrc::Reference(ref))"}
     entry.update(rooflines(1e6 * (READ_LEN + 4.0 + 16.0), max(ks, 1e-9) if ks > 0 else dt))
+    rp_, dtp, ksp = with_pruning(lambda: sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k)))
+    entry["with_pruned_first_pass"] = {"reads_per_s": 1_000_000 / dtp, "kernels_ms": ksp * 1e3,
+                                       "identical": all(bool(torch.equal(getattr(rp_, f), getattr(rg, f)))
+                                                        for f in ("score", "status", "ref_start", "ref_end", "query_start", "query_end"))}
+    del rp_
     out["score_ranges_1M_x_150bp_vs_2kb"] = entry
     st = (rg.ref_start.to(torch.int64) - rg.query_start.to(torch.int64)).clamp(0, REF_LEN - READ_LEN).to(torch.int32)
     ln = torch.full_like(st, READ_LEN)
@@ -474,6 +542,8 @@ def main():
             },
             "parity_checked_reads": args.verify if verified else 0,
         }
+        if world == 1 and not args.no_pruned:
+            out["exact_pruning"] = pruned_headline(zoe_amd, ctx, profiles, reference, last, n_local, args.steps)
         if not args.no_secondary and world == 1:
             del reads, profiles, last
             torch.cuda.empty_cache()
