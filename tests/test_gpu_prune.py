@@ -91,11 +91,9 @@ def test_lengths_outside_the_pruned_range_take_the_full_pass(za, oracle, pruned)
 
     ref = synth.reference_host(2000)
     dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
-    for L in (64, 153, 200):
+    for L in (64, 401, 600):
         reads = synth.reads_host(ref, 5, 300, L)
         assert _check(za, oracle, reads, dna, -10, -1, ref, pruned) == 0
-    long_ref = synth.reference_host(2049)
-    assert _check(za, oracle, synth.reads_host(long_ref, 5, 300, 150), dna, -10, -1, long_ref, pruned) == 0
 
 
 @pytest.mark.parametrize("R", [1, 10, 31, 32, 33, 150, 500, 2047, 2048])
@@ -255,3 +253,47 @@ def test_ends_ranges_and_alignments_with_the_pruned_first_pass(za, oracle, prune
             assert (int(rg.score[i]), (int(rg.ref_start[i]), int(rg.ref_end[i])), (int(rg.query_start[i]), int(rg.query_end[i]))) == (s, rr, qr), i
     if kind == "synthetic":
         assert 0 < rescored < n // 2  # the pruned first pass ran (the 2 % random reads always go back), and mostly pruned
+
+
+@pytest.mark.parametrize("L,R", [(153, 2000), (250, 5000), (304, 3000), (305, 4000), (400, 30000)])
+def test_longer_reads_and_references_than_one_row_table(za, oracle, pruned, L, R):
+    """The wider classes (48-column strip; 8 x 32 and 16 x 22 window columns) and references longer than one LDS row table
+    (each block stages the rows its windows cover)."""
+    from zoe_amd import synth
+
+    rng = np.random.default_rng(stable_seed("long", L, R))
+    ref = synth.reference_host(R)
+    reads = synth.reads_host(ref, 17, 1500, L)
+    adv = _adversarial_reads(rng, ref, L)[::3]
+    reads = np.concatenate([reads, adv])
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    rescored = _check(za, oracle, reads, dna, -10, -1, ref, pruned)
+    assert 0 < rescored < len(reads)
+
+
+def test_ragged_batch_mixed_lengths_vs_30kb(za, oracle, pruned):
+    """BASELINE.json configs[4] shape: reads of 75-400 bp vs a 30 kb reference; the length classes of the ragged batch that
+    share a pruning class are pruned together, every other class takes the full pass. Empty reads included."""
+    import torch
+
+    from zoe_amd import synth
+
+    n = 6000
+    ref = synth.reference_host(30000)
+    bases, off = synth.reads_ragged_host(ref, 5, n, 75, 400)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    sc = oracle.Scoring(dna.signed_weights(), dna.mapping.index_map, -10, -1)
+    want_s, want_st, want_tier = oracle.batch_score_w256(8, sc, bases, ref, offsets=off, threads=8)
+    rb = za.ReadBatch(torch.from_numpy(bases).cuda(), n, offsets=torch.from_numpy(off.astype(np.int64)).cuda())
+    prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
+    got = prof.sw_score_from_i8(ref)
+    rescored = pruned.prune_rescored()
+    assert np.array_equal(got.status.cpu().numpy(), want_st)
+    assert np.array_equal(got.score.cpu().numpy().view(np.uint32), want_s)
+    assert np.array_equal(got.tier.cpu().numpy(), want_tier)
+    assert 0 < rescored < n // 2
+    rg = prof.sw_score_ranges_from_i8(za.SeqSrc.Reference(ref))
+    pruned.debug_set(0)
+    want = prof.sw_score_ranges_from_i8(za.SeqSrc.Reference(ref))
+    for f in ("score", "status", "tier", "ref_start", "ref_end", "query_start", "query_end"):
+        assert torch.equal(getattr(rg, f), getattr(want, f)), f

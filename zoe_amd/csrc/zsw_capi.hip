@@ -277,14 +277,13 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     }
     ZSW_HIP(ctx, ctx->d_bucket_counts.ensure(64 * 4));
     ctx->prune_chunk = 0;
-    if ((ctx->debug & ZSW_DEBUG_SCORE_PRUNE) && !reads->offsets && n > 0 &&
-        (n >= PR_MIN_READS || (ctx->debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) && st->max_len > (uint32_t)PR_CP + 40 &&
-        st->max_len <= (uint32_t)(PR_CP + PR_G2 * PR_C2) && ctx->ref_len > 0 && ctx->ref_len <= 2048) {
-        const uint32_t chunk = std::min<uint32_t>((uint32_t)n, PR_CHUNK_READS);
+    if ((ctx->debug & ZSW_DEBUG_SCORE_PRUNE) && n > 0 && (n >= PR_MIN_READS || (ctx->debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) &&
+        ctx->ref_len > 0 && (reads->offsets ? st->max_len > 64 : prune_class_for(st->max_len) >= 0)) {
+        const uint32_t chunk = prune_chunk_reads((uint32_t)n, (uint32_t)ctx->ref_len);
         ZSW_HIP(ctx, ctx->d_prune.ensure(prune_workspace_bytes(chunk, (uint32_t)ctx->ref_len)));
         ZSW_HIP(ctx, ctx->d_prune_list.ensure((size_t)n * 4 + 4));
-        ZSW_HIP(ctx, ctx->d_prune_count.ensure(4));
-        ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 4, stream));
+        ZSW_HIP(ctx, ctx->d_prune_count.ensure(8));
+        ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 8, stream));  // [0] the class in flight, [1] the call's total
         ctx->prune_chunk = chunk;
     }
     uint32_t need = std::max<uint32_t>(512, (st->max_len + 127) / 128 * 128);
@@ -1232,7 +1231,7 @@ zsw_error zsw_prune_rescored(zsw_context* ctx, uint64_t* out_reads) {
     if (!ctx->prune_chunk || !ctx->d_prune_count.p) return ZSW_OK;
     uint32_t cnt = 0;
     ZSW_HIP(ctx, hipDeviceSynchronize());
-    ZSW_HIP(ctx, hipMemcpy(&cnt, ctx->d_prune_count.p, 4, hipMemcpyDeviceToHost));
+    ZSW_HIP(ctx, hipMemcpy(&cnt, ctx->d_prune_count.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost));
     *out_reads = cnt;
     return ZSW_OK;
 }

@@ -375,6 +375,8 @@ __global__ void bucket_scatter_kernel(const uint64_t* offsets, uint32_t n, Bucke
     }
 }
 
+__global__ void add_count_kernel(const uint32_t* count, uint32_t* total) { *total += *count; }
+
 hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
                         const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
                         const ScoreWorkspace& ws, hipStream_t stream, KernelTimer* timer, int mode) {
@@ -502,6 +504,34 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
                            (const uint32_t*)nullptr, d_ref, ref_len, d_sc, rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
         return hipGetLastError();
     };
+    // Column-pruned pass over the items of `bb` (reads of at most kPruneClasses[cls].max_len bases), then score_kernel_v2 over the
+    // reads it hands back (device-side list and count). hipErrorNotSupported: not switched on, or the batch does not qualify.
+    auto prune_items = [&](const BatchDev& bb, int cls) -> hipError_t {
+        if (!use_v2 || !ws.prune_work || !(ws.debug & ZSW_DEBUG_SCORE_PRUNE)) return hipErrorNotSupported;
+        if (bb.n_items < PR_MIN_READS && !(ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) return hipErrorNotSupported;
+        ScoreArgsV2 ap = a2;
+        if (!build_tables_v2(h_sc, 1, &ap)) return hipErrorNotSupported;
+        const uint32_t floor_strip = ap.floor0, limit_strip = ap.limit;
+        if (!build_tables_v2(h_sc, kPruneClasses[cls].g, &ap)) return hipErrorNotSupported;
+        if (!prune_applicable(h_sc, kPruneClasses[cls].max_len, ref_len, std::min(limit_strip, ap.limit))) return hipErrorNotSupported;
+        int Gr = 0, Cr = 0;
+        if (!score_config_for(kPruneClasses[cls].max_len, &Gr, &Cr)) return hipErrorNotSupported;
+        hipError_t pe = hipMemsetAsync(ws.prune_fail_count, 0, 4, stream);
+        if (pe != hipSuccess) return pe;
+        ap.b = bb;
+        pe = launch_score_pruned(ap, cls, floor_strip, ap.floor0, h_sc, ws.prune_work, ws.prune_bytes, ws.prune_chunk, ws.prune_fail_list,
+                                 ws.prune_fail_count, mode, stream);
+        if (pe != hipSuccess) return pe;
+        if (!build_tables_v2(h_sc, Gr, &a2)) return hipErrorInvalidValue;
+        a2.b = bb;
+        a2.b.items = ws.prune_fail_list;
+        a2.n_items_dev = ws.prune_fail_count;
+        pe = launch_table_cfg_v2(a2, Gr, Cr, mode, stream);
+        a2.n_items_dev = nullptr;
+        if (pe != hipSuccess) return pe;
+        hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, stream, ws.prune_fail_count, ws.prune_fail_count + 1);
+        return hipGetLastError();
+    };
     if (!table_ok) {  // alphabet outside the table kernels: exact kernel over the whole batch
         if (timer) timer->begin(stream);
         e = exact_all(b);
@@ -545,6 +575,29 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         }
         const hipStream_t main_stream = stream;
         int used = 0;
+        // column-pruned pass (opt-in): consecutive length classes that share a pruning class form one item range
+        for (int pc = PR_N_CLASSES - 1; pc >= 0; --pc) {
+            int k0 = -1, k1 = -1;
+            for (int k = 0; k < NCLS; ++k) {
+                const uint32_t cap = caps.cap[k];
+                const bool in = cap <= kPruneClasses[pc].max_len && (pc == 0 || cap > kPruneClasses[pc - 1].max_len) && cap > (uint32_t)kPruneClasses[pc].cp + 40;
+                if (in) {
+                    if (k0 < 0) k0 = k;
+                    k1 = k;
+                }
+            }
+            if (k0 < 0) continue;
+            BatchDev bp = b;
+            bp.items = ws.bucket_items + starts[k0];
+            bp.n_items = starts[k1] + counts[k1] - starts[k0];
+            if (!bp.n_items) continue;
+            e = prune_items(bp, pc);
+            if (e == hipSuccess) {
+                for (int k = k0; k <= k1; ++k) counts[k] = 0;
+            } else if (e != hipErrorNotSupported) {
+                return e;
+            }
+        }
         for (int k = NCLS; k >= 0; --k) {  // longest class first
             if (!counts[k]) continue;
             BatchDev bk = b;
@@ -587,41 +640,20 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
             if (e != hipSuccess) return e;
             return finish_worklist();
         }
-        // Short reads, a reference that fits one row table: the column-pruned pass; the reads it hands back
-        // (a check failed: some uncomputed cell might matter) are scored over all their cells, on the device-side list.
-        ScoreArgsV2 ap = a2;
-        bool pruned = false;
-        if (use_v2 && !b.items && (b.n_items >= PR_MIN_READS || (ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) && ws.prune_work && (ws.debug & ZSW_DEBUG_SCORE_PRUNE) && build_tables_v2(h_sc, 1, &ap)) {
-            const uint32_t floor_strip = ap.floor0, limit_strip = ap.limit;
-            if (build_tables_v2(h_sc, PR_G2, &ap) && prune_applicable(h_sc, max_len, ref_len, std::min(limit_strip, ap.limit))) {
-                if (timer) timer->begin(stream);
-                ap.b = b;
-                e = launch_score_pruned(ap, floor_strip, ap.floor0, h_sc, ws.prune_work, ws.prune_bytes, ws.prune_chunk, ws.prune_fail_list,
-                                        ws.prune_fail_count, mode, stream);
-                if (e == hipSuccess) {
-                    pruned = true;
-                    if (build_tables_v2(h_sc, G, &a2)) {
-                        a2.b = b;
-                        a2.b.items = ws.prune_fail_list;
-                        a2.n_items_dev = ws.prune_fail_count;
-                        e = launch_table_cfg_v2(a2, G, C, mode, stream);
-                        a2.n_items_dev = nullptr;
-                    } else {
-                        e = hipErrorInvalidValue;
-                    }
-                } else if (e == hipErrorNotSupported) {
-                    e = hipSuccess;
-                }
-                if (timer && pruned) timer->end(stream);
-                if (e != hipSuccess) return e;
-            }
+        // The column-pruned pass (opt-in, zsw_score_prune.hip); the reads it hands back are scored over all their cells.
+        e = hipErrorNotSupported;
+        const int cls = prune_class_for(max_len);
+        if (cls >= 0) {
+            if (timer) timer->begin(stream);
+            e = prune_items(b, cls);
+            if (timer && e == hipSuccess) timer->end(stream);
         }
-        if (!pruned) {
+        if (e == hipErrorNotSupported) {
             if (timer) timer->begin(stream);
             e = launch_one(b, G, C);
             if (timer) timer->end(stream);
-            if (e != hipSuccess) return e;
         }
+        if (e != hipSuccess) return e;
     }
     return finish_worklist();
 }

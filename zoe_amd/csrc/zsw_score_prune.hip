@@ -67,6 +67,9 @@ __device__ __forceinline__ void read_span(const BatchDev& b, uint32_t id, uint64
     }
 }
 
+// read id of entry k of the chunk (the batch may address its reads through an item list: length classes of a ragged batch)
+__device__ __forceinline__ uint32_t read_id(const PruneArgs& a, uint32_t k) { return a.b.items ? a.b.items[a.first + k] : a.first + k; }
+
 // selector of query column q of reads A and B for the v_perm lookup (zsw_score_v2.hpp (3))
 __device__ __forceinline__ uint32_t column_selector(const BatchDev& b, const uint8_t* lut, uint32_t q, uint64_t offA, uint32_t lenA,
                                                     uint64_t offB, uint32_t lenB) {
@@ -94,8 +97,8 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_strip_kernel(Pru
     __syncthreads();
     uint64_t offA = 0, offB = 0;
     uint32_t lenA = 0, lenB = 0;
-    if (valid) read_span(a.b, a.first + 2 * pair, &offA, &lenA);
-    if (validB) read_span(a.b, a.first + 2 * pair + 1, &offB, &lenB);
+    if (valid) read_span(a.b, read_id(a, 2 * pair), &offA, &lenA);
+    if (validB) read_span(a.b, read_id(a, 2 * pair + 1), &offB, &lenB);
     uint32_t sel[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) sel[c] = column_selector(a.b, lut, (uint32_t)c, offA, lenA, offB, lenB);
@@ -198,10 +201,11 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_strip_kernel(Pru
     }
 }
 
-template <int CP, int C, int MODE>
+template <int CP, int G, int C, int MODE>
 __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel(PruneArgs a) {
-    constexpr int G = PR_G2;
-    __shared__ uint2 rp[CH + G];
+    constexpr int M2 = PR_M2 + 8 * (G / 8);  // longer reads: more room for deletions below the anchor
+    __shared__ uint2 rp[CH + 2 * G];
+    __shared__ int s_lo, s_hi;
     __shared__ uint2 swt[9];
     __shared__ uint32_t lut32[64];
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut32);
@@ -215,17 +219,17 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
     const int R = (int)a.ref_len;
     if (tid < 64) lut32[tid] = reinterpret_cast<const uint32_t*>(a.sc->index_map)[tid];
     if (tid < 9) swt[tid] = make_uint2(a.wtab[tid][0], a.wtab[tid][1]);
-    __syncthreads();
-    for (int j = tid; j < R + G; j += BLOCK) {  // the whole reference; entry j = row j - (G - 1), the last entry is neutral
-        const int row = j - (G - 1);
-        rp[j] = swt[(row >= 0 && row < R && j < R + G - 1) ? (int)lut[a.ref[row]] : NEUTRAL];
+    if (tid == 0) {
+        s_lo = 0x7fffffff;
+        s_hi = 0;
     }
     __syncthreads();
 
     uint64_t offA = 0, offB = 0;
     uint32_t lenA = 0, lenB = 0;
-    if (validA) read_span(a.b, a.first + ridA, &offA, &lenA);
-    if (validB) read_span(a.b, a.first + ridB, &offB, &lenB);
+    const uint32_t idA = validA ? read_id(a, ridA) : 0, idB = validB ? read_id(a, ridB) : 0;
+    if (validA) read_span(a.b, idA, &offA, &lenA);
+    if (validB) read_span(a.b, idB, &offB, &lenB);
     uint32_t sel[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) sel[c] = column_selector(a.b, lut, (uint32_t)(CP + g * C + c), offA, lenA, offB, lenB);
@@ -236,11 +240,28 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
     const int maxlen = (int)max(lenA, lenB);
     const int Rup = (R + PR_BLK - 1) / PR_BLK * PR_BLK;
     const int a0 = max(0, lo - PR_M1) / PR_BLK * PR_BLK;
-    const int b0 = min(Rup, (hi + 1 + max(0, maxlen - CP) + PR_M2 + PR_BLK - 1) / PR_BLK * PR_BLK);
+    const int b0 = min(Rup, (hi + 1 + max(0, maxlen - CP) + M2 + PR_BLK - 1) / PR_BLK * PR_BLK);
     int Tw = validA ? b0 - a0 : 0;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) Tw = max(Tw, __shfl_xor(Tw, d, 64));  // the wavefront's groups walk equally many rows
     const int b1 = min(Rup, a0 + Tw);
+    // the block's row table: rows [lo - (G - 1), hi + G) of the reference (real rows for the lanes' skewed last rows too:
+    // V3 needs every lane's final state to sit in a real row, or past the end of the reference)
+    if (g == 0 && validA) {
+        atomicMin(&s_lo, a0);
+        atomicMax(&s_hi, a0 + Tw);
+    }
+    __syncthreads();
+    const int blo = s_lo, bhi = s_hi;
+    const bool staged = bhi - blo + 2 * G <= CH + 2 * G && blo <= bhi;  // reads sorted by anchor: the windows of a block overlap
+    if (staged) {
+        for (int j = tid; j < bhi - blo + 2 * G; j += BLOCK) {
+            const int row = blo - (G - 1) + j;
+            rp[j] = swt[(row >= 0 && row < R) ? (int)lut[a.ref[row]] : NEUTRAL];
+        }
+    }
+    __syncthreads();
+    const int joff = a0 - blo + (G - 1) - g;  // table entry of this lane's row at step t: joff + t
 
     // the boundary streams of the two reads
     const uint2* bA = a.bnd + (size_t)(ridA >> 1) * (size_t)a.row_stride;
@@ -272,12 +293,11 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
         ldA = bA[a0];
         ldB = bB[a0];
     }
-    const int T = Tw + G - 1;
-    const int jmax = R + G - 1;
-    uint2 w = rp[min(a0 - g + (G - 1), jmax)];
+    const int T = staged ? Tw + G - 1 : 0;
+    uint2 w = rp[staged ? joff : 0];
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
-        const uint2 wn = rp[min(a0 + t + 1 - g + (G - 1), jmax)];
+        const uint2 wn = rp[joff + t + 1];
         const int row = t - g;  // row of the window
         const bool rebase = ge1 != 0 && row > 0 && (row & (int)(K - 1)) == 0;
         if (__ballot(rebase) != 0) {
@@ -428,13 +448,13 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
         const bool second = g == 1;
         const bool v = second ? validB : validA;
         if (v) {
-            const uint32_t id = a.first + (second ? ridB : ridA);
+            const uint32_t id = second ? idB : idA;
             const uint32_t len = second ? lenB : lenA;
             const int S = second ? SB : SA, bound = second ? wB : wA;
             // score only: a path outside the computed cells matters if it can score MORE than S. With ends it also matters
             // if it can score S (it could end in an earlier row), and the maximum has to lie right of the strip, whose cells keep
             // no coordinates.
-            const bool redo = MODE == 0 ? bound > S : (bound >= S || (second ? stripB : stripA) >= S);
+            const bool redo = !staged || (MODE == 0 ? bound > S : (bound >= S || (second ? stripB : stripA) >= S));
             if (len == 0) {
                 a.out.score[id] = 0;
                 a.out.status[id] = ZSW_STATUS_EMPTY;
@@ -481,23 +501,48 @@ size_t prune_workspace_bytes(uint32_t chunk_reads, uint32_t ref_len) {
            4 * round256((size_t)chunk_reads * 4 + 8) + round256(prune_sort_temp_bytes(chunk_reads)) + 256;
 }
 
+// reads per round of the two kernels: as many as PR_WORK_BYTES of boundary stream hold (8 bytes per pair and reference row)
+uint32_t prune_chunk_reads(uint32_t n_reads, uint32_t ref_len) {
+    const size_t per_pair = (((size_t)ref_len + 7) & ~(size_t)7) * sizeof(uint2) + ((size_t)ref_len / PR_BLK + 1) * sizeof(uint2) + 64;
+    const size_t pairs = std::max<size_t>(PR_WORK_BYTES / per_pair, 1024);
+    return (uint32_t)std::min<size_t>(std::min<size_t>(2 * pairs, PR_CHUNK_READS), std::max<uint32_t>(n_reads, 2));
+}
+
+int prune_class_for(uint32_t max_len) {
+    for (int k = 0; k < PR_N_CLASSES; ++k)
+        if (max_len <= kPruneClasses[k].max_len) return max_len > (uint32_t)kPruneClasses[k].cp + 40 ? k : -1;
+    return -1;
+}
+
 bool prune_applicable(const ScoringDev& s, uint32_t max_len, uint32_t ref_len, uint32_t limit) {
     int maxw = 0;
     for (int i = 0; i < s.S * s.S; ++i) maxw = std::max(maxw, (int)s.w[i]);
-    if (maxw <= 0) return false;
-    if (ref_len == 0 || ref_len > (uint32_t)CH) return false;
-    if (max_len <= (uint32_t)PR_CP + 40 || max_len > (uint32_t)(PR_CP + PR_G2 * PR_C2)) return false;
+    if (maxw <= 0 || ref_len == 0 || prune_class_for(max_len) < 0) return false;
     return (uint64_t)maxw * max_len + 8 < limit;  // no score can leave the packed range
 }
 
-// Scores reads [0, b.n_reads) of a fixed-length or ragged batch without an item list; reads that fail a check are appended to
-// fail_list (device count in fail_count, zeroed here). `a2` carries the v2 tables and drift constants for G = 1 and G = 4
-// (the constants do not depend on G below 16 rows of slack, see the caller).
-hipError_t launch_score_pruned(const ScoreArgsV2& a2, uint32_t floor_strip, uint32_t floor_window, const ScoringDev& h_sc, uint8_t* work,
-                               size_t work_bytes, uint32_t chunk_reads, uint32_t* fail_list, uint32_t* fail_count, int mode, hipStream_t stream) {
-    const uint32_t n = a2.b.n_reads, R = a2.ref_len;
+namespace {
+
+template <int CP, int G, int C>
+void launch_window(const PruneArgs& a, int mode, hipStream_t stream) {
+    const uint32_t groups = (a.n + 1) / 2, per_block = BLOCK / G;
+    const dim3 grid((groups + per_block - 1) / per_block);
+    if (mode == 0) hipLaunchKernelGGL((prune_window_kernel<CP, G, C, 0>), grid, dim3(BLOCK), 0, stream, a);
+    else if (mode == 1) hipLaunchKernelGGL((prune_window_kernel<CP, G, C, 1>), grid, dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((prune_window_kernel<CP, G, C, 2>), grid, dim3(BLOCK), 0, stream, a);
+}
+
+}  // namespace
+
+// Scores items [0, a2.b.n_items) of the batch (reads of at most kPruneClasses[cls].max_len bases); reads that fail a check are
+// appended to fail_list (device count in fail_count, NOT zeroed here: the classes of a ragged batch share the list... each
+// class passes its own). `a2` carries the v2 tables; floor_strip / floor_window are the drift floors for G = 1 and the class's G.
+hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t floor_strip, uint32_t floor_window, const ScoringDev& h_sc,
+                               uint8_t* work, size_t work_bytes, uint32_t chunk_reads, uint32_t* fail_list, uint32_t* fail_count, int mode,
+                               hipStream_t stream) {
+    const uint32_t n = a2.b.n_items, R = a2.ref_len;
     if (n == 0) return hipSuccess;
-    if (work_bytes < prune_workspace_bytes(chunk_reads, R)) return hipErrorNotSupported;
+    if (cls < 0 || cls >= PR_N_CLASSES || chunk_reads < 2 || work_bytes < prune_workspace_bytes(chunk_reads, R)) return hipErrorNotSupported;
     PruneArgs a;
     a.b = a2.b;
     a.ref = a2.ref;
@@ -538,25 +583,23 @@ hipError_t launch_score_pruned(const ScoreArgsV2& a2, uint32_t floor_strip, uint
     int key_bits = 1;
     while ((1u << key_bits) < R + 1 && key_bits < 32) ++key_bits;
 
-    hipError_t e = hipMemsetAsync(fail_count, 0, 4, stream);
-    if (e != hipSuccess) return e;
     for (uint32_t first = 0; first < n; first += chunk_reads) {
         a.first = first;
         a.n = std::min<uint32_t>(chunk_reads, n - first);
         a.n_pairs = (a.n + 1) / 2;
         a.floor0 = floor_strip;
-        hipLaunchKernelGGL((prune_strip_kernel<PR_CP>), dim3((a.n_pairs + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, a);
+        const dim3 sgrid((a.n_pairs + BLOCK - 1) / BLOCK);
+        if (kPruneClasses[cls].cp == 24) hipLaunchKernelGGL((prune_strip_kernel<24>), sgrid, dim3(BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((prune_strip_kernel<48>), sgrid, dim3(BLOCK), 0, stream, a);
         hipLaunchKernelGGL(iota32_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, ids_in, a.n);
-        e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t*)a.anchor, keys_out, (const uint32_t*)ids_in, ids_out,
-                                               (int)a.n, 0, key_bits, stream);
+        hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t*)a.anchor, keys_out, (const uint32_t*)ids_in, ids_out,
+                                                          (int)a.n, 0, key_bits, stream);
         if (e != hipSuccess) return e;
         a.order = ids_out;
         a.floor0 = floor_window;
-        const uint32_t groups = (a.n + 1) / 2, per_block = BLOCK / PR_G2;
-        const dim3 wgrid((groups + per_block - 1) / per_block);
-        if (mode == 0) hipLaunchKernelGGL((prune_window_kernel<PR_CP, PR_C2, 0>), wgrid, dim3(BLOCK), 0, stream, a);
-        else if (mode == 1) hipLaunchKernelGGL((prune_window_kernel<PR_CP, PR_C2, 1>), wgrid, dim3(BLOCK), 0, stream, a);
-        else hipLaunchKernelGGL((prune_window_kernel<PR_CP, PR_C2, 2>), wgrid, dim3(BLOCK), 0, stream, a);
+        if (cls == 0) launch_window<24, 4, 32>(a, mode, stream);
+        else if (cls == 1) launch_window<48, 8, 32>(a, mode, stream);
+        else launch_window<48, 16, 22>(a, mode, stream);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

@@ -1,24 +1,33 @@
-// zsw_score_prune.hpp — launcher of the column-pruned score-only pass (zsw_score_prune.hip).
+// zsw_score_prune.hpp — launcher of the column-pruned first pass (zsw_score_prune.hip).
 #pragma once
 #include "zsw_internal.hpp"
 
 namespace zsw {
 
-constexpr int PR_CP = 24;   // query columns of the strip that sees every reference row
-constexpr int PR_G2 = 4;    // lanes per read pair of the window kernel
-constexpr int PR_C2 = 32;   // columns per lane of the window kernel: reads of up to PR_CP + PR_G2 * PR_C2 = 152 bases
+// Read-length classes: the strip's columns CP see every reference row; the window kernel holds the other columns in G lanes x C
+// columns per read pair. A longer read loses more score to its mismatches, so its strip is wider: the checks compare the junk
+// that leaves the strip (~20-30) with maxw * CP minus those losses.
+struct PruneClass {
+    int cp, g, c;
+    uint32_t max_len;  // cp + g * c
+};
+constexpr int PR_N_CLASSES = 3;
+constexpr PruneClass kPruneClasses[PR_N_CLASSES] = {{24, 4, 32, 152}, {48, 8, 32, 304}, {48, 16, 22, 400}};
 constexpr int PR_BLK = 32;  // rows per block of the boundary maxima (windows are whole blocks)
 constexpr int PR_M1 = 8;    // window rows kept above the anchor
-constexpr int PR_M2 = 24;   // and below the row where an alignment without deletions ends
+constexpr int PR_M2 = 24;   // and below the row where an alignment without deletions ends (+8 per 8 lanes of the class)
 constexpr uint32_t PR_MIN_READS = 1u << 16;    // smaller batches cannot fill the chip with one pair per lane: the full pass is faster
-constexpr uint32_t PR_CHUNK_READS = 2u << 20;  // reads per round of the two kernels (16 KiB of boundary stream per pair at 2 kb)
+constexpr uint32_t PR_CHUNK_READS = 2u << 20;  // reads per round of the two kernels, at most
+constexpr size_t PR_WORK_BYTES = size_t(32) << 30;  // and as many as this much boundary stream holds (8 B per pair and reference row)
 
 struct ScoreArgsV2;
 
 size_t prune_workspace_bytes(uint32_t chunk_reads, uint32_t ref_len);
+uint32_t prune_chunk_reads(uint32_t n_reads, uint32_t ref_len);
+int prune_class_for(uint32_t max_len);
 bool prune_applicable(const ScoringDev& s, uint32_t max_len, uint32_t ref_len, uint32_t limit);
-hipError_t launch_score_pruned(const ScoreArgsV2& a2, uint32_t floor_strip, uint32_t floor_window, const ScoringDev& h_sc, uint8_t* work,
-                               size_t work_bytes, uint32_t chunk_reads, uint32_t* fail_list, uint32_t* fail_count,
+hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t floor_strip, uint32_t floor_window, const ScoringDev& h_sc,
+                               uint8_t* work, size_t work_bytes, uint32_t chunk_reads, uint32_t* fail_list, uint32_t* fail_count,
                                int mode /* as launch_score */, hipStream_t stream);
 
 }  // namespace zsw
