@@ -60,3 +60,18 @@ if n <= 2_000_000 and "--score-only" not in sys.argv:
         t1 = timed(fn)
         ctx.debug_set(0)
         print(f"{name}: default {t0*1e3:.1f} ms ({n/t0/1e6:.1f} M/s), pruned first pass {t1*1e3:.1f} ms ({n/t1/1e6:.1f} M/s)")
+
+if "--mixed" in sys.argv:
+    ref30 = synth.reference_host(30000)
+    rr = synth.reads_ragged_device(ctx, ref30, 0, 1_000_000, 75, 400)
+    pm = zoe_amd.LocalProfilesBatch.new_with_w256(rr, dna, -10, -1)
+    cells = float(rr.offsets[-1]) * 30000
+    res = {}
+    for name, flags in (("default", 0), ("pruned", _lib.DEBUG_SCORE_PRUNE)):
+        ctx.debug_set(flags)
+        t = timed(lambda: pm.sw_score_from_i8(ref30), reps=2)
+        res[name] = pm.sw_score_from_i8(ref30)
+        extra = f", rescored {ctx.prune_rescored()}" if flags else ""
+        print(f"mixed 1M x 75-400 bp vs 30 kb, {name}: {t*1e3:.1f} ms, {1e6/t/1e6:.2f} M reads/s, {cells/t/1e12:.2f} TCUPS-equivalent{extra}")
+    ctx.debug_set(0)
+    print("identical:", bool(torch.equal(res["default"].score, res["pruned"].score) and torch.equal(res["default"].status, res["pruned"].status)))

@@ -506,21 +506,27 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     };
     // Column-pruned pass over the items of `bb` (reads of at most kPruneClasses[cls].max_len bases), then score_kernel_v2 over the
     // reads it hands back (device-side list and count). hipErrorNotSupported: not switched on, or the batch does not qualify.
-    auto prune_items = [&](const BatchDev& bb, int cls) -> hipError_t {
+    auto prune_items = [&](const BatchDev& bb, int cls, uint32_t n_cls) -> hipError_t {
         if (!use_v2 || !ws.prune_work || !(ws.debug & ZSW_DEBUG_SCORE_PRUNE)) return hipErrorNotSupported;
         if (bb.n_items < PR_MIN_READS && !(ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) return hipErrorNotSupported;
+        const int last = n_cls < bb.n_items ? cls + 1 : cls;  // the range may hold the next class too (same strip width)
         ScoreArgsV2 ap = a2;
         if (!build_tables_v2(h_sc, 1, &ap)) return hipErrorNotSupported;
-        const uint32_t floor_strip = ap.floor0, limit_strip = ap.limit;
-        if (!build_tables_v2(h_sc, kPruneClasses[cls].g, &ap)) return hipErrorNotSupported;
-        if (!prune_applicable(h_sc, kPruneClasses[cls].max_len, ref_len, std::min(limit_strip, ap.limit))) return hipErrorNotSupported;
+        const uint32_t floor_strip = ap.floor0;
+        uint32_t limit = ap.limit, floor_window[2] = {0, 0};
+        for (int c = cls; c <= last; ++c) {
+            if (!build_tables_v2(h_sc, kPruneClasses[c].g, &ap)) return hipErrorNotSupported;
+            floor_window[c - cls] = ap.floor0;
+            limit = std::min(limit, ap.limit);
+        }
+        if (!prune_applicable(h_sc, kPruneClasses[last].max_len, ref_len, limit)) return hipErrorNotSupported;
         int Gr = 0, Cr = 0;
-        if (!score_config_for(kPruneClasses[cls].max_len, &Gr, &Cr)) return hipErrorNotSupported;
+        if (!score_config_for(kPruneClasses[last].max_len, &Gr, &Cr)) return hipErrorNotSupported;
         hipError_t pe = hipMemsetAsync(ws.prune_fail_count, 0, 4, stream);
         if (pe != hipSuccess) return pe;
         ap.b = bb;
-        pe = launch_score_pruned(ap, cls, floor_strip, ap.floor0, h_sc, ws.prune_work, ws.prune_bytes, ws.prune_chunk, ws.prune_fail_list,
-                                 ws.prune_fail_count, mode, stream);
+        pe = launch_score_pruned(ap, cls, n_cls, floor_strip, floor_window, h_sc, ws.prune_work, ws.prune_bytes, ws.prune_chunk,
+                                 ws.prune_fail_list, ws.prune_fail_count, mode, stream);
         if (pe != hipSuccess) return pe;
         if (!build_tables_v2(h_sc, Gr, &a2)) return hipErrorInvalidValue;
         a2.b = bb;
@@ -575,27 +581,39 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         }
         const hipStream_t main_stream = stream;
         int used = 0;
-        // column-pruned pass (opt-in): consecutive length classes that share a pruning class form one item range
-        for (int pc = PR_N_CLASSES - 1; pc >= 0; --pc) {
-            int k0 = -1, k1 = -1;
-            for (int k = 0; k < NCLS; ++k) {
-                const uint32_t cap = caps.cap[k];
-                const bool in = cap <= kPruneClasses[pc].max_len && (pc == 0 || cap > kPruneClasses[pc - 1].max_len) && cap > (uint32_t)kPruneClasses[pc].cp + 40;
-                if (in) {
-                    if (k0 < 0) k0 = k;
-                    k1 = k;
+        // column-pruned pass (opt-in): consecutive length classes that share a pruning class form one item range, and pruning
+        // classes with the same strip width share the strip launch
+        {
+            int k0[PR_N_CLASSES], k1[PR_N_CLASSES];
+            uint32_t cnt[PR_N_CLASSES];
+            for (int pc = 0; pc < PR_N_CLASSES; ++pc) {
+                k0[pc] = k1[pc] = -1;
+                cnt[pc] = 0;
+                for (int k = 0; k < NCLS; ++k) {
+                    const uint32_t cap = caps.cap[k];
+                    if (cap <= kPruneClasses[pc].max_len && (pc == 0 || cap > kPruneClasses[pc - 1].max_len) && cap > (uint32_t)kPruneClasses[pc].cp + 40) {
+                        if (k0[pc] < 0) k0[pc] = k;
+                        k1[pc] = k;
+                        cnt[pc] += counts[k];
+                    }
                 }
             }
-            if (k0 < 0) continue;
-            BatchDev bp = b;
-            bp.items = ws.bucket_items + starts[k0];
-            bp.n_items = starts[k1] + counts[k1] - starts[k0];
-            if (!bp.n_items) continue;
-            e = prune_items(bp, pc);
-            if (e == hipSuccess) {
-                for (int k = k0; k <= k1; ++k) counts[k] = 0;
-            } else if (e != hipErrorNotSupported) {
-                return e;
+            for (int pc = 0; pc < PR_N_CLASSES; ++pc) {
+                if (k0[pc] < 0) continue;
+                int last = pc;
+                if (pc + 1 < PR_N_CLASSES && k0[pc + 1] == k1[pc] + 1 && kPruneClasses[pc + 1].cp == kPruneClasses[pc].cp && ref_len < (1u << 24)) last = pc + 1;
+                BatchDev bp = b;
+                bp.items = ws.bucket_items + starts[k0[pc]];
+                bp.n_items = starts[k1[last]] + counts[k1[last]] - starts[k0[pc]];
+                if (bp.n_items) {
+                    e = prune_items(bp, pc, cnt[pc]);
+                    if (e == hipSuccess) {
+                        for (int k = k0[pc]; k <= k1[last]; ++k) counts[k] = 0;
+                    } else if (e != hipErrorNotSupported) {
+                        return e;
+                    }
+                }
+                pc = last;
             }
         }
         for (int k = NCLS; k >= 0; --k) {  // longest class first
@@ -645,7 +663,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         const int cls = prune_class_for(max_len);
         if (cls >= 0) {
             if (timer) timer->begin(stream);
-            e = prune_items(b, cls);
+            e = prune_items(b, cls, b.n_items);
             if (timer && e == hipSuccess) timer->end(stream);
         }
         if (e == hipErrorNotSupported) {

@@ -45,6 +45,7 @@ struct PruneArgs {
     uint32_t first;    // first read of the chunk
     uint32_t n;        // reads of the chunk
     uint32_t n_pairs;  // (n + 1) / 2
+    uint32_t split;    // strip kernel: entries >= split of the chunk belong to the next length class (sort key bit 24)
     uint32_t maxw;
     uint32_t nblk;     // blocks of PR_BLK rows
     uint2* bnd;        // [pair][row_stride]: (H[r][CP-1], F[r][CP]), true scores, read A in the low halves
@@ -196,8 +197,8 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_strip_kernel(Pru
     }
     if (valid) {
         a.best0[pair] = best;
-        a.anchor[2 * pair] = ancA;
-        if (validB) a.anchor[2 * pair + 1] = ancB;
+        a.anchor[2 * pair] = ancA | (2 * pair >= a.split ? 1u << 24 : 0u);
+        if (validB) a.anchor[2 * pair + 1] = ancB | (2 * pair + 1 >= a.split ? 1u << 24 : 0u);
     }
 }
 
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
     for (int c = 0; c < C; ++c) sel[c] = column_selector(a.b, lut, (uint32_t)(CP + g * C + c), offA, lenA, offB, lenB);
 
     // the window: blocks of rows around the two anchors
-    const int rsA = validA ? (int)a.anchor[ridA] : 0, rsB = validB ? (int)a.anchor[ridB] : rsA;
+    const int rsA = validA ? (int)(a.anchor[ridA] & 0xffffffu) : 0, rsB = validB ? (int)(a.anchor[ridB] & 0xffffffu) : rsA;
     const int lo = min(rsA, rsB), hi = max(rsA, rsB);
     const int maxlen = (int)max(lenA, lenB);
     const int Rup = (R + PR_BLK - 1) / PR_BLK * PR_BLK;
@@ -534,15 +535,17 @@ void launch_window(const PruneArgs& a, int mode, hipStream_t stream) {
 
 }  // namespace
 
-// Scores items [0, a2.b.n_items) of the batch (reads of at most kPruneClasses[cls].max_len bases); reads that fail a check are
-// appended to fail_list (device count in fail_count, NOT zeroed here: the classes of a ragged batch share the list... each
-// class passes its own). `a2` carries the v2 tables; floor_strip / floor_window are the drift floors for G = 1 and the class's G.
-hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t floor_strip, uint32_t floor_window, const ScoringDev& h_sc,
-                               uint8_t* work, size_t work_bytes, uint32_t chunk_reads, uint32_t* fail_list, uint32_t* fail_count, int mode,
-                               hipStream_t stream) {
+// Scores items [0, a2.b.n_items) of the batch: the first n_cls of them are reads of class `cls`, the rest of class cls + 1 (same
+// strip width: one strip launch serves both, so that a small class does not cost a round of its own). Reads that fail a check
+// are appended to fail_list (device count in fail_count, zeroed by the caller). `a2` carries the v2 tables; floor_strip /
+// floor_window[2] are the drift floors for G = 1 and for the two classes' G.
+hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t n_cls, uint32_t floor_strip, const uint32_t* floor_window,
+                               const ScoringDev& h_sc, uint8_t* work, size_t work_bytes, uint32_t chunk_reads, uint32_t* fail_list,
+                               uint32_t* fail_count, int mode, hipStream_t stream) {
     const uint32_t n = a2.b.n_items, R = a2.ref_len;
     if (n == 0) return hipSuccess;
     if (cls < 0 || cls >= PR_N_CLASSES || chunk_reads < 2 || work_bytes < prune_workspace_bytes(chunk_reads, R)) return hipErrorNotSupported;
+    if (n_cls < n && (cls + 1 >= PR_N_CLASSES || kPruneClasses[cls + 1].cp != kPruneClasses[cls].cp || R >= (1u << 24))) return hipErrorNotSupported;
     PruneArgs a;
     a.b = a2.b;
     a.ref = a2.ref;
@@ -582,11 +585,26 @@ hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t floor_st
     size_t temp_bytes = prune_sort_temp_bytes(chunk_reads);
     int key_bits = 1;
     while ((1u << key_bits) < R + 1 && key_bits < 32) ++key_bits;
+    if (n_cls < n) key_bits = 25;  // bit 24: the second class of the range
 
+    // a round of the strip kernel should not spill a few blocks into a second wave of blocks: every block walks all R rows,
+    // so 545 blocks on 512 slots take twice as long as 512. Rounds are whole multiples of what the chip holds at once.
+    {
+        int dev = 0, cus = 0, per_cu = 0;
+        hipError_t qe = hipGetDevice(&dev);
+        if (qe == hipSuccess) qe = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (qe == hipSuccess)
+            qe = kPruneClasses[cls].cp == 24 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prune_strip_kernel<24>, BLOCK, 0)
+                                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prune_strip_kernel<48>, BLOCK, 0);
+        if (qe != hipSuccess) return qe;
+        const uint64_t quantum = (uint64_t)cus * (uint64_t)per_cu * 2 * BLOCK;  // reads the chip holds at once
+        if (quantum > 0 && chunk_reads >= quantum) chunk_reads = (uint32_t)(chunk_reads / quantum * quantum);
+    }
     for (uint32_t first = 0; first < n; first += chunk_reads) {
         a.first = first;
         a.n = std::min<uint32_t>(chunk_reads, n - first);
         a.n_pairs = (a.n + 1) / 2;
+        a.split = first >= n_cls ? 0u : std::min<uint32_t>(a.n, n_cls - first);  // entries of the chunk that belong to `cls`
         a.floor0 = floor_strip;
         const dim3 sgrid((a.n_pairs + BLOCK - 1) / BLOCK);
         if (kPruneClasses[cls].cp == 24) hipLaunchKernelGGL((prune_strip_kernel<24>), sgrid, dim3(BLOCK), 0, stream, a);
@@ -595,11 +613,19 @@ hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t floor_st
         hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t*)a.anchor, keys_out, (const uint32_t*)ids_in, ids_out,
                                                           (int)a.n, 0, key_bits, stream);
         if (e != hipSuccess) return e;
-        a.order = ids_out;
-        a.floor0 = floor_window;
-        if (cls == 0) launch_window<24, 4, 32>(a, mode, stream);
-        else if (cls == 1) launch_window<48, 8, 32>(a, mode, stream);
-        else launch_window<48, 16, 22>(a, mode, stream);
+        // the window kernel per class: the sorted order holds the reads of `cls` first, then those of the next class
+        const uint32_t n_chunk = a.n, n_first = a.split;
+        for (int part = 0; part < 2; ++part) {
+            const int c = cls + part;
+            a.order = ids_out + (part ? n_first : 0);
+            a.n = part ? n_chunk - n_first : n_first;
+            if (a.n == 0) continue;
+            a.floor0 = floor_window[part];
+            if (c == 0) launch_window<24, 4, 32>(a, mode, stream);
+            else if (c == 1) launch_window<48, 8, 32>(a, mode, stream);
+            else launch_window<48, 16, 22>(a, mode, stream);
+        }
+        a.n = n_chunk;
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
