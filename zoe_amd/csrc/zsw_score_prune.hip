@@ -588,7 +588,8 @@ hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t n_cls, u
     if (n_cls < n) key_bits = 25;  // bit 24: the second class of the range
 
     // a round of the strip kernel should not spill a few blocks into a second wave of blocks: every block walks all R rows,
-    // so 545 blocks on 512 slots take twice as long as 512. Rounds are whole multiples of what the chip holds at once.
+    // so 545 blocks on 512 slots take twice as long as 512. When the batch needs several rounds, a round is a whole multiple of
+    // what the chip holds at once.
     {
         int dev = 0, cus = 0, per_cu = 0;
         hipError_t qe = hipGetDevice(&dev);
@@ -598,7 +599,7 @@ hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t n_cls, u
                                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prune_strip_kernel<48>, BLOCK, 0);
         if (qe != hipSuccess) return qe;
         const uint64_t quantum = (uint64_t)cus * (uint64_t)per_cu * 2 * BLOCK;  // reads the chip holds at once
-        if (quantum > 0 && chunk_reads >= quantum) chunk_reads = (uint32_t)(chunk_reads / quantum * quantum);
+        if (quantum > 0 && n > chunk_reads && chunk_reads >= quantum) chunk_reads = (uint32_t)(chunk_reads / quantum * quantum);
     }
     for (uint32_t first = 0; first < n; first += chunk_reads) {
         a.first = first;
