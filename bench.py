@@ -319,6 +319,13 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     entry["valu_roofline"] = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": VALU_LANE_OPS_PEAK / 1e12,
                               "unit": "T lane-ops/s of USEFUL cells (7.5 packed VALU per two cells; padding columns and rows not counted)",
                               "frac": lane_ops / VALU_LANE_OPS_PEAK, "valu_peak_source": VALU_PEAK_SOURCE}
+    ctx.timing_enable(True)
+    full_mixed = pm.sw_score_from_i8(ref30k)
+    got, dtp, ksp = with_pruning(lambda: pm.sw_score_from_i8(ref30k))
+    ctx.timing_enable(False)
+    entry["with_pruned_first_pass"] = {"reads_per_s": 1_000_000 / dtp, "tcups_equivalent": cells / dtp / 1e12, "kernels_ms": ksp * 1e3,
+                                       "identical": bool(torch.equal(got.score, full_mixed.score) and torch.equal(got.status, full_mixed.status)
+                                                         and torch.equal(got.tier, full_mixed.tier))}
     out["score_mixed_1M_x_75_400bp_vs_30kb"] = entry
     return out
 

@@ -4,7 +4,7 @@
 set -e
 export TMPDIR=/tmp
 OUT=$1
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --verify 0 --no-secondary"
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --verify 0 --no-secondary --no-pruned"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/bench_stats.json 2> $OUT/stats.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err

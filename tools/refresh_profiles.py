@@ -2,7 +2,7 @@
 
 usage: python tools/refresh_profiles.py r02      # reads gpurun_out/<tag>_prof_head, gpurun_out/<tag>_prof_final, gpurun_out/<tag>_bench_default.json
 On the GPU box the inputs come from:
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/<tag>_prof_head -o run -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --verify 0 --no-secondary > gpurun_out/<tag>_prof_head_bench.json
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/<tag>_prof_head -o run -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --verify 0 --no-secondary --no-pruned > gpurun_out/<tag>_prof_head_bench.json
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/<tag>_prof_final -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/<tag>_prof_final_bench.json
   python3 bench.py > gpurun_out/<tag>_bench_default.json
 """
@@ -29,7 +29,7 @@ b = last_json(f"gpurun_out/{tag}_prof_head_bench.json")
 json.dump(b, open(f"profiles/{tag}_final_headline_bench_under_rocprof.json", "w"))
 r = rows[0]
 open(f"profiles/{tag}_final_headline_summary.txt", "w").write(
-    f"# {tag} final, headline only: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --verify 0 --no-secondary\n"
+    f"# {tag} final, headline only: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --verify 0 --no-secondary --no-pruned\n"
     "# every launch of the kernel below is one step of the benchmark (10 M reads x 150 bp vs 2 kb)\n"
     f"{r['Name']}: calls={r['Calls']} avg_ms={float(r['AverageNs'])/1e6:.3f} min_ms={float(r['MinNs'])/1e6:.3f} max_ms={float(r['MaxNs'])/1e6:.3f} pct={r['Percentage']}\n"
     f"bench line of the same run: kernel_ms (HIP events inside bench.py) = {b['roofline']['kernel_ms']:.3f}, ms_per_step = {b['ms_per_step']:.3f}, value = {b['value']:.4g} reads/s\n")
