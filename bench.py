@@ -214,7 +214,8 @@ def pruned_headline(zoe_amd, ctx, profiles, reference, full, n_reads, steps):
                "the read's anchor (prune_window_kernel); three upper-bound checks per read decide whether any uncomputed cell could "
                "matter; reads that fail are rescored by score_kernel_v2 over all their cells. Exact for every input; opt-in "
                "(zsw_debug_set(ZSW_DEBUG_SCORE_PRUNE)); see DESIGN.md 4.1d",
-        "work": "cells computed / cells of the full pass = 0.29 on this workload (profiles/r02_prune_summary.txt)",
+        "work": "VALU wave-instructions issued / those of the full pass = 0.31 on this workload: strip 0.17, window 0.09, rescoring 0.05 ("
+                + file_tag("profiles/r02_prune_summary.txt") + ")",
     }
 
 
