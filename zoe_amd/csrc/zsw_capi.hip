@@ -280,11 +280,14 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     if ((ctx->debug & ZSW_DEBUG_SCORE_PRUNE) && n > 0 && (n >= PR_MIN_READS || (ctx->debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) &&
         ctx->ref_len > 0 && (reads->offsets ? st->max_len > 64 : prune_class_for(st->max_len) >= 0)) {
         const uint32_t chunk = prune_chunk_reads((uint32_t)n, (uint32_t)ctx->ref_len);
-        ZSW_HIP(ctx, ctx->d_prune.ensure(prune_workspace_bytes(chunk, (uint32_t)ctx->ref_len)));
-        ZSW_HIP(ctx, ctx->d_prune_list.ensure((size_t)n * 4 + 4));
-        ZSW_HIP(ctx, ctx->d_prune_count.ensure(8));
-        ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 8, stream));  // [0] the class in flight, [1] the call's total
-        ctx->prune_chunk = chunk;
+        // a reference so long that the boundary streams of a round's reads no longer fill the chip: the full pass
+        if (chunk >= std::min<uint32_t>((uint32_t)n, PR_MIN_READS) || (ctx->debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) {
+            ZSW_HIP(ctx, ctx->d_prune.ensure(prune_workspace_bytes(chunk, (uint32_t)ctx->ref_len)));
+            ZSW_HIP(ctx, ctx->d_prune_list.ensure((size_t)n * 4 + 4));
+            ZSW_HIP(ctx, ctx->d_prune_count.ensure(8));
+            ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 8, stream));  // [0] the class in flight, [1] the call's total
+            ctx->prune_chunk = chunk;
+        }
     }
     uint32_t need = std::max<uint32_t>(512, (st->max_len + 127) / 128 * 128);
     if (need > ctx->scratch_len || !ctx->d_scratch.p) {
