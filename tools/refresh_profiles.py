@@ -41,7 +41,9 @@ with open(f"profiles/{tag}_final_kernel_stats.csv", "w") as f:
 out = [f"# {tag} final: rocprofv3 --kernel-trace --stats on `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (one MI355X).",
        "# Headline launches = score_kernel_v2<4,38,0> (10 M reads x 150 bp vs 2 kb: warm-up + 3 timed; its average also contains the",
        f"# 2,048-read parity-check launch and the 1 M-read launches of the `secondary` section, see {tag}_final_headline_summary.txt for the clean figure);",
-       "# the other kernels belong to `secondary` (10 M reads exact align; 1 M reads each: 3-pass align, ranges, filter, mixed lengths on side streams).", ""]
+       "# the other kernels belong to `secondary` (10 M reads exact align; 1 M reads each: 3-pass align, ranges, filter, mixed lengths on side streams)",
+       "# and to the runs with the opt-in column-pruned first pass (prune_strip_kernel / prune_window_kernel + score_kernel_v2 on the rescore lists):",
+       "# the headline workload again (`exact_pruning`) and the `with_pruned_first_pass` repeats of the secondary entries.", ""]
 for r in rows[:40]:
     out.append(f"{r['Name'][:84]:84s} calls={r['Calls']:>3s} avg_ms={float(r['AverageNs'])/1e6:9.3f} total_ms={float(r['TotalDurationNs'])/1e6:9.2f} pct={r['Percentage']}")
 b = last_json(f"gpurun_out/{tag}_prof_final_bench.json")
