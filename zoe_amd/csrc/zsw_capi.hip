@@ -282,11 +282,15 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
         const uint32_t chunk = prune_chunk_reads((uint32_t)n, (uint32_t)ctx->ref_len);
         // a reference so long that the boundary streams of a round's reads no longer fill the chip: the full pass
         if (chunk >= std::min<uint32_t>((uint32_t)n, PR_MIN_READS) || (ctx->debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) {
-            ZSW_HIP(ctx, ctx->d_prune.ensure(prune_workspace_bytes(chunk, (uint32_t)ctx->ref_len)));
-            ZSW_HIP(ctx, ctx->d_prune_list.ensure((size_t)n * 4 + 4));
-            ZSW_HIP(ctx, ctx->d_prune_count.ensure(8));
-            ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 8, stream));  // [0] the class in flight, [1] the call's total
-            ctx->prune_chunk = chunk;
+            // the workspace is large (8 B per read pair and reference row): if the device cannot spare it, the full pass runs
+            if (ctx->d_prune.ensure(prune_workspace_bytes(chunk, (uint32_t)ctx->ref_len)) == hipSuccess &&
+                ctx->d_prune_list.ensure((size_t)n * 4 + 4) == hipSuccess && ctx->d_prune_count.ensure(8) == hipSuccess) {
+                ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 8, stream));  // [0] the class in flight, [1] the call's total
+                ctx->prune_chunk = chunk;
+            } else {
+                (void)hipGetLastError();
+                ctx->d_prune.release();
+            }
         }
     }
     uint32_t need = std::max<uint32_t>(512, (st->max_len + 127) / 128 * 128);
