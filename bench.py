@@ -229,15 +229,22 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     ref2k = synth.reference_host(REF_LEN)
 
     def timed(fn):
+        """result, wall seconds and kernel seconds of the faster of two calls after a warm-up call (a single call now and then
+        catches an allocation of the caching allocators: 3-pass 1 M reads measured 61 and 36 ms in consecutive bench runs)"""
         fn()  # warm-up (allocations, first-launch costs)
-        torch.cuda.synchronize()
-        ctx.timing_read()
-        t0 = time.perf_counter()
-        r = fn()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        ks, _ = ctx.timing_read()
-        return r, dt, ks
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            ctx.timing_read()
+            t0 = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ks, _ = ctx.timing_read()
+            if best is None or dt < best[1]:
+                best = (r, dt, ks)
+            del r
+        return best
 
     def with_pruning(fn):
         """the same call with the opt-in column-pruned first pass (bit-identical)"""
@@ -263,8 +270,8 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
              "kernel": "zsw::align_kernel_pk<16,10> (+ <32,5> for the reads that answer at i8x32); pass 1 = score_kernel_v2<4,38,1>"}
     # algorithmic bytes: read in, record out (score, 4 coordinates, 2 lengths, count, offset = 40 B), 5 B per ciglet
     entry.update(rooflines(n_full * (READ_LEN + 4.0) + n_some * 40.0 + n_cig * 5.0, ks, ALIGN_PK_VALU_PER_READ * n_full, ALIGN_PK_PROFILE))
-    ap, dtp, _ = with_pruning(lambda: prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref2k)))
-    entry["with_pruned_first_pass"] = {"reads_per_s_end_to_end_incl_d2h": n_full / dtp,
+    ap, dtp, ksp = with_pruning(lambda: prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref2k)))
+    entry["with_pruned_first_pass"] = {"reads_per_s_end_to_end_incl_d2h": n_full / dtp, "pass2_kernel_ms": ksp * 1e3,
                                        "identical": bool(np.array_equal(ap.status, a.status) and np.array_equal(ap.records, a.records)
                                                          and np.array_equal(ap.inc, a.inc) and np.array_equal(ap.op, a.op))}
     del ap
@@ -278,8 +285,8 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     entry = {"reads_per_s_end_to_end_incl_d2h": 1_000_000 / dt, "kernels_ms": ks * 1e3, "ciglets": int(len(a3.inc)),
              "call": "into_local_profile(..).sw_align_from_i8_3pass(SeqSrc::Reference(ref)) (three_pass.rs: ranges, then no-gaps / banded / scalar in the box)"}
     entry.update(rooflines(1e6 * (READ_LEN + 4.0) + float((a3.status == 0).sum()) * 40.0 + len(a3.inc) * 5.0, ks))
-    ap, dtp, _ = with_pruning(lambda: prof.sw_align_from_i8_3pass(zoe_amd.SeqSrc.Reference(ref2k)))
-    entry["with_pruned_first_pass"] = {"reads_per_s_end_to_end_incl_d2h": 1_000_000 / dtp,
+    ap, dtp, ksp = with_pruning(lambda: prof.sw_align_from_i8_3pass(zoe_amd.SeqSrc.Reference(ref2k)))
+    entry["with_pruned_first_pass"] = {"reads_per_s_end_to_end_incl_d2h": 1_000_000 / dtp, "kernels_ms": ksp * 1e3,
                                        "identical": bool(np.array_equal(ap.status, a3.status) and np.array_equal(ap.records, a3.records)
                                                          and np.array_equal(ap.inc, a3.inc) and np.array_equal(ap.op, a3.op))}
     out["align_3pass_1M_x_150bp_vs_2kb"] = entry
