@@ -178,14 +178,14 @@ def rooflines(algo_bytes: float, kernel_s: float, valu_instr: float = None, sour
 
 
 def pruned_headline(zoe_amd, ctx, profiles, reference, full, n_reads, steps):
-    """The headline workload again with the opt-in column-pruned pass (zsw_debug_set(ZSW_DEBUG_SCORE_PRUNE),
+    """The headline workload again with the opt-in column-pruned pass (zsw_set_option(ZSW_OPTION_EXACT_PRUNING, 1),
     zoe_amd/csrc/zsw_score_prune.hip): every score, status and tier must equal the full pass's (`full`), all n_reads of them.
     Not part of `value`: `value` is the default path, which computes every cell."""
     import torch
 
     from zoe_amd import _lib
 
-    ctx.debug_set(_lib.DEBUG_SCORE_PRUNE)
+    ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
     try:
         got = profiles.sw_score_from_i8(reference)  # warm-up: workspace allocation
         torch.cuda.synchronize()
@@ -199,7 +199,7 @@ def pruned_headline(zoe_amd, ctx, profiles, reference, full, n_reads, steps):
         ctx.timing_enable(False)
         rescored = ctx.prune_rescored()
     finally:
-        ctx.debug_set(0)
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
     same = bool(torch.equal(got.score, full.score) and torch.equal(got.status, full.status) and torch.equal(got.tier, full.tier))
     if not same:
         raise SystemExit("PARITY FAILURE: the column-pruned pass differs from the full pass")
@@ -213,7 +213,7 @@ def pruned_headline(zoe_amd, ctx, profiles, reference, full, n_reads, steps):
         "how": "a 24-column strip over every reference row (prune_strip_kernel) + the other 126 columns in a window of rows around "
                "the read's anchor (prune_window_kernel); three upper-bound checks per read decide whether any uncomputed cell could "
                "matter; reads that fail are rescored by score_kernel_v2 over all their cells. Exact for every input; opt-in "
-               "(zsw_debug_set(ZSW_DEBUG_SCORE_PRUNE)); see DESIGN.md 4.1d",
+               "(zsw_set_option(ctx, ZSW_OPTION_EXACT_PRUNING, 1)); see DESIGN.md 4.1d",
         "work": "VALU wave-instructions issued / those of the full pass = 0.31 on this workload: strip 0.17, window 0.09, rescoring 0.05 ("
                 + file_tag("profiles/r02_prune_summary.txt") + ")",
     }
@@ -250,11 +250,11 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
         """the same call with the opt-in column-pruned first pass (bit-identical)"""
         from zoe_amd import _lib
 
-        ctx.debug_set(_lib.DEBUG_SCORE_PRUNE)
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
         try:
             return timed(fn)
         finally:
-            ctx.debug_set(0)
+            ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
 
     ctx.timing_enable(True)
     # configs[2]: 10 M reads, sw_simd_align with CIGAR, bit-exact vs the CPU path of the same <T, N>

@@ -254,6 +254,12 @@ void zsw_synth_reads_ragged_host(uint64_t seed, uint64_t first, uint64_t n, uint
 zsw_error zsw_timing_enable(zsw_context* ctx, int enable);
 zsw_error zsw_timing_read(zsw_context* ctx, double* seconds, uint64_t* launches);
 
+/* Options of a context. ZSW_OPTION_EXACT_PRUNING (value 0 / 1, default 0): the exact column-pruned first pass described at
+ * ZSW_DEBUG_SCORE_PRUNE below — same results for every input, about three times the rate on reads that resemble the reference,
+ * up to 32 GiB of device workspace. Unknown options or values return ZSW_ERR_INVALID_ARGUMENT. */
+typedef enum zsw_option { ZSW_OPTION_EXACT_PRUNING = 1 } zsw_option;
+zsw_error zsw_set_option(zsw_context* ctx, zsw_option option, int64_t value);
+
 /* Kernel-selection overrides for the parity tests (every path below is bit-identical to the default one; the tests
  * prove it by running both). Results never depend on these bits, only which kernel produces them. The library reads
  * no environment variable. */
@@ -265,7 +271,8 @@ typedef enum zsw_debug_flag {
     ZSW_DEBUG_NO_SIDE_STREAMS = 16,  /* score: length classes of a ragged batch run one after the other */
     ZSW_DEBUG_NO_PIPELINE = 32,      /* score: host batches are copied whole before the kernel */
     ZSW_DEBUG_ALIGN_NO_PACKED = 64,  /* align: the 32-bit one-read-per-lane-group kernel answers every group */
-    /* The exact column-pruned first pass (zsw_score_prune.hip), opt-in: every entry point that starts with a score
+    /* The exact column-pruned first pass (zsw_score_prune.hip), opt-in (the bit zsw_set_option(ctx,
+     * ZSW_OPTION_EXACT_PRUNING, 1) sets): every entry point that starts with a score
      * pass (score, ends, ranges, alignment, 3-pass alignment) takes it for reads of 65..400 bases in batches (or length classes of a
      * ragged batch) of 65,536 reads or more: a narrow strip of query columns against every reference row, the other columns only in
      * a window of rows around the read's anchor, upper-bound checks, and the full pass for the reads that fail one. Same results

@@ -297,3 +297,33 @@ def test_ragged_batch_mixed_lengths_vs_30kb(za, oracle, pruned):
     want = prof.sw_score_ranges_from_i8(za.SeqSrc.Reference(ref))
     for f in ("score", "status", "tier", "ref_start", "ref_end", "query_start", "query_end"):
         assert torch.equal(getattr(rg, f), getattr(want, f)), f
+
+
+def test_the_option_switches_the_pruned_pass_on_and_off(za):
+    """zsw_set_option(ZSW_OPTION_EXACT_PRUNING): the documented switch (the debug bits only add the any-size override for tests)."""
+    import torch
+
+    from zoe_amd import _lib, synth
+
+    ctx = za.SwContext.get(0)
+    ref = synth.reference_host(2000)
+    n = 70000  # above the size threshold of the pruned pass
+    rb = synth.reads_device(ctx, ref, 0, n, 150)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
+    full = prof.sw_score_from_i8(ref)
+    assert ctx.prune_rescored() == 0
+    ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
+    try:
+        got = prof.sw_score_from_i8(ref)
+        assert 0 < ctx.prune_rescored() < n // 4
+    finally:
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
+    again = prof.sw_score_from_i8(ref)
+    assert ctx.prune_rescored() == 0
+    for a in (got, again):
+        assert torch.equal(a.score, full.score) and torch.equal(a.status, full.status) and torch.equal(a.tier, full.tier)
+    with pytest.raises(_lib.ZswError):
+        ctx.set_option(99, 1)
+    with pytest.raises(_lib.ZswError):
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 2)

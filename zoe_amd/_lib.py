@@ -27,6 +27,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 # zsw_debug_flag (kernel-selection overrides for the parity tests; results never depend on them)
 DEBUG_SCORE_V1, DEBUG_NO_TILES, DEBUG_NO_W32, DEBUG_NO_WIDE, DEBUG_NO_SIDE_STREAMS, DEBUG_NO_PIPELINE, DEBUG_ALIGN_NO_PACKED = 1, 2, 4, 8, 16, 32, 64
 DEBUG_SCORE_PRUNE, DEBUG_SCORE_PRUNE_ANY_SIZE = 128, 256
+OPTION_EXACT_PRUNING = 1
 INT_TYPES = {"i8": 0, "i16": 1, "i32": 2, "u8": 3, "u16": 4, "u32": 5}
 
 # every symbol include/zoe_sw.h declares (tests/test_capi_symbols.py checks the two lists agree)
@@ -34,7 +35,7 @@ SYMBOLS = [
     "zsw_create", "zsw_destroy", "zsw_last_error_string", "zsw_device_count", "zsw_set_scoring", "zsw_set_reference",
     "zsw_score_batch", "zsw_score_batch_from", "zsw_score_ends_batch", "zsw_score_ranges_batch", "zsw_score_ranges_batch_from", "zsw_align_batch", "zsw_align_batch_from", "zsw_align_3pass_batch", "zsw_align_3pass_batch_from", "zsw_sneaky_snake_batch",
     "zsw_synth_reads", "zsw_synth_reads_ragged", "zsw_synth_length", "zsw_synth_reference_host", "zsw_synth_reads_host",
-    "zsw_synth_reads_ragged_host", "zsw_selftest", "zsw_timing_enable", "zsw_timing_read", "zsw_debug_set", "zsw_prune_rescored",
+    "zsw_synth_reads_ragged_host", "zsw_selftest", "zsw_timing_enable", "zsw_timing_read", "zsw_debug_set", "zsw_prune_rescored", "zsw_set_option",
     "zsw_group_create", "zsw_group_destroy", "zsw_group_size", "zsw_group_context", "zsw_group_last_error_string", "zsw_group_set_scoring",
     "zsw_group_set_reference", "zsw_group_score_batch_from", "zsw_group_score_batch_from_device", "zsw_group_align_batch_from",
     "zsw_group_align_3pass_batch_from",
@@ -121,6 +122,7 @@ def load() -> C.CDLL:
     lib.zsw_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.zsw_debug_set.argtypes = [vp, C.c_uint32]
     lib.zsw_prune_rescored.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.zsw_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.zsw_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     lib.zsw_group_destroy.argtypes = [vp]
     lib.zsw_group_destroy.restype = None

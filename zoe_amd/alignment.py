@@ -254,6 +254,10 @@ class SwContext:
         """zsw_debug_set: kernel-selection overrides (_lib.DEBUG_*) for the parity tests; 0 restores the defaults."""
         self.check(self.lib.zsw_debug_set(self.h, int(flags)))
 
+    def set_option(self, option: int, value: int):
+        """zsw_set_option, e.g. set_option(_lib.OPTION_EXACT_PRUNING, 1): the exact column-pruned first pass (same results)."""
+        self.check(self.lib.zsw_set_option(self.h, int(option), int(value)), profile_errors=False)
+
     def prune_rescored(self) -> int:
         """zsw_prune_rescored: reads of the last column-pruned score call that were rescored over all their cells."""
         v = C.c_uint64(0)

@@ -1231,6 +1231,15 @@ zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags) {
     return ZSW_OK;
 }
 
+zsw_error zsw_set_option(zsw_context* ctx, zsw_option option, int64_t value) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (option == ZSW_OPTION_EXACT_PRUNING && (value == 0 || value == 1)) {
+        ctx->debug = value ? (ctx->debug | ZSW_DEBUG_SCORE_PRUNE) : (ctx->debug & ~(uint32_t)ZSW_DEBUG_SCORE_PRUNE);
+        return ZSW_OK;
+    }
+    return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "unknown option or value");
+}
+
 zsw_error zsw_prune_rescored(zsw_context* ctx, uint64_t* out_reads) {
     DeviceGuard device_guard(ctx);
     if (!ctx || !out_reads) return ZSW_ERR_INVALID_ARGUMENT;
