@@ -131,6 +131,8 @@ class GpuContext {
     GpuContext(const GpuContext&) = delete;
     GpuContext& operator=(const GpuContext&) = delete;
     zsw_context* raw() const { return ctx_; }
+    // zsw_set_option(ZSW_OPTION_EXACT_PRUNING): the exact column-pruned first pass (same results for every input)
+    void set_exact_pruning(bool on) { check(zsw_set_option(ctx_, ZSW_OPTION_EXACT_PRUNING, on ? 1 : 0)); }
     void check(zsw_error e) const {
         if (e == ZSW_OK) return;
         if (e >= 1 && e <= 4) throw ProfileError(e);
