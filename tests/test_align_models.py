@@ -37,3 +37,14 @@ def test_packed_row_update_twin_equals_the_oracle(tmp_path, seed):
     per wavefront with different lengths and last rows, the first rows through the flag-less scan path."""
     out = subprocess.run([_build(tmp_path, "align_pk_twin"), "5", str(seed)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("seed", [20261004, 5, 77])
+def test_pruning_bounds_model(tmp_path, seed):
+    """The claim the column-pruned first pass rests on (zoe_amd/csrc/zsw_score_prune.hip), with plain integers against the full
+    Gotoh matrix: a read that passes the three bound checks has the true maximum (and, with the strict checks, the true first
+    row and column); strips of 8-48 columns, six scoring schemes (free gaps and gap_extend 0 among them), repeats, second
+    copies, long gaps, junk ends, reads hanging over the reference ends."""
+    out = subprocess.run([_build(tmp_path, "prune_bounds"), "80", str(seed)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "prune_bounds OK" in out.stdout
