@@ -1,6 +1,7 @@
 """CPU checks of the alignment kernel's arithmetic (no GPU): the closed form of Zoe's lazy-F loop (striped.rs:528-553)
 and the packed row update the gfx950 kernel is compiled from (zoe_amd/csrc/zsw_align_pk.hpp), both compared cell by
-cell with the oracle's literal restatement of sw_simd_align."""
+cell with the oracle's literal restatement of sw_simd_align; and the bound checks of the column-pruned first pass
+(zoe_amd/csrc/zsw_score_prune.hip) against the full DP matrix."""
 import os
 import subprocess
 
