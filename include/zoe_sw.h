@@ -274,7 +274,7 @@ typedef enum zsw_debug_flag {
     /* The exact column-pruned first pass (zsw_score_prune.hip), opt-in (the bit zsw_set_option(ctx,
      * ZSW_OPTION_EXACT_PRUNING, 1) sets): every entry point that starts with a score
      * pass (score, ends, ranges, alignment, 3-pass alignment) takes it for reads of 65..400 bases in batches (or length classes of a
-     * ragged batch) of 65,536 reads or more: a narrow strip of query columns against every reference row, the other columns only in
+     * ragged batch) of 98,304 reads or more: a narrow strip of query columns against every reference row, the other columns only in
      * a window of rows around the read's anchor, upper-bound checks, and the full pass for the reads that fail one. Same results
      * for every input; about three times the rate on reads that resemble the reference; up to 32 GiB of workspace. */
     ZSW_DEBUG_SCORE_PRUNE = 128,

@@ -307,7 +307,7 @@ def test_the_option_switches_the_pruned_pass_on_and_off(za):
 
     ctx = za.SwContext.get(0)
     ref = synth.reference_host(2000)
-    n = 70000  # above the size threshold of the pruned pass
+    n = 100000  # above the size threshold of the pruned pass
     rb = synth.reads_device(ctx, ref, 0, n, 150)
     dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
     prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
