@@ -254,15 +254,21 @@ void zsw_synth_reads_ragged_host(uint64_t seed, uint64_t first, uint64_t n, uint
 zsw_error zsw_timing_enable(zsw_context* ctx, int enable);
 zsw_error zsw_timing_read(zsw_context* ctx, double* seconds, uint64_t* launches);
 
-/* Options of a context. ZSW_OPTION_EXACT_PRUNING (value 0 / 1, default 0): the exact column-pruned first pass described at
- * ZSW_DEBUG_SCORE_PRUNE below — same results for every input, about three times the rate on reads that resemble the reference,
- * up to 32 GiB of device workspace. Unknown options or values return ZSW_ERR_INVALID_ARGUMENT. */
+/* Options of a context. ZSW_OPTION_EXACT_PRUNING (value 0 / 1, default 1): the seeded exact first pass (zsw_score_seed.hip;
+ * DESIGN.md 4.1e). sw_simd_score returns only the maximum of the DP matrix (striped.rs:65-142), so every entry point that starts
+ * with a score pass (score, ends, ranges, alignment, 3-pass alignment) first looks a few k-mers of each read up in an index of
+ * the reference, computes the rows around the diagonal they agree on, and accepts the maximum found there only if upper bounds
+ * show that no alignment elsewhere can reach it; every other read is scored over all its cells. Same results for every input;
+ * roughly an order of magnitude fewer cells on reads that resemble the reference, the cost of the full pass plus a few per
+ * cent on reads that do not. 20 bytes of device workspace per read and 8 * 4^K bytes of index (K = 8 for a 2 kb reference:
+ * 512 KiB; K = 10 for 30 kb: 8 MiB). Value 0 frees the workspace and computes every cell of every read.
+ * Unknown options or values return ZSW_ERR_INVALID_ARGUMENT. */
 typedef enum zsw_option { ZSW_OPTION_EXACT_PRUNING = 1 } zsw_option;
 zsw_error zsw_set_option(zsw_context* ctx, zsw_option option, int64_t value);
 
 /* Kernel-selection overrides for the parity tests (every path below is bit-identical to the default one; the tests
- * prove it by running both). Results never depend on these bits, only which kernel produces them. The library reads
- * no environment variable. */
+ * prove it by running both). Results never depend on these bits, only which kernel produces them. They are kept apart
+ * from the options above: zsw_debug_set(ctx, 0) does not switch an option off. The library reads no environment variable. */
 typedef enum zsw_debug_flag {
     ZSW_DEBUG_SCORE_V1 = 1,          /* score: Zoe's signed-offset arithmetic (score_kernel) instead of the drift-domain kernel */
     ZSW_DEBUG_NO_TILES = 2,          /* score: reads longer than the widest strip configuration go to the exact 32-bit kernel */
@@ -271,19 +277,19 @@ typedef enum zsw_debug_flag {
     ZSW_DEBUG_NO_SIDE_STREAMS = 16,  /* score: length classes of a ragged batch run one after the other */
     ZSW_DEBUG_NO_PIPELINE = 32,      /* score: host batches are copied whole before the kernel */
     ZSW_DEBUG_ALIGN_NO_PACKED = 64,  /* align: the 32-bit one-read-per-lane-group kernel answers every group */
-    /* The exact column-pruned first pass (zsw_score_prune.hip), opt-in (the bit zsw_set_option(ctx,
-     * ZSW_OPTION_EXACT_PRUNING, 1) sets): every entry point that starts with a score
-     * pass (score, ends, ranges, alignment, 3-pass alignment) takes it for reads of 65..400 bases in batches (or length classes of a
-     * ragged batch) of 98,304 reads or more: a narrow strip of query columns against every reference row, the other columns only in
-     * a window of rows around the read's anchor, upper-bound checks, and the full pass for the reads that fail one. Same results
-     * for every input; about three times the rate on reads that resemble the reference; up to 32 GiB of workspace. */
-    ZSW_DEBUG_SCORE_PRUNE = 128,
-    ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE = 256 /* with SCORE_PRUNE: batches of every size do (the full pass is faster for small ones; tests) */
+    ZSW_DEBUG_SCORE_PRUNE = 128,     /* the bit ZSW_OPTION_EXACT_PRUNING holds (set by default); here for completeness */
+    ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE = 256, /* pruned passes for batches of every size (by default batches under 1,024 reads take the full pass) */
+    /* with SCORE_PRUNE: round 2's column-pruned pass (zsw_score_prune.hip) instead of the seeded one: a narrow
+     * strip of query columns against every reference row, the other columns in a window of rows around the strip's best row,
+     * bound checks, the full pass for the reads that fail one. Reads of 65..400 bases, batches of 98,304 reads or more (or
+     * ANY_SIZE), up to 32 GiB of workspace. Kept as a cross-check of the seeded pass. */
+    ZSW_DEBUG_PRUNE_STRIP = 512
 } zsw_debug_flag;
 zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags);
 
-/* Reads of the context's last column-pruned score call that failed a bound check and were scored over all their cells
- * (0 if the last score call did not take the pruned pass). Synchronises the device. Diagnostics for tests and bench.py. */
+/* Reads of the context's last score call that the seeded (or column-pruned) pass handed back — no anchor, or a bound check
+ * failed — and that were scored over all their cells (0 if the call did not take such a pass). Synchronises the device.
+ * Diagnostics for tests and bench.py. */
 zsw_error zsw_prune_rescored(zsw_context* ctx, uint64_t* out_reads);
 
 #ifdef __cplusplus

@@ -1,10 +1,14 @@
-"""GPU parity tests of the column-pruned score-only pass (zsw_score_prune.hip, ZSW_DEBUG_SCORE_PRUNE).
+"""GPU parity tests of the two exact pruned score passes: the seeded pass (zsw_score_seed.hip, the default) and round 2's
+column-pruned pass (zsw_score_prune.hip, ZSW_DEBUG_PRUNE_STRIP).
 
-The pruned pass must return exactly what the full pass returns — for every input, because a read whose bound checks fail
-is rescored over all its cells. Checker: oracle/ (CPU restatement) on every case, plus the default GPU path on the large
-batch. The cases are built to hit both outcomes: reads that pass the checks (the fast path) and reads that cannot (repeats,
-long gaps, chimeras, junk ends, low scores), and `prune_rescored()` shows which happened.
+A pruned pass must return exactly what the full pass returns — for every input, because a read without an anchor or whose
+bound checks fail is rescored over all its cells. Checker: oracle/ (CPU restatement) on every case, plus the full GPU pass
+(zsw_set_option(ZSW_OPTION_EXACT_PRUNING, 0)) on the large batches. The cases are built to hit both outcomes: reads that
+pass the checks (the fast path) and reads that cannot (repeats, long gaps, chimeras, junk ends, low scores), and
+`prune_rescored()` shows which happened.
 """
+import contextlib
+
 import numpy as np
 import pytest
 
@@ -24,14 +28,28 @@ def za():
     return zoe_amd
 
 
-@pytest.fixture
-def pruned(za):
+@pytest.fixture(params=["seeded", "strip"])
+def pruned(za, request):
+    """The context with a pruned pass switched on for batches of every size: the seeded pass, or the strip + window pass."""
     from zoe_amd import _lib
 
     ctx = za.SwContext.get(0)
-    ctx.debug_set(_lib.DEBUG_SCORE_PRUNE | _lib.DEBUG_SCORE_PRUNE_ANY_SIZE)
+    ctx.kind = request.param
+    ctx.debug_set(_lib.DEBUG_SCORE_PRUNE_ANY_SIZE | (_lib.DEBUG_PRUNE_STRIP if request.param == "strip" else 0))
     yield ctx
     ctx.debug_set(0)
+
+
+@contextlib.contextmanager
+def full_pass(ctx):
+    """every cell of every read (the option off)"""
+    from zoe_amd import _lib
+
+    ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
+    try:
+        yield
+    finally:
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
 
 
 def _score(za, reads2d, matrix, go, ge, ref):
@@ -91,7 +109,7 @@ def test_lengths_outside_the_pruned_range_take_the_full_pass(za, oracle, pruned)
 
     ref = synth.reference_host(2000)
     dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
-    for L in (64, 401, 600):
+    for L in ((64, 401, 600) if pruned.kind == "strip" else (8, 23)):
         reads = synth.reads_host(ref, 5, 300, L)
         assert _check(za, oracle, reads, dna, -10, -1, ref, pruned) == 0
 
@@ -195,9 +213,9 @@ def test_large_batch_equals_the_full_pass_and_is_mostly_pruned(za, pruned):
     prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
     got = prof.sw_score_from_i8(ref)
     rescored = pruned.prune_rescored()
-    pruned.debug_set(0)
-    want = prof.sw_score_from_i8(ref)
-    assert pruned.prune_rescored() == 0
+    with full_pass(pruned):
+        want = prof.sw_score_from_i8(ref)
+        assert pruned.prune_rescored() == 0
     assert torch.equal(got.score, want.score) and torch.equal(got.status, want.status) and torch.equal(got.tier, want.tier)
     assert 0 < rescored < n // 10
 
@@ -234,9 +252,8 @@ def test_ends_ranges_and_alignments_with_the_pruned_first_pass(za, oracle, prune
 
     got = run_all()
     rescored = pruned.prune_rescored()
-    pruned.debug_set(0)
-    want = run_all()
-    pruned.debug_set(_lib.DEBUG_SCORE_PRUNE | _lib.DEBUG_SCORE_PRUNE_ANY_SIZE)
+    with full_pass(pruned):
+        want = run_all()
     for g, w in zip(got[:3], want[:3]):
         for tg, tw in zip(_tensors(g), _tensors(w)):
             assert torch.equal(tg, tw)
@@ -293,34 +310,35 @@ def test_ragged_batch_mixed_lengths_vs_30kb(za, oracle, pruned):
     assert np.array_equal(got.tier.cpu().numpy(), want_tier)
     assert 0 < rescored < n // 2
     rg = prof.sw_score_ranges_from_i8(za.SeqSrc.Reference(ref))
-    pruned.debug_set(0)
-    want = prof.sw_score_ranges_from_i8(za.SeqSrc.Reference(ref))
+    with full_pass(pruned):
+        want = prof.sw_score_ranges_from_i8(za.SeqSrc.Reference(ref))
     for f in ("score", "status", "tier", "ref_start", "ref_end", "query_start", "query_end"):
         assert torch.equal(getattr(rg, f), getattr(want, f)), f
 
 
-def test_the_option_switches_the_pruned_pass_on_and_off(za):
-    """zsw_set_option(ZSW_OPTION_EXACT_PRUNING): the documented switch (the debug bits only add the any-size override for tests)."""
+def test_the_option_switches_the_pruned_pass_off_and_on(za):
+    """zsw_set_option(ZSW_OPTION_EXACT_PRUNING): on by default; 0 computes every cell; zsw_debug_set does not touch it."""
     import torch
 
     from zoe_amd import _lib, synth
 
     ctx = za.SwContext.get(0)
     ref = synth.reference_host(2000)
-    n = 100000  # above the size threshold of the pruned pass
+    n = 100000
     rb = synth.reads_device(ctx, ref, 0, n, 150)
     dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
     prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
-    full = prof.sw_score_from_i8(ref)
-    assert ctx.prune_rescored() == 0
-    ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
-    try:
-        got = prof.sw_score_from_i8(ref)
-        assert 0 < ctx.prune_rescored() < n // 4
-    finally:
-        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
+    got = prof.sw_score_from_i8(ref)
+    assert 0 < ctx.prune_rescored() < n // 4  # the default path prunes (the 2 % random reads always go back)
+    ctx.debug_set(0)  # ADVICE r02: the debug word and the options are separate
     again = prof.sw_score_from_i8(ref)
-    assert ctx.prune_rescored() == 0
+    assert 0 < ctx.prune_rescored() < n // 4
+    ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
+    try:
+        full = prof.sw_score_from_i8(ref)
+        assert ctx.prune_rescored() == 0
+    finally:
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
     for a in (got, again):
         assert torch.equal(a.score, full.score) and torch.equal(a.status, full.status) and torch.equal(a.tier, full.tier)
     with pytest.raises(_lib.ZswError):

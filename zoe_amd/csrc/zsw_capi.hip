@@ -11,6 +11,7 @@
 #include "zsw_align.hpp"
 #include "zsw_internal.hpp"
 #include "zsw_score_prune.hpp"
+#include "zsw_score_seed.hpp"
 #include "zsw_synth.h"
 #include "zsw_timer.hpp"
 
@@ -48,8 +49,14 @@ struct zsw_context {
     ScoringDev h_sc{};
     int bias = 0;
     DevBuf d_sc, d_ref, d_fb_list, d_fb_count, d_scratch, d_maxlen, d_bucket_items, d_bucket_counts, d_tile_buf, d_tile_state;
-    DevBuf d_prune, d_prune_list, d_prune_count;  // column-pruned score pass
+    DevBuf d_prune, d_prune_list, d_prune_count;  // column-pruned score pass; the worklist and its counters also serve the seeded pass
     uint32_t prune_chunk = 0;
+    // seeded exact score pass (zsw_score_seed.hip): index of the reference under the current matrix (built with the first batch
+    // that can use it, rebuilt after zsw_set_scoring / zsw_set_reference), a host copy of the reference to build it from
+    SeedIndex seed;
+    std::vector<uint8_t> h_ref;
+    DevBuf d_seed_work;
+    bool seed_ready = false;  // this call's batch takes the seeded pass (workspace and worklist are in place)
     size_t ref_len = 0;
     uint32_t scratch_len = 0;
     size_t exact_slots = 0;
@@ -61,7 +68,9 @@ struct zsw_context {
     DevBuf r_ws[20];
     KernelTimer timer;
     std::string err;
-    uint32_t debug = 0;  // zsw_debug_set
+    uint32_t debug = 0;    // zsw_debug_set (kernel-selection overrides for tests)
+    uint32_t options = ZSW_DEBUG_SCORE_PRUNE;  // zsw_set_option, as ZSW_DEBUG_* bits; exact pruning is on by default
+    uint32_t flags() const { return debug | options; }
     // host batches: reads of chunk k+1 cross PCIe on this stream while chunk k computes
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> copy_events;
@@ -277,19 +286,41 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     }
     ZSW_HIP(ctx, ctx->d_bucket_counts.ensure(64 * 4));
     ctx->prune_chunk = 0;
-    if ((ctx->debug & ZSW_DEBUG_SCORE_PRUNE) && n > 0 && (n >= PR_MIN_READS || (ctx->debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) &&
+    ctx->seed_ready = false;
+    const uint32_t flags = ctx->flags();
+    const bool any_size = (flags & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE) != 0;
+    if ((flags & ZSW_DEBUG_SCORE_PRUNE) && !(flags & ZSW_DEBUG_PRUNE_STRIP) && n > 0 && (n >= SEED_MIN_READS || any_size) && ctx->ref_len > 0 &&
+        st->max_len >= SEED_MIN_LEN) {
+        // the seeded exact pass: index of the reference (first use after a change of reference or matrix), 20 bytes of workspace
+        // per read and the worklist of the reads it hands back. If the device cannot spare them the full pass runs.
+        if (!ctx->seed.valid) ZSW_HIP(ctx, seed_index_update(&ctx->seed, ctx->h_sc, ctx->h_ref.data(), ctx->ref_len));
+        if (ctx->seed.usable) {
+            const size_t want = seed_workspace_bytes(n) + 24 * seed_workspace_bytes(0);  // ragged batches: a region per length class
+            if (ctx->d_seed_work.ensure(want) == hipSuccess && ctx->d_prune_list.ensure((size_t)n * 4 + 4) == hipSuccess &&
+                ctx->d_prune_count.ensure(64 * 4) == hipSuccess) {
+                ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 64 * 4, stream));  // [1] the call's total, [0], [2..] lists in flight
+                ctx->seed_ready = true;
+            } else {
+                (void)hipGetLastError();
+                ctx->d_seed_work.release();
+                ctx->err = "seeded pass skipped: workspace allocation failed (every cell is computed instead)";
+            }
+        }
+    }
+    if ((flags & ZSW_DEBUG_SCORE_PRUNE) && (flags & ZSW_DEBUG_PRUNE_STRIP) && n > 0 && (n >= PR_MIN_READS || any_size) &&
         ctx->ref_len > 0 && (reads->offsets ? st->max_len > 64 : prune_class_for(st->max_len) >= 0)) {
         const uint32_t chunk = prune_chunk_reads((uint32_t)n, (uint32_t)ctx->ref_len);
         // a reference so long that the boundary streams of a round's reads no longer fill the chip: the full pass
-        if (chunk >= std::min<uint32_t>((uint32_t)n, PR_MIN_READS) || (ctx->debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) {
+        if (chunk >= std::min<uint32_t>((uint32_t)n, PR_MIN_READS) || any_size) {
             // the workspace is large (8 B per read pair and reference row): if the device cannot spare it, the full pass runs
             if (ctx->d_prune.ensure(prune_workspace_bytes(chunk, (uint32_t)ctx->ref_len)) == hipSuccess &&
-                ctx->d_prune_list.ensure((size_t)n * 4 + 4) == hipSuccess && ctx->d_prune_count.ensure(8) == hipSuccess) {
-                ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 8, stream));  // [0] the class in flight, [1] the call's total
+                ctx->d_prune_list.ensure((size_t)n * 4 + 4) == hipSuccess && ctx->d_prune_count.ensure(64 * 4) == hipSuccess) {
+                ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 64 * 4, stream));  // [0] the class in flight, [1] the call's total
                 ctx->prune_chunk = chunk;
             } else {
                 (void)hipGetLastError();
                 ctx->d_prune.release();
+                ctx->err = "column-pruned pass skipped: workspace allocation failed (every cell is computed instead)";
             }
         }
     }
@@ -316,7 +347,14 @@ ScoreWorkspace score_ws(zsw_context* ctx) {
     w.tile_bytes = ctx->d_tile_buf.cap / 16 * 16;
     w.tile_state = ctx->d_tile_state.as<uint4>();
     w.side = ctx->side;
-    w.debug = ctx->debug;
+    w.debug = ctx->flags();
+    if (ctx->seed_ready) {
+        w.seed = &ctx->seed;
+        w.seed_work = ctx->d_seed_work.as<uint8_t>();
+        w.seed_bytes = ctx->d_seed_work.cap;
+        w.prune_fail_list = ctx->d_prune_list.as<uint32_t>();
+        w.prune_fail_count = ctx->d_prune_count.as<uint32_t>();
+    }
     if (ctx->prune_chunk) {
         w.prune_work = ctx->d_prune.as<uint8_t>();
         w.prune_bytes = ctx->d_prune.cap;
@@ -349,7 +387,7 @@ zsw_error run_score(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     Staged st;
     // fixed-length host batches of more than one chunk: the H2D copy of chunk k+1 overlaps the kernel of chunk k
     const bool pipelined = reads && reads->mem == ZSW_MEM_HOST && !reads->offsets && reads->fixed_len > 0 &&
-                           reads->n_reads > PIPE_CHUNK && !(ctx && (ctx->debug & ZSW_DEBUG_NO_PIPELINE));
+                           reads->n_reads > PIPE_CHUNK && !(ctx && (ctx->flags() & ZSW_DEBUG_NO_PIPELINE));
     zsw_error ze = stage(ctx, reads, stream, out_tier != nullptr, want_ends, out_score, out_status, out_tier, out_rend,
                          out_qend, &st, pipelined);
     if (ze != ZSW_OK) return ze;
@@ -682,7 +720,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     // the packed kernel (two reads per lane group, zsw_align_pk_kernel.hpp) answers the groups it covers; the 32-bit kernels
     // take scores beyond 16-bit lanes, more than 32 vectors, large alphabets and the full-window reruns
     auto packed = [&](const GroupRun& g, bool full) {
-        return !full && !g.wide && !(ctx->debug & ZSW_DEBUG_ALIGN_NO_PACKED) && align_pk_supported(g.N, g.nv, S);
+        return !full && !g.wide && !(ctx->flags() & ZSW_DEBUG_ALIGN_NO_PACKED) && align_pk_supported(g.N, g.nv, S);
     };
     auto ring_bytes_of = [&](const GroupRun& g, bool full, uint32_t grid) {
         return packed(g, full) ? align_pk_ring_bytes(g.N, g.nv, window_of(g, full), grid) : align_ring_bytes(g.N, g.nv, window_of(g, full), grid);
@@ -967,11 +1005,12 @@ void zsw_destroy(zsw_context* ctx) {
     DeviceGuard device_guard(ctx);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state, &ctx->d_prune, &ctx->d_prune_list, &ctx->d_prune_count,
+    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state, &ctx->d_prune, &ctx->d_prune_list, &ctx->d_prune_count, &ctx->d_seed_work,
                       &ctx->s_bases, &ctx->s_offsets, &ctx->s_score, &ctx->s_status, &ctx->s_tier, &ctx->s_rend, &ctx->s_qend};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->a_ws) b.release();
     for (DevBuf& b : ctx->r_ws) b.release();
+    seed_index_release(&ctx->seed);
     ctx->timer.destroy();
     if (ctx->side) {
         (void)hipEventDestroy(ctx->side->fork);
@@ -1018,6 +1057,7 @@ zsw_error zsw_set_scoring(zsw_context* ctx, const int8_t* weights, int S, const 
     ZSW_HIP(ctx, ctx->d_sc.ensure(sizeof(ScoringDev)));
     ZSW_HIP(ctx, hipMemcpy(ctx->d_sc.p, &s, sizeof(ScoringDev), hipMemcpyHostToDevice));
     ctx->scoring_set = true;
+    ctx->seed.valid = false;  // the index spells k-mers with the matrix's good residues
     return ZSW_OK;
 }
 
@@ -1030,6 +1070,12 @@ zsw_error zsw_set_reference(zsw_context* ctx, const uint8_t* reference, size_t l
     ZSW_HIP(ctx, ctx->d_ref.ensure(len + 16));
     if (len)
         ZSW_HIP(ctx, hipMemcpy(ctx->d_ref.p, reference, len, mem == ZSW_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
+    ctx->h_ref.resize(len);  // the seeded pass builds its k-mer index from a host copy
+    if (len) {
+        if (mem == ZSW_MEM_HOST) memcpy(ctx->h_ref.data(), reference, len);
+        else ZSW_HIP(ctx, hipMemcpy(ctx->h_ref.data(), reference, len, hipMemcpyDeviceToHost));
+    }
+    ctx->seed.valid = false;
     ctx->ref_len = len;
     ctx->reference_set = true;
     return ZSW_OK;
@@ -1234,7 +1280,13 @@ zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags) {
 zsw_error zsw_set_option(zsw_context* ctx, zsw_option option, int64_t value) {
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     if (option == ZSW_OPTION_EXACT_PRUNING && (value == 0 || value == 1)) {
-        ctx->debug = value ? (ctx->debug | ZSW_DEBUG_SCORE_PRUNE) : (ctx->debug & ~(uint32_t)ZSW_DEBUG_SCORE_PRUNE);
+        ctx->options = value ? (ctx->options | ZSW_DEBUG_SCORE_PRUNE) : (ctx->options & ~(uint32_t)ZSW_DEBUG_SCORE_PRUNE);
+        if (!value) {  // the workspaces of the pruned passes go back to the device
+            DeviceGuard device_guard(ctx);
+            ZSW_HIP(ctx, hipDeviceSynchronize());
+            ctx->d_prune.release();
+            ctx->d_seed_work.release();
+        }
         return ZSW_OK;
     }
     return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "unknown option or value");
@@ -1244,7 +1296,7 @@ zsw_error zsw_prune_rescored(zsw_context* ctx, uint64_t* out_reads) {
     DeviceGuard device_guard(ctx);
     if (!ctx || !out_reads) return ZSW_ERR_INVALID_ARGUMENT;
     *out_reads = 0;
-    if (!ctx->prune_chunk || !ctx->d_prune_count.p) return ZSW_OK;
+    if ((!ctx->prune_chunk && !ctx->seed_ready) || !ctx->d_prune_count.p) return ZSW_OK;
     uint32_t cnt = 0;
     ZSW_HIP(ctx, hipDeviceSynchronize());
     ZSW_HIP(ctx, hipMemcpy(&cnt, ctx->d_prune_count.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost));

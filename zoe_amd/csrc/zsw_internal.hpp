@@ -95,7 +95,12 @@ struct ScoreWorkspace {
     uint32_t prune_chunk = 0;
     uint32_t* prune_fail_list = nullptr;
     uint32_t* prune_fail_count = nullptr;
-    uint32_t debug = 0;           // ZSW_DEBUG_* bits of the context (zsw_debug_set): kernel-selection overrides for tests
+    // seeded exact pass (zsw_score_seed.hip): the context's reference index and seed_workspace_bytes(n_reads) + slack of workspace;
+    // shares the worklist above. null when the batch does not qualify
+    const struct SeedIndex* seed = nullptr;
+    uint8_t* seed_work = nullptr;
+    size_t seed_bytes = 0;
+    uint32_t debug = 0;           // ZSW_DEBUG_* bits of the context (zsw_debug_set) | its options: kernel-selection overrides
 };
 
 hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,

@@ -27,6 +27,7 @@
 #include "zsw_internal.hpp"
 #include "zsw_score_v1.hpp"
 #include "zsw_score_prune.hpp"
+#include "zsw_score_seed.hpp"
 #include "zsw_score_v2.hpp"
 #include "zsw_timer.hpp"
 
@@ -504,10 +505,33 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
                            (const uint32_t*)nullptr, d_ref, ref_len, d_sc, rule, out, ws.scratch, (uint32_t)ws.slots, ws.scratch_len, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
         return hipGetLastError();
     };
+    // Seeded exact pass (zsw_score_seed.hip) over the items of `bb` in strip configuration (g, c): seed + sort + window kernel, then
+    // score_kernel_v2 over the reads it hands back (device-side list; `counter` = its count, zeroed here). The workspace region
+    // [work_off, work_off + seed_workspace_bytes(n_items)) and fail_list + list_off belong to this call alone.
+    auto seed_items = [&](const BatchDev& bb, int g, int c, uint32_t longest, size_t work_off, uint32_t list_off, uint32_t* counter) -> hipError_t {
+        if (!use_v2 || !ws.seed || !ws.seed_work || !ws.prune_fail_list || !(ws.debug & ZSW_DEBUG_SCORE_PRUNE) || (ws.debug & ZSW_DEBUG_PRUNE_STRIP))
+            return hipErrorNotSupported;
+        if (bb.n_items < SEED_MIN_READS && !(ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) return hipErrorNotSupported;
+        if (g == 32 || work_off + seed_workspace_bytes(bb.n_items) > ws.seed_bytes) return hipErrorNotSupported;
+        ScoreArgsV2 ap = a2;
+        if (!build_tables_v2(h_sc, g, &ap) || !seed_applicable(*ws.seed, longest, ref_len, ap.limit)) return hipErrorNotSupported;
+        hipError_t pe = hipMemsetAsync(counter, 0, 4, stream);
+        if (pe != hipSuccess) return pe;
+        ap.b = bb;
+        pe = launch_score_seeded(ap, g, c, *ws.seed, ws.seed_work + work_off, seed_workspace_bytes(bb.n_items), ws.prune_fail_list + list_off, counter,
+                                 mode, stream);
+        if (pe != hipSuccess) return pe;
+        ap.b.items = ws.prune_fail_list + list_off;
+        ap.n_items_dev = counter;
+        pe = launch_table_cfg_v2(ap, g, c, mode, stream);
+        if (pe != hipSuccess) return pe;
+        hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, stream, counter, ws.prune_fail_count + 1);
+        return hipGetLastError();
+    };
     // Column-pruned pass over the items of `bb` (reads of at most kPruneClasses[cls].max_len bases), then score_kernel_v2 over the
     // reads it hands back (device-side list and count). hipErrorNotSupported: not switched on, or the batch does not qualify.
     auto prune_items = [&](const BatchDev& bb, int cls, uint32_t n_cls) -> hipError_t {
-        if (!use_v2 || !ws.prune_work || !(ws.debug & ZSW_DEBUG_SCORE_PRUNE)) return hipErrorNotSupported;
+        if (!use_v2 || !ws.prune_work || !(ws.debug & ZSW_DEBUG_SCORE_PRUNE) || !(ws.debug & ZSW_DEBUG_PRUNE_STRIP)) return hipErrorNotSupported;
         if (bb.n_items < PR_MIN_READS && !(ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) return hipErrorNotSupported;
         const int last = n_cls < bb.n_items ? cls + 1 : cls;  // the range may hold the next class too (same strip width)
         ScoreArgsV2 ap = a2;
@@ -581,8 +605,27 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         }
         const hipStream_t main_stream = stream;
         int used = 0;
-        // column-pruned pass (opt-in): consecutive length classes that share a pruning class form one item range, and pruning
-        // classes with the same strip width share the strip launch
+        // seeded exact pass per length class: each class has its own region of the workspace, its own part of the worklist (at
+        // its items' offset) and its own counter, so the classes can share the stream or not
+        {
+            size_t work_off = 0;
+            for (int k = NCLS - 1; k >= 0; --k) {
+                if (!counts[k]) continue;
+                BatchDev bk = b;
+                bk.items = ws.bucket_items + starts[k];
+                bk.n_items = counts[k];
+                const Cfg& cf = kCfgs[kBucketCfg[k]];
+                e = seed_items(bk, cf.G, cf.C, caps.cap[k], work_off, starts[k], ws.prune_fail_count + 2 + k);
+                if (e == hipSuccess) {
+                    work_off += seed_workspace_bytes(counts[k]);
+                    counts[k] = 0;
+                } else if (e != hipErrorNotSupported) {
+                    return e;
+                }
+            }
+        }
+        // column-pruned pass (strip + window; ZSW_DEBUG_PRUNE_STRIP): consecutive length classes that share a pruning class form
+        // one item range, and pruning classes with the same strip width share the strip launch
         {
             int k0[PR_N_CLASSES], k1[PR_N_CLASSES];
             uint32_t cnt[PR_N_CLASSES];
@@ -658,19 +701,18 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
             if (e != hipSuccess) return e;
             return finish_worklist();
         }
-        // The column-pruned pass (opt-in, zsw_score_prune.hip); the reads it hands back are scored over all their cells.
+        // The seeded exact pass (zsw_score_seed.hip), or the column-pruned pass (zsw_score_prune.hip; ZSW_DEBUG_PRUNE_STRIP); the
+        // reads they hand back are scored over all their cells. Otherwise the full pass. One timed interval either way.
+        if (timer) timer->begin(stream);
         e = hipErrorNotSupported;
+        {
+            int Gs = 0, Cs = 0;
+            if (score_config_for(max_len, &Gs, &Cs)) e = seed_items(b, Gs, Cs, max_len, 0, 0, ws.prune_fail_count);
+        }
         const int cls = prune_class_for(max_len);
-        if (cls >= 0) {
-            if (timer) timer->begin(stream);
-            e = prune_items(b, cls, b.n_items);
-            if (timer && e == hipSuccess) timer->end(stream);
-        }
-        if (e == hipErrorNotSupported) {
-            if (timer) timer->begin(stream);
-            e = launch_one(b, G, C);
-            if (timer) timer->end(stream);
-        }
+        if (e == hipErrorNotSupported && cls >= 0) e = prune_items(b, cls, b.n_items);
+        if (e == hipErrorNotSupported) e = launch_one(b, G, C);
+        if (timer) timer->end(stream);
         if (e != hipSuccess) return e;
     }
     return finish_worklist();

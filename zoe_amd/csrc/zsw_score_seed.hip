@@ -1,0 +1,222 @@
+// zsw_score_seed.hip — the seeded exact score pass (sw_simd_score, striped.rs:65-142: only the maximum of the DP matrix is
+// returned). Per read: (1) seed_kernel looks a few k-mers of the read up in an index of the reference (first / last occurrence
+// per k-mer), votes an anchor diagonal and derives two upper bounds on what any alignment far from that diagonal can score;
+// (2) the reads are ordered by anchor (hipCUB radix sort) so that the two reads of a lane and the reads of a block share their
+// rows; (3) seed_window_kernel (zsw_score_seed_kernel.hpp) computes all query columns for the ~len + 56 reference rows around
+// the anchor and accepts its maximum if the bounds allow no better path elsewhere. Reads without an anchor and reads whose
+// bounds fail go to a device-side list and are scored over all their cells by score_kernel_v2 (the caller does that), so the
+// results are the full pass's for every input. The argument and its arithmetic: zsw_seed.hpp; host model with the full Gotoh
+// matrix as the truth: tests/models/seed_bounds.cpp.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "zsw_score_seed.hpp"
+#include "zsw_score_v2.hpp"
+
+namespace zsw {
+
+namespace {
+
+struct SeedArgs {
+    BatchDev b;
+    const ScoringDev* sc;
+    SeedParams sp;
+    const uint2* table;
+    uint32_t first, n;
+    uint32_t* keys;
+    uint32_t* ids;
+    uint32_t* info;
+    uint32_t* masks;
+    uint32_t key_bias, fail_key;
+    uint32_t ref_len;
+    uint32_t* fail_list;
+    uint32_t* fail_count;
+};
+
+__global__ __launch_bounds__(256) void seed_kernel(SeedArgs a) {
+    __shared__ uint32_t lut32[64];
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut32);
+    if (threadIdx.x < 64) lut32[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.sc->index_map)[threadIdx.x];
+    __syncthreads();
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = k < a.n;
+    uint32_t id = 0, len = 0;
+    uint64_t off = 0;
+    if (valid) {
+        id = a.b.items ? a.b.items[a.first + k] : a.first + k;
+        off = a.b.offsets ? a.b.offsets[id] : (uint64_t)id * a.b.fixed_len;
+        len = a.b.offsets ? (uint32_t)(a.b.offsets[id + 1] - off) : a.b.fixed_len;
+    }
+    SeedRead sr;
+    sr.ok = 0;
+    sr.t_all = sr.d_fa = sr.d_bl = 0;
+    sr.bl_mask = 0;
+    if (valid && len >= SEED_MIN_LEN && len < SEED_KEY_BIAS) {
+        const uint8_t* bases = a.b.bases + off;
+        const uint2* table = a.table;
+        sr = seed_read(
+            a.sp, (int)len, [&](int c) { return (int)lut[bases[c]]; },
+            [&](uint32_t code, uint32_t* f1, uint32_t* l1) {
+                const uint2 e = table[code];
+                *f1 = e.x;
+                *l1 = e.y;
+            });
+    }
+    const bool fail = valid && !sr.ok;
+    if (valid) {
+        a.keys[k] = sr.ok ? (uint32_t)(sr.dt + (int)a.key_bias) : a.fail_key;
+        a.ids[k] = k;
+        a.info[k] = (uint32_t)sr.t_all | ((uint32_t)sr.d_fa << 16) | ((uint32_t)sr.d_bl << 24);
+        a.masks[k] = sr.bl_mask;
+    }
+    // reads without an anchor are scored over all their cells: one atomic per wavefront
+    const unsigned long long m = __ballot(fail);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(a.fail_count, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (fail) a.fail_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = id;
+    }
+}
+
+size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t sort_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                             (uint32_t*)nullptr, (int)n, 0, 32, (hipStream_t)0);
+    return bytes;
+}
+
+}  // namespace
+
+size_t seed_workspace_bytes(uint32_t n) { return 6 * round256((size_t)n * 4 + 8) + round256(sort_temp_bytes(n)) + 256; }
+
+bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, uint32_t limit) {
+    if (!ix.valid || !ix.usable || !ix.d_table || ref_len == 0 || ref_len >= (1u << 24)) return false;
+    if (max_len < SEED_MIN_LEN || max_len > SEED_MAX_LEN) return false;
+    return (uint64_t)ix.params.maxw * max_len + 8 < limit;  // no score can leave the packed range
+}
+
+hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIndex& ix, uint8_t* work, size_t work_bytes, uint32_t* fail_list,
+                               uint32_t* fail_count, int mode, hipStream_t stream) {
+    const uint32_t n = a2.b.n_items;
+    if (n == 0) return hipSuccess;
+    if (!work || work_bytes < seed_workspace_bytes(n)) return hipErrorNotSupported;
+    const size_t per = round256((size_t)n * 4 + 8);
+    uint32_t* keys = reinterpret_cast<uint32_t*>(work);
+    uint32_t* keys_out = reinterpret_cast<uint32_t*>(work + per);
+    uint32_t* ids = reinterpret_cast<uint32_t*>(work + 2 * per);
+    uint32_t* order = reinterpret_cast<uint32_t*>(work + 3 * per);
+    uint32_t* info = reinterpret_cast<uint32_t*>(work + 4 * per);
+    uint32_t* masks = reinterpret_cast<uint32_t*>(work + 5 * per);
+    void* temp = work + 6 * per;
+    size_t temp_bytes = sort_temp_bytes(n);
+    int key_bits = 1;
+    while ((1ull << key_bits) < (uint64_t)a2.ref_len + 2ull * SEED_KEY_BIAS + 2 && key_bits < 32) ++key_bits;
+    const uint32_t fail_key = key_bits >= 32 ? 0xffffffffu : (1u << key_bits) - 1u;
+
+    SeedArgs s;
+    s.b = a2.b;
+    s.sc = a2.sc;
+    s.sp = ix.params;
+    s.table = reinterpret_cast<const uint2*>(ix.d_table);
+    s.first = 0;
+    s.n = n;
+    s.keys = keys;
+    s.ids = ids;
+    s.info = info;
+    s.masks = masks;
+    s.key_bias = SEED_KEY_BIAS;
+    s.fail_key = fail_key;
+    s.ref_len = a2.ref_len;
+    s.fail_list = fail_list;
+    s.fail_count = fail_count;
+    hipLaunchKernelGGL(seed_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, s);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t*)keys, keys_out, (const uint32_t*)ids, order, (int)n, 0,
+                                                      key_bits, stream);
+    if (e != hipSuccess) return e;
+
+    SeedWindowArgs w;
+    w.b = a2.b;
+    w.ref = a2.ref;
+    w.ref_len = a2.ref_len;
+    w.sc = a2.sc;
+    for (int r = 0; r < 9; ++r) {
+        w.wtab[r][0] = a2.wtab[r][0];
+        w.wtab[r][1] = a2.wtab[r][1];
+    }
+    w.ge2 = a2.ge2;
+    w.gd2 = a2.gd2;
+    w.floor0 = a2.floor0;
+    w.K = a2.K;
+    w.rule = a2.rule;
+    w.out = a2.out;
+    w.sp = ix.params;
+    w.first = 0;
+    w.n = n;
+    w.order = order;
+    w.keys = keys;
+    w.info = info;
+    w.masks = masks;
+    w.key_bias = SEED_KEY_BIAS;
+    w.fail_key = fail_key;
+    w.fail_list = fail_list;
+    w.fail_count = fail_count;
+    if (mode == 0) return launch_seed_window_m0(w, G, C, stream);
+    if (mode == 1) return launch_seed_window_m1(w, G, C, stream);
+    return launch_seed_window_m2(w, G, C, stream);
+}
+
+hipError_t seed_index_update(SeedIndex* ix, const ScoringDev& sc, const uint8_t* h_ref, size_t ref_len) {
+    ix->valid = true;
+    ix->usable = false;
+    if (ref_len == 0 || ref_len >= (size_t(1) << 24)) return hipSuccess;
+    std::vector<uint8_t> res(ref_len);
+    bool ref_has[32] = {false};
+    for (size_t i = 0; i < ref_len; ++i) {
+        res[i] = sc.index_map[h_ref[i]];
+        ref_has[res[i] & 31] = true;
+    }
+    const int K = seed_k_for(ref_len);
+    SeedParams p{};
+    if (sc.S > 7 || !seed_analyze(sc.S, sc.w, sc.gap_open, sc.gap_extend, ref_has, K, &p)) return hipSuccess;
+    p.M1 = SEED_M1;
+    p.M2 = SEED_M2;
+    p.Dn = SEED_DN;
+    p.tol = SEED_TOL;
+    const size_t entries = size_t(1) << (2 * K);
+    std::vector<uint32_t> table(2 * entries, 0u);
+    seed_index_build(p, res.data(), ref_len, table.data());
+    const size_t bytes = table.size() * sizeof(uint32_t);
+    if (bytes > ix->table_bytes) {
+        if (ix->d_table) (void)hipFree(ix->d_table);
+        ix->d_table = nullptr;
+        ix->table_bytes = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ix->d_table), bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return hipSuccess;  // no index: every cell is computed
+        }
+        ix->table_bytes = bytes;
+    }
+    hipError_t e = hipMemcpy(ix->d_table, table.data(), bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    ix->params = p;
+    ix->usable = true;
+    return hipSuccess;
+}
+
+void seed_index_release(SeedIndex* ix) {
+    if (ix->d_table) (void)hipFree(ix->d_table);
+    ix->d_table = nullptr;
+    ix->table_bytes = 0;
+    ix->valid = false;
+    ix->usable = false;
+}
+
+}  // namespace zsw

@@ -1,0 +1,67 @@
+// zsw_score_seed.hpp — the seeded exact score pass: declarations shared by zsw_score_seed.hip (seed kernel, reference index,
+// launcher), zsw_score_seed_m{0,1,2}.hip (the window kernel per MODE) and zsw_score.hip / zsw_capi.hip (callers).
+#pragma once
+#include "zsw_internal.hpp"
+#include "zsw_seed.hpp"
+
+namespace zsw {
+
+constexpr int SEED_M1 = 40;   // window rows above the first row of the anchor diagonal (gap_open + (M1 - Dn) * gap_extend is the
+                              // price of a path that comes down to the anchor from above the window)
+constexpr int SEED_M2 = 16;   // and below its last row (the read's own deletions)
+constexpr int SEED_DN = 4;    // diagonals left of the anchor that count as near (the read's own insertions)
+constexpr int SEED_TOL = 8;   // anchor vote tolerance
+constexpr uint32_t SEED_KEY_BIAS = 1u << 16;  // sort key = anchor diagonal + bias (reads of up to 65,535 bases)
+constexpr uint32_t SEED_MAX_LEN = 2432;       // the widest strip configuration
+constexpr uint32_t SEED_MIN_LEN = 24;
+constexpr uint32_t SEED_MIN_READS = 1024;     // smaller batches: the launches of the seeded pass cost more than the cells they save
+
+// The reference index of a context: rebuilt when the reference or the scoring changes.
+struct SeedIndex {
+    bool valid = false;     // params / table describe the context's current reference and matrix
+    bool usable = false;    // ... and the seeded pass can prune with them
+    SeedParams params{};
+    uint32_t* d_table = nullptr;  // 2 * 4^K entries: (first position + 1, last position + 1) per k-mer
+    size_t table_bytes = 0;
+};
+
+struct SeedWindowArgs {
+    BatchDev b;
+    const uint8_t* ref;
+    uint32_t ref_len;
+    const ScoringDev* sc;
+    uint32_t wtab[9][2];
+    uint32_t ge2, gd2, floor0, K;
+    ResultRule rule;
+    ScoreOut out;
+    SeedParams sp;
+    uint32_t first;           // first item of the range
+    uint32_t n;               // items of the range
+    const uint32_t* order;    // items of the range sorted by key
+    const uint32_t* keys;     // [item of the range]: anchor diagonal + key_bias, or fail_key
+    const uint32_t* info;     // [item of the range]: t_all | d_fa << 16 | d_bl << 24
+    const uint32_t* masks;    // [item of the range]: SeedRead::bl_mask
+    uint32_t key_bias, fail_key;
+    uint32_t* fail_list;      // global read ids
+    uint32_t* fail_count;
+};
+
+struct ScoreArgsV2;
+
+// bytes of workspace for a range of n items
+size_t seed_workspace_bytes(uint32_t n);
+// can reads of up to max_len bases be seeded with this index, given the packed kernels' score limit?
+bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, uint32_t limit);
+// Seeds, sorts and runs the window kernel (strip configuration G x C of a2's tables) over the items of a2.b; reads without an
+// anchor and reads whose bounds fail are appended to fail_list (count at fail_count, not reset here).
+hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIndex& ix, uint8_t* work, size_t work_bytes, uint32_t* fail_list,
+                               uint32_t* fail_count, int mode, hipStream_t stream);
+// (Re)builds the index for a reference given as residue indices on the host.
+hipError_t seed_index_update(SeedIndex* ix, const ScoringDev& sc, const uint8_t* h_ref, size_t ref_len);
+void seed_index_release(SeedIndex* ix);
+
+hipError_t launch_seed_window_m0(const SeedWindowArgs& a, int G, int C, hipStream_t stream);
+hipError_t launch_seed_window_m1(const SeedWindowArgs& a, int G, int C, hipStream_t stream);
+hipError_t launch_seed_window_m2(const SeedWindowArgs& a, int G, int C, hipStream_t stream);
+
+}  // namespace zsw

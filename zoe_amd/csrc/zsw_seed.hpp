@@ -1,0 +1,338 @@
+// zsw_seed.hpp — arithmetic of the seeded exact score pass (zsw_score_seed.hip), shared with its host model
+// (tests/models/seed_bounds.cpp compiles this header with g++ and checks every claim below against the full Gotoh matrix).
+//
+// sw_simd_score returns only the maximum of the DP matrix (striped.rs:65-142). The seeded pass computes a WINDOW of reference
+// rows [a0, b1) of that matrix (all query columns, zero state above row a0) and proves, per read, that no alignment path with a
+// cell outside the window can score more than the window's maximum S'. The proof uses k-mers sampled from the read:
+//
+//   * every query column c can add at most Wp[c] = max(0, max_x w[x][q_c]) to a path, so a path spanning columns [cs, ce)
+//     scores at most the sum of Wp over the span (gaps only cost);
+//   * "good" residues are those with w[q][q] == maxw; a sampled k-mer (K consecutive query columns, all good) that a path
+//     spans completely is either aligned diagonally, without a gap, to an identical piece of the reference (an exact
+//     occurrence), or costs the path at least lambda of that potential: a mismatch costs maxw - w[x][q] >= lambda1, a deletion
+//     inside it gap_open, an inserted column maxw + gap_open (run starts in the k-mer's territory) or (s + 1) * (maxw +
+//     gap_extend) (run started before the s spacer columns in front of the k-mer, which belong to no other k-mer);
+//   * the reference index holds, per k-mer, the first and last position at which it occurs, so "no exact occurrence on a
+//     diagonal left of the window" and "none below the window" are two comparisons per k-mer.
+//
+// Paths with a cell outside the window are of three kinds, bounded separately (seed_bounds):
+//   above  the path starts in a row < a0. Its first cell lies on a diagonal (row - column) <= a0 - 1. Either it never reaches
+//          diagonal dq = dt - Dn (dt: the read's anchor diagonal) — then every exact occurrence it uses has a diagonal < dq, and
+//          it loses lambda per sampled k-mer without such an occurrence (maximised over the columns it may span: U_fa) — or it
+//          does, which takes deletions of total length >= dq - a0 + 1: T_all - gap_open - (dq - a0) * gap_extend;
+//   below  the path starts in a row >= b1: exact occurrences at positions >= b1 only (U_below);
+//   exit   the path starts inside and leaves through the last computed rows: bounded from the kernel's final H / E / F state
+//          plus the potential of the columns to the right (the V3 check of the column-pruned pass).
+// If all three are <= S' (< S' when the ends are wanted), S' is the read's score; otherwise the read is scored over all its cells.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define ZSW_SEED_HD __host__ __device__ __forceinline__
+#else
+#define ZSW_SEED_HD inline
+#endif
+
+namespace zsw {
+
+constexpr int SEED_MAX_KMERS = 8;
+constexpr int SEED_WILD_MAX = 3;      // reference windows with up to this many non-good residues are indexed under every spelling
+constexpr uint32_t SEED_NONE = 0xffffffffu;
+
+struct SeedParams {
+    int K;            // k-mer length
+    int maxw;         // largest weight of the matrix
+    int lambda;       // least loss of a sampled k-mer that is spanned but not traversed exactly (before the spacer term)
+    int ins_col;      // maxw + gap_extend: loss of one query column inside a running insertion
+    int go, ge;       // positive magnitudes
+    int M1, M2;       // window rows above the anchor diagonal's first row / below its last row
+    int Dn;           // diagonals left of the anchor that still count as "near" (the read's own insertions)
+    int tol;          // anchor vote: k-mers within this many diagonals support each other
+    uint8_t code[32]; // residue index -> 2-bit code; 0xff: not a good residue
+    uint8_t wp[32];   // residue index of the READ -> potential of a column holding it
+};
+
+// Sampled k-mers of a read of `len` bases: m of them at columns c0 + j * stride.
+ZSW_SEED_HD void seed_layout(int len, int K, int* m, int* stride, int* c0) {
+    int mm = (len + 10) / (K + 10);
+    if (mm > SEED_MAX_KMERS) mm = SEED_MAX_KMERS;
+    if (len < K) mm = 0;
+    else if (mm < 1) mm = 1;
+    *m = mm;
+    *stride = mm ? len / mm : 0;
+    *c0 = mm ? (*stride - K) / 2 : 0;
+}
+
+// lambda of a read whose sampled k-mers are `stride` columns apart
+ZSW_SEED_HD int seed_lambda(const SeedParams& p, int stride) {
+    const int spacer = (stride - p.K + 1) * p.ins_col;
+    return p.lambda < spacer ? p.lambda : spacer;
+}
+
+// Anchor diagonal: the candidate (first / last occurrence of a k-mer, as a diagonal) that most k-mers agree with.
+// has[j]: k-mer j is usable and occurs; dlo / dhi: diagonals of its first / last occurrence. Returns the support.
+ZSW_SEED_HD int seed_vote(int m, const bool* has, const int* dlo, const int* dhi, int tol, int* dt) {
+    int best = 0, bd = 0;
+    for (int i = 0; i < 2 * m; ++i) {
+        const int j = i >> 1;
+        if (!has[j] || ((i & 1) && dhi[j] == dlo[j])) continue;
+        const int d = (i & 1) ? dhi[j] : dlo[j];
+        int sup = 0;
+        for (int k = 0; k < m; ++k) {
+            if (!has[k]) continue;
+            const int a = dlo[k] - d, b = dhi[k] - d;
+            if ((a <= tol && a >= -tol) || (b <= tol && b >= -tol)) ++sup;
+        }
+        if (sup > best) {
+            best = sup;
+            bd = d;
+        }
+    }
+    *dt = bd;
+    return best;
+}
+
+// max over column spans [L, Rr) of  potential(span) - lambda * #{j in `set` : k-mer j inside the span}.
+ZSW_SEED_HD int seed_span_bound(int m, const int* pot_lo, const int* pot_hi, int t_all, const bool* set, int lambda) {
+    // left cut a: 0 -> column 0 (k-mers a.. included); a = i + 1 -> column c_i + 1 (k-mer i excluded). pot_lo[i] = potential of
+    // columns [0, c_i + 1). right cut b: m -> column len; b = i -> column c_i + K - 1 exclusive (k-mer i excluded). pot_hi[i] =
+    // potential of columns [0, c_i + K - 1).
+    int cnt[SEED_MAX_KMERS + 1];
+    cnt[0] = 0;
+    for (int j = 0; j < m; ++j) cnt[j + 1] = cnt[j] + (set[j] ? 1 : 0);
+    int best = 0;
+    for (int a = 0; a <= m; ++a) {
+        const int lo = a == 0 ? 0 : pot_lo[a - 1];
+        for (int b = a; b <= m; ++b) {  // k-mers a .. b-1 are inside
+            const int hi = b == m ? t_all : pot_hi[b];
+            const int v = hi - lo - lambda * (cnt[b] - cnt[a]);
+            if (v > best) best = v;
+        }
+    }
+    return best;
+}
+
+// Exit bound. A path that leaves the computed rows downwards continues in rows >= b1, where the k-mers of `set` (bit j: k-mer j
+// has no occurrence down there) cost lambda each. q[i], i in [0, m]: the most such a path can add from column c_i on (c_m = len),
+// every column worth maxw at most, with the right end of the path free: q[m] = 0, q[i] = max(stop before k-mer i ends, go on).
+ZSW_SEED_HD void seed_suffix_q(int m, int K, int c0, int stride, int len, int maxw, uint32_t set, int lambda, int* q /* m + 1 */) {
+    q[m] = 0;
+    for (int i = m - 1; i >= 0; --i) {
+        const int ci = c0 + i * stride, cn = i + 1 < m ? ci + stride : len;
+        const int on = maxw * (cn - ci) - (((set >> i) & 1u) ? lambda : 0) + q[i + 1];
+        const int stop = maxw * (K - 1);
+        q[i] = on > stop ? on : stop;
+    }
+}
+
+// v: value (H, or the E / F already inside a gap) of the last computed cell, in column x; the path consumes columns > x afterwards
+ZSW_SEED_HD int seed_exit_bound(int v, int x, int m, int c0, int stride, int len, int maxw, const int* q) {
+    int i = 0;  // first sampled k-mer that lies completely right of column x
+    if (m > 0 && x >= c0) {
+        i = (x - c0) / stride + 1;
+        if (i > m) i = m;
+    }
+    const int ci = i < m ? c0 + i * stride : len;
+    return v + maxw * (ci - 1 - x) + q[i];
+}
+
+struct SeedBounds {
+    int above, below;  // -1: no such path exists (the window touches that end of the reference)
+};
+
+// a0 / b1: first computed row / first row below the computed rows (of the lane group the read ran in); dt: the read's anchor
+// diagonal; d_fa = T_all - U_fa, d_bl = T_all - U_below as stored by the seed kernel.
+ZSW_SEED_HD SeedBounds seed_bounds(const SeedParams& p, int t_all, int d_fa, int d_bl, int dt, int a0, int b1, int ref_len) {
+    SeedBounds r;
+    r.above = -1;
+    r.below = -1;
+    if (a0 > 0) {
+        const int need = dt - p.Dn - a0 + 1;  // deleted reference rows it takes to reach diagonal dt - Dn from above the window
+        const int gm = need >= 1 ? p.go + (need - 1) * p.ge : 0;
+        const int cut = d_fa < gm ? d_fa : gm;
+        r.above = t_all - cut;
+    }
+    if (b1 < ref_len) r.below = t_all - d_bl;
+    return r;
+}
+
+// What the seed kernel derives from one read. res(c): residue index of query column c; look(code, &first1, &last1): the index
+// entry of a k-mer (positions + 1; 0 = the k-mer does not occur).
+struct SeedRead {
+    int ok;     // an anchor was found
+    int dt;     // anchor diagonal (reference row - query column)
+    int t_all;  // potential of all columns
+    int d_fa;   // t_all - (bound of the paths that stay left of diagonal dt - Dn), capped at 255
+    int d_bl;   // t_all - (bound of the paths below row dt + len + M2), capped at 255
+    uint32_t bl_mask;  // bit j: sampled k-mer j is usable and does not occur at or below row dt + len + M2 (the exit bound's set)
+};
+
+template <class GetRes, class Lookup>
+ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetRes res, Lookup look) {
+    SeedRead out;
+    out.ok = 0;
+    out.dt = 0;
+    out.t_all = 0;
+    out.d_fa = 0;
+    out.d_bl = 0;
+    out.bl_mask = 0;
+    int m, stride, c0;
+    seed_layout(len, p.K, &m, &stride, &c0);
+    int pot_lo[SEED_MAX_KMERS], pot_hi[SEED_MAX_KMERS];
+    uint32_t code[SEED_MAX_KMERS];
+    bool usable[SEED_MAX_KMERS];
+    for (int j = 0; j < SEED_MAX_KMERS; ++j) {
+        pot_lo[j] = pot_hi[j] = 0;
+        code[j] = 0;
+        usable[j] = j < m;
+    }
+    int pot = 0, j = 0;
+    for (int c = 0; c < len; ++c) {
+        const int r = res(c) & 31;
+        pot += p.wp[r];
+        if (j < m) {
+            const int k = c - (c0 + j * stride);
+            if (k >= 0) {
+                const uint8_t cd = p.code[r];
+                if (cd == 0xff) usable[j] = false;
+                else code[j] |= (uint32_t)cd << (2 * k);
+                if (k == 0) pot_lo[j] = pot;
+                if (k == p.K - 2) pot_hi[j] = pot;
+                if (k == p.K - 1) ++j;
+            }
+        }
+    }
+    out.t_all = pot;
+    if (m == 0) return out;
+    bool has[SEED_MAX_KMERS];
+    int dlo[SEED_MAX_KMERS], dhi[SEED_MAX_KMERS], last[SEED_MAX_KMERS];
+    for (int i = 0; i < SEED_MAX_KMERS; ++i) {
+        has[i] = false;
+        dlo[i] = dhi[i] = last[i] = 0;
+        if (i < m && usable[i]) {
+            uint32_t f1 = 0, l1 = 0;
+            look(code[i], &f1, &l1);
+            if (f1 != 0) {
+                has[i] = true;
+                dlo[i] = (int)(f1 - 1) - (c0 + i * stride);
+                dhi[i] = (int)(l1 - 1) - (c0 + i * stride);
+                last[i] = (int)(l1 - 1);
+            }
+        }
+    }
+    int dt = 0;
+    const int support = seed_vote(m, has, dlo, dhi, p.tol, &dt);
+    if (support < (m >= 3 ? 2 : 1)) return out;
+    bool fa[SEED_MAX_KMERS], bl[SEED_MAX_KMERS];
+    for (int i = 0; i < SEED_MAX_KMERS; ++i) {
+        fa[i] = i < m && usable[i] && (!has[i] || dlo[i] >= dt - p.Dn);
+        bl[i] = i < m && usable[i] && (!has[i] || last[i] < dt + len + p.M2);
+    }
+    const int lam = seed_lambda(p, stride);
+    const int u_fa = seed_span_bound(m, pot_lo, pot_hi, pot, fa, lam);
+    const int u_bl = seed_span_bound(m, pot_lo, pot_hi, pot, bl, lam);
+    out.ok = 1;
+    out.dt = dt;
+    out.d_fa = pot - u_fa > 255 ? 255 : pot - u_fa;
+    out.d_bl = pot - u_bl > 255 ? 255 : pot - u_bl;
+    for (int i = 0; i < m; ++i) out.bl_mask |= bl[i] ? 1u << i : 0u;
+    return out;
+}
+
+// ---- host side: what the matrix allows, and the reference index ------------------------------------------------------------
+
+// Fills p->maxw / lambda / ins_col / go / ge / code / wp from the S x S matrix (row = reference residue). `ref_has[x]`: residue
+// index x occurs in the reference. Returns false when the seeded pass cannot prune anything for this matrix / reference (no two
+// to four good residues, a mismatch that scores maxw, free gaps): the caller then scores every cell.
+inline bool seed_analyze(int S, const int32_t* w, int go, int ge, const bool* ref_has, int K, SeedParams* p) {
+    if (S < 2 || S > 32) return false;
+    int maxw = 0;
+    for (int i = 0; i < S * S; ++i) maxw = w[i] > maxw ? w[i] : maxw;
+    if (maxw <= 0 || go <= 0) return false;
+    int n_good = 0;
+    for (int q = 0; q < 32; ++q) {
+        p->code[q] = 0xff;
+        p->wp[q] = 0;
+    }
+    for (int q = 0; q < S; ++q) {
+        int col_max = 0;
+        for (int x = 0; x < S; ++x) col_max = w[x * S + q] > col_max ? w[x * S + q] : col_max;
+        p->wp[q] = (uint8_t)(col_max > 255 ? 255 : col_max);
+        if (w[q * S + q] == maxw) {
+            if (n_good == 4) return false;  // more good residues than two bits spell
+            p->code[q] = (uint8_t)n_good++;
+        }
+    }
+    if (n_good < 2) return false;
+    int lambda = go < K * maxw ? go : K * maxw;  // a deletion inside the k-mer; and never more than the k-mer can add at all
+    for (int q = 0; q < S; ++q) {
+        if (p->code[q] == 0xff) continue;
+        for (int x = 0; x < S; ++x) {
+            if (x == q) continue;
+            const int loss = maxw - w[x * S + q];
+            if (p->code[x] != 0xff) {
+                lambda = loss < lambda ? loss : lambda;  // a mismatch between good residues
+            } else if (ref_has[x]) {
+                // a reference residue that is not good (N, ...) under a good query residue: windows with up to SEED_WILD_MAX of
+                // them are indexed under every spelling, more of them must cost at least lambda together
+                const int many = (SEED_WILD_MAX + 1) * loss;
+                lambda = many < lambda ? many : lambda;
+            }
+        }
+    }
+    if (lambda < 2) return false;
+    p->K = K;
+    p->maxw = maxw;
+    p->lambda = lambda;
+    p->ins_col = maxw + ge;
+    p->go = go;
+    p->ge = ge;
+    return true;
+}
+
+// k-mer length for a reference of R residues: a random k-mer should occur in it with a probability of a few per cent
+inline int seed_k_for(uint64_t R) {
+    int K = 8;
+    while (K < 12 && (uint64_t(1) << (2 * K)) < 32 * R) ++K;
+    return K;
+}
+
+// The index: entry[code] = (first position + 1, last position + 1) of the k-mer in the reference, (0, 0) if it does not occur.
+// `res[i]` = residue index of reference position i. Windows holding 1..SEED_WILD_MAX non-good residues are entered under every
+// spelling of those positions (a path may run through them at the loss of a wildcard, which is less than lambda).
+inline void seed_index_build(const SeedParams& p, const uint8_t* res, uint64_t R, uint32_t* table /* 2 * 4^K entries, zeroed */) {
+    const int K = p.K;
+    if (R < (uint64_t)K) return;
+    auto enter = [&](uint32_t code, uint32_t pos) {
+        uint32_t* e = table + 2 * (size_t)code;
+        if (e[0] == 0 || pos + 1 < e[0]) e[0] = pos + 1;
+        if (pos + 1 > e[1]) e[1] = pos + 1;
+    };
+    for (uint64_t i = 0; i + K <= R; ++i) {
+        uint32_t code = 0;
+        int wild[SEED_WILD_MAX], nw = 0;
+        bool skip = false;
+        for (int k = 0; k < K; ++k) {
+            const uint8_t c = p.code[res[i + k] & 31];
+            if (c == 0xff) {
+                if (nw == SEED_WILD_MAX) {
+                    skip = true;
+                    break;
+                }
+                wild[nw++] = k;
+            } else {
+                code |= (uint32_t)c << (2 * k);
+            }
+        }
+        if (skip) continue;
+        const int combos = 1 << (2 * nw);
+        for (int v = 0; v < combos; ++v) {
+            uint32_t cv = code;
+            for (int t = 0; t < nw; ++t) cv |= (uint32_t)((v >> (2 * t)) & 3) << (2 * wild[t]);
+            enter(cv, (uint32_t)i);
+        }
+    }
+}
+
+}  // namespace zsw
