@@ -101,7 +101,7 @@ bool check_read(const Scheme& s, const SeedParams& p, const std::vector<uint32_t
     ++cnt->reads;
     if (plain) ++cnt->plain;
     const Best truth = gotoh(s, ref, q, Region{0, R, 0, R}, 0);
-    auto res = [&](int c) { return (int)q[c]; };
+    auto res = [&](int c) { return zsw::seed_cell(p, (int)q[c]); };
     auto look = [&](uint32_t code, uint32_t* f1, uint32_t* l1) {
         *f1 = table[2 * (size_t)code];
         *l1 = table[2 * (size_t)code + 1];
@@ -109,7 +109,7 @@ bool check_read(const Scheme& s, const SeedParams& p, const std::vector<uint32_t
     const zsw::SeedRead sr = zsw::seed_read(p, L, res, look);
     if (!sr.ok) return true;  // no anchor: the read is scored over all its cells
     ++cnt->anchored;
-    int a0 = std::max(0, sr.dt - p.M1 - extra_top);
+    int a0 = std::max(0, sr.dt - zsw::seed_rows_above(p, L) - extra_top);
     int b1 = std::min(R, sr.dt + L + p.M2 + extra_bottom);
     if (b1 <= a0) return true;  // anchor outside the reference: handed back
     // the window: zero state above row a0
@@ -120,7 +120,7 @@ bool check_read(const Scheme& s, const SeedParams& p, const std::vector<uint32_t
     int v3 = -1;
     if (b1 < R) {
         int m, stride, c0, q[zsw::SEED_MAX_KMERS + 1];
-        zsw::seed_layout(L, p.K, &m, &stride, &c0);
+        zsw::seed_layout(L, p.K, p.spacer, &m, &stride, &c0);
         zsw::seed_suffix_q(m, p.K, c0, stride, L, p.maxw, sr.bl_mask, zsw::seed_lambda(p, stride), q);
         for (int c = 1; c <= L; ++c) {
             const int he = std::max(std::max(last_h[c], next_e[c]), 0);
@@ -211,6 +211,8 @@ int main(int argc, char** argv) {
         const int K = rnd(3, 6);
         if (!zsw::seed_analyze(s.S, s.w.data(), s.go, s.ge, ref_has, K, &p)) continue;
         p.M1 = rnd(2, 24);
+        p.M1_per8 = rnd(0, 2);
+        if (rnd(0, 2) == 0) p.spacer += rnd(0, 6);  // sparser sampling is valid too
         p.M2 = rnd(2, 14);
         p.Dn = rnd(0, 4);
         p.tol = rnd(0, 5);

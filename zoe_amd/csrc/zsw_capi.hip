@@ -55,7 +55,7 @@ struct zsw_context {
     // that can use it, rebuilt after zsw_set_scoring / zsw_set_reference), a host copy of the reference to build it from
     SeedIndex seed;
     std::vector<uint8_t> h_ref;
-    DevBuf d_seed_work;
+    DevBuf d_seed_work, d_seed_gtab;
     bool seed_ready = false;  // this call's batch takes the seeded pass (workspace and worklist are in place)
     size_t ref_len = 0;
     uint32_t scratch_len = 0;
@@ -296,7 +296,8 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
         if (!ctx->seed.valid) ZSW_HIP(ctx, seed_index_update(&ctx->seed, ctx->h_sc, ctx->h_ref.data(), ctx->ref_len));
         if (ctx->seed.usable) {
             const size_t want = seed_workspace_bytes(n) + 24 * seed_workspace_bytes(0);  // ragged batches: a region per length class
-            if (ctx->d_seed_work.ensure(want) == hipSuccess && ctx->d_prune_list.ensure((size_t)n * 4 + 4) == hipSuccess &&
+            if (ctx->d_seed_work.ensure(want) == hipSuccess && ctx->d_seed_gtab.ensure((ctx->ref_len + 2 * SEED_GTAB_PAD) * 8) == hipSuccess &&
+                ctx->d_prune_list.ensure((size_t)n * 4 + 4) == hipSuccess &&
                 ctx->d_prune_count.ensure(64 * 4) == hipSuccess) {
                 ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 64 * 4, stream));  // [1] the call's total, [0], [2..] lists in flight
                 ctx->seed_ready = true;
@@ -352,6 +353,7 @@ ScoreWorkspace score_ws(zsw_context* ctx) {
         w.seed = &ctx->seed;
         w.seed_work = ctx->d_seed_work.as<uint8_t>();
         w.seed_bytes = ctx->d_seed_work.cap;
+        w.seed_gtab = ctx->d_seed_gtab.as<uint2>();
         w.prune_fail_list = ctx->d_prune_list.as<uint32_t>();
         w.prune_fail_count = ctx->d_prune_count.as<uint32_t>();
     }
@@ -1005,7 +1007,7 @@ void zsw_destroy(zsw_context* ctx) {
     DeviceGuard device_guard(ctx);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state, &ctx->d_prune, &ctx->d_prune_list, &ctx->d_prune_count, &ctx->d_seed_work,
+    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state, &ctx->d_prune, &ctx->d_prune_list, &ctx->d_prune_count, &ctx->d_seed_work, &ctx->d_seed_gtab,
                       &ctx->s_bases, &ctx->s_offsets, &ctx->s_score, &ctx->s_status, &ctx->s_tier, &ctx->s_rend, &ctx->s_qend};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->a_ws) b.release();

@@ -70,7 +70,7 @@ struct KernelTimer;
 
 // Side streams on which the length classes of a ragged batch run concurrently (forked from / joined to the caller's stream).
 struct SideStreams {
-    static constexpr int N = 4;
+    static constexpr int N = 8;
     hipStream_t s[N];
     hipEvent_t fork, join[N];
 };
@@ -100,6 +100,7 @@ struct ScoreWorkspace {
     const struct SeedIndex* seed = nullptr;
     uint8_t* seed_work = nullptr;
     size_t seed_bytes = 0;
+    uint2* seed_gtab = nullptr;   // ref_len + 2 * SEED_GTAB_PAD entries: the per-row score table for blocks without an LDS table
     uint32_t debug = 0;           // ZSW_DEBUG_* bits of the context (zsw_debug_set) | its options: kernel-selection overrides
 };
 

@@ -370,13 +370,30 @@ __global__ void bucket_count_kernel(const uint64_t* offsets, uint32_t n, BucketC
 }
 
 __global__ void bucket_scatter_kernel(const uint64_t* offsets, uint32_t n, BucketCaps caps, uint32_t* cursors, uint32_t* items) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int k = bucket_of(caps, (uint32_t)(offsets[i + 1] - offsets[i]));
-        items[atomicAdd(&cursors[k], 1u)] = i;
+    // one atomic per wavefront and class (a million single atomics on twenty cursors took 3.2 ms)
+    const int lane = threadIdx.x & 63;
+    const uint32_t per_sweep = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += per_sweep) {
+        const uint32_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        const int k = valid ? bucket_of(caps, (uint32_t)(offsets[i + 1] - offsets[i])) : -1;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int kl = __shfl(k, leader, 64);
+            const unsigned long long same = __ballot(valid && k == kl);
+            if (k == kl) {
+                uint32_t start = 0;
+                if (lane == leader) start = atomicAdd(&cursors[kl], (uint32_t)__popcll(same));
+                start = (uint32_t)__shfl((int)start, leader, 64);
+                items[start + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = i;
+            }
+            todo &= ~same;
+        }
     }
 }
 
-__global__ void add_count_kernel(const uint32_t* count, uint32_t* total) { *total += *count; }
+__global__ void add_count_kernel(const uint32_t* count, uint32_t* total) { atomicAdd(total, *count); }
 
 hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const BatchDev& b, uint32_t max_len,
                         const uint8_t* d_ref, uint32_t ref_len, const ResultRule& rule, const ScoreOut& out,
@@ -508,6 +525,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     // Seeded exact pass (zsw_score_seed.hip) over the items of `bb` in strip configuration (g, c): seed + sort + window kernel, then
     // score_kernel_v2 over the reads it hands back (device-side list; `counter` = its count, zeroed here). The workspace region
     // [work_off, work_off + seed_workspace_bytes(n_items)) and fail_list + list_off belong to this call alone.
+    bool gtab_built = false;
     auto seed_items = [&](const BatchDev& bb, int g, int c, uint32_t longest, size_t work_off, uint32_t list_off, uint32_t* counter) -> hipError_t {
         if (!use_v2 || !ws.seed || !ws.seed_work || !ws.prune_fail_list || !(ws.debug & ZSW_DEBUG_SCORE_PRUNE) || (ws.debug & ZSW_DEBUG_PRUNE_STRIP))
             return hipErrorNotSupported;
@@ -515,11 +533,18 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         if (g == 32 || work_off + seed_workspace_bytes(bb.n_items) > ws.seed_bytes) return hipErrorNotSupported;
         ScoreArgsV2 ap = a2;
         if (!build_tables_v2(h_sc, g, &ap) || !seed_applicable(*ws.seed, longest, ref_len, ap.limit)) return hipErrorNotSupported;
-        hipError_t pe = hipMemsetAsync(counter, 0, 4, stream);
+        if (!ws.seed_gtab) return hipErrorNotSupported;
+        hipError_t pe = hipSuccess;
+        if (!gtab_built) {  // the per-row score table, for blocks whose windows do not fit one LDS table (same bytes for every g)
+            pe = seed_build_gtab(ap, ws.seed_gtab, stream);
+            if (pe != hipSuccess) return pe;
+            gtab_built = true;
+        }
+        pe = hipMemsetAsync(counter, 0, 4, stream);
         if (pe != hipSuccess) return pe;
         ap.b = bb;
-        pe = launch_score_seeded(ap, g, c, *ws.seed, ws.seed_work + work_off, seed_workspace_bytes(bb.n_items), ws.prune_fail_list + list_off, counter,
-                                 mode, stream);
+        pe = launch_score_seeded(ap, g, c, *ws.seed, ws.seed_work + work_off, seed_workspace_bytes(bb.n_items), ws.seed_gtab,
+                                 ws.prune_fail_list + list_off, counter, mode, stream);
         if (pe != hipSuccess) return pe;
         ap.b.items = ws.prune_fail_list + list_off;
         ap.n_items_dev = counter;
@@ -595,6 +620,15 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         // 70 k reads is two wavefronts per SIMD): they are spread over side streams, forked from and joined to `stream`.
         SideStreams* side = ws.side;  // owned by the context: two contexts never share fork/join events
         const bool fork = side != nullptr && !(ws.debug & ZSW_DEBUG_NO_SIDE_STREAMS);
+        if (use_v2 && ws.seed && ws.seed_gtab && (ws.debug & ZSW_DEBUG_SCORE_PRUNE) && !(ws.debug & ZSW_DEBUG_PRUNE_STRIP)) {
+            // the seeded pass's per-row score table, before the fork: every side stream reads it
+            ScoreArgsV2 ag = a2;
+            if (build_tables_v2(h_sc, 4, &ag)) {
+                e = seed_build_gtab(ag, ws.seed_gtab, stream);
+                if (e != hipSuccess) return e;
+                gtab_built = true;
+            }
+        }
         if (fork) {
             e = hipEventRecord(side->fork, stream);
             if (e != hipSuccess) return e;
@@ -606,7 +640,9 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         const hipStream_t main_stream = stream;
         int used = 0;
         // seeded exact pass per length class: each class has its own region of the workspace, its own part of the worklist (at
-        // its items' offset) and its own counter, so the classes can share the stream or not
+        // its items' offset) and its own counter, so every class runs its whole pipeline (seed, sort, window, full pass over the
+        // reads handed back) on a side stream of its own turn. A handed-back read walks all R rows however few there are of them —
+        // 15 ms per class against a 30 kb reference — so these launches must overlap.
         {
             size_t work_off = 0;
             for (int k = NCLS - 1; k >= 0; --k) {
@@ -615,7 +651,10 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
                 bk.items = ws.bucket_items + starts[k];
                 bk.n_items = counts[k];
                 const Cfg& cf = kCfgs[kBucketCfg[k]];
+                stream = fork ? side->s[used % SideStreams::N] : main_stream;
                 e = seed_items(bk, cf.G, cf.C, caps.cap[k], work_off, starts[k], ws.prune_fail_count + 2 + k);
+                stream = main_stream;
+                if (e == hipSuccess) ++used;
                 if (e == hipSuccess) {
                     work_off += seed_workspace_bytes(counts[k]);
                     counts[k] = 0;

@@ -36,9 +36,8 @@ struct SeedArgs {
 };
 
 __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a) {
-    __shared__ uint32_t lut32[64];
-    const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut32);
-    if (threadIdx.x < 64) lut32[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.sc->index_map)[threadIdx.x];
+    __shared__ uint16_t cell_lut[256];  // read byte -> seed_cell (potential, 2-bit code) of its residue
+    cell_lut[threadIdx.x] = (uint16_t)seed_cell(a.sp, (int)a.sc->index_map[threadIdx.x]);
     __syncthreads();
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const bool valid = k < a.n;
@@ -57,7 +56,7 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a) {
         const uint8_t* bases = a.b.bases + off;
         const uint2* table = a.table;
         sr = seed_read(
-            a.sp, (int)len, [&](int c) { return (int)lut[bases[c]]; },
+            a.sp, (int)len, [&](int c) { return (uint32_t)cell_lut[bases[c]]; },
             [&](uint32_t code, uint32_t* f1, uint32_t* l1) {
                 const uint2 e = table[code];
                 *f1 = e.x;
@@ -83,6 +82,14 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a) {
     }
 }
 
+__global__ void seed_gtab_kernel(const uint8_t* ref, uint32_t ref_len, const ScoringDev* sc, ScoreArgsV2 a, uint2* gtab) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ref_len + 2 * SEED_GTAB_PAD) return;
+    const int row = (int)i - SEED_GTAB_PAD;
+    const int idx = (row >= 0 && row < (int)ref_len) ? (int)sc->index_map[ref[row]] : NEUTRAL;
+    gtab[i] = make_uint2(a.wtab[idx][0], a.wtab[idx][1]);
+}
+
 size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 size_t sort_temp_bytes(uint32_t n) {
@@ -102,11 +109,11 @@ bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, ui
     return (uint64_t)ix.params.maxw * max_len + 8 < limit;  // no score can leave the packed range
 }
 
-hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIndex& ix, uint8_t* work, size_t work_bytes, uint32_t* fail_list,
-                               uint32_t* fail_count, int mode, hipStream_t stream) {
+hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIndex& ix, uint8_t* work, size_t work_bytes, uint2* gtab,
+                               uint32_t* fail_list, uint32_t* fail_count, int mode, hipStream_t stream) {
     const uint32_t n = a2.b.n_items;
     if (n == 0) return hipSuccess;
-    if (!work || work_bytes < seed_workspace_bytes(n)) return hipErrorNotSupported;
+    if (!work || !gtab || work_bytes < seed_workspace_bytes(n)) return hipErrorNotSupported;
     const size_t per = round256((size_t)n * 4 + 8);
     uint32_t* keys = reinterpret_cast<uint32_t*>(work);
     uint32_t* keys_out = reinterpret_cast<uint32_t*>(work + per);
@@ -163,6 +170,7 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIn
     w.keys = keys;
     w.info = info;
     w.masks = masks;
+    w.gtab = gtab;
     w.key_bias = SEED_KEY_BIAS;
     w.fail_key = fail_key;
     w.fail_list = fail_list;
@@ -170,6 +178,11 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIn
     if (mode == 0) return launch_seed_window_m0(w, G, C, stream);
     if (mode == 1) return launch_seed_window_m1(w, G, C, stream);
     return launch_seed_window_m2(w, G, C, stream);
+}
+
+hipError_t seed_build_gtab(const ScoreArgsV2& a2, uint2* gtab, hipStream_t stream) {
+    hipLaunchKernelGGL(seed_gtab_kernel, dim3((a2.ref_len + 2 * SEED_GTAB_PAD + 255) / 256), dim3(256), 0, stream, a2.ref, a2.ref_len, a2.sc, a2, gtab);
+    return hipGetLastError();
 }
 
 hipError_t seed_index_update(SeedIndex* ix, const ScoringDev& sc, const uint8_t* h_ref, size_t ref_len) {
@@ -186,6 +199,7 @@ hipError_t seed_index_update(SeedIndex* ix, const ScoringDev& sc, const uint8_t*
     SeedParams p{};
     if (sc.S > 7 || !seed_analyze(sc.S, sc.w, sc.gap_open, sc.gap_extend, ref_has, K, &p)) return hipSuccess;
     p.M1 = SEED_M1;
+    p.M1_per8 = SEED_M1_PER8;
     p.M2 = SEED_M2;
     p.Dn = SEED_DN;
     p.tol = SEED_TOL;

@@ -6,14 +6,15 @@
 
 namespace zsw {
 
-constexpr int SEED_M1 = 40;   // window rows above the first row of the anchor diagonal (gap_open + (M1 - Dn) * gap_extend is the
-                              // price of a path that comes down to the anchor from above the window)
+constexpr int SEED_M1 = 24;   // window rows above the first row of the anchor diagonal: M1 + len / 8 (gap_open + (rows - Dn) *
+constexpr int SEED_M1_PER8 = 1;  // gap_extend is the price of a path that comes down to the anchor from above the window)
 constexpr int SEED_M2 = 16;   // and below its last row (the read's own deletions)
 constexpr int SEED_DN = 4;    // diagonals left of the anchor that count as near (the read's own insertions)
 constexpr int SEED_TOL = 8;   // anchor vote tolerance
 constexpr uint32_t SEED_KEY_BIAS = 1u << 16;  // sort key = anchor diagonal + bias (reads of up to 65,535 bases)
 constexpr uint32_t SEED_MAX_LEN = 2432;       // the widest strip configuration
 constexpr uint32_t SEED_MIN_LEN = 24;
+constexpr int SEED_GTAB_PAD = 128;            // neutral entries on either side of the per-row table (lane skew: up to 64 + 2 rows)
 constexpr uint32_t SEED_MIN_READS = 1024;     // smaller batches: the launches of the seeded pass cost more than the cells they save
 
 // The reference index of a context: rebuilt when the reference or the scoring changes.
@@ -41,6 +42,7 @@ struct SeedWindowArgs {
     const uint32_t* keys;     // [item of the range]: anchor diagonal + key_bias, or fail_key
     const uint32_t* info;     // [item of the range]: t_all | d_fa << 16 | d_bl << 24
     const uint32_t* masks;    // [item of the range]: SeedRead::bl_mask
+    const uint2* gtab;        // the 8 table bytes of every reference row (index SEED_GTAB_PAD + row), neutral rows in the pads
     uint32_t key_bias, fail_key;
     uint32_t* fail_list;      // global read ids
     uint32_t* fail_count;
@@ -54,8 +56,10 @@ size_t seed_workspace_bytes(uint32_t n);
 bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, uint32_t limit);
 // Seeds, sorts and runs the window kernel (strip configuration G x C of a2's tables) over the items of a2.b; reads without an
 // anchor and reads whose bounds fail are appended to fail_list (count at fail_count, not reset here).
-hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIndex& ix, uint8_t* work, size_t work_bytes, uint32_t* fail_list,
-                               uint32_t* fail_count, int mode, hipStream_t stream);
+// gtab: (ref_len + 2 * SEED_GTAB_PAD) uint2, filled by seed_build_gtab (once per call of launch_score, from a2's tables).
+hipError_t seed_build_gtab(const ScoreArgsV2& a2, uint2* gtab, hipStream_t stream);
+hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIndex& ix, uint8_t* work, size_t work_bytes, uint2* gtab,
+                               uint32_t* fail_list, uint32_t* fail_count, int mode, hipStream_t stream);
 // (Re)builds the index for a reference given as residue indices on the host.
 hipError_t seed_index_update(SeedIndex* ix, const ScoringDev& sc, const uint8_t* h_ref, size_t ref_len);
 void seed_index_release(SeedIndex* ix);

@@ -13,9 +13,23 @@ namespace zsw {
     X(4, 19) X(4, 22) X(4, 25) X(4, 28) X(4, 32) X(4, 35) X(4, 38) X(8, 19) X(8, 22) X(8, 25) X(8, 28) X(8, 32) X(8, 35) X(8, 38) \
     X(16, 22) X(16, 25) X(16, 32) X(16, 38) X(64, 19) X(64, 38)
 
+// Waves per SIMD the register allocator must leave room for. Besides score_kernel_v2's state (H, E, selectors [+ snapshot row])
+// this kernel keeps the window geometry and both reads' identities across the loop and needs H and E again for the exit bound:
+// ~64 registers on top, so the widest strips run at two waves per SIMD (which still fills the 4-cycle issue slots: r03 PMC,
+// seed_window_kernel<4,38,2> at 3.99 cycles per instruction with two) instead of spilling at three.
+constexpr int seed_min_waves(int C, int MODE) {
+    const int need = MODE == 2 ? 4 * C + 96 : 3 * C + 64;
+    return need <= 80 ? 6 : need <= 96 ? 5 : need <= 128 ? 4 : need <= 168 ? 3 : 2;
+}
+
 template <int G, int C, int MODE>
-__global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void seed_window_kernel(SeedWindowArgs a) {
-    __shared__ uint2 rp[CH + 2 * G];
+__global__ __launch_bounds__(BLOCK, seed_min_waves(C, MODE)) void seed_window_kernel(SeedWindowArgs a) {
+    // one raw buffer: the block's row table during the row loop, afterwards each lane's column of max(H, E) values for the exit
+    // bound (C dwords per lane: a rolled loop over LDS instead of ~70 more live registers in an unrolled one)
+    constexpr size_t RP_BYTES = (size_t)(CH + 2 * G) * sizeof(uint2), HE_BYTES = (size_t)C * BLOCK * sizeof(uint32_t);
+    __shared__ __attribute__((aligned(16))) uint8_t sraw[RP_BYTES > HE_BYTES ? RP_BYTES : HE_BYTES];
+    uint2* rp = reinterpret_cast<uint2*>(sraw);
+    uint32_t* she = reinterpret_cast<uint32_t*>(sraw);
     __shared__ int s_lo, s_hi;
     __shared__ uint2 swt[9];
     __shared__ uint32_t lut32[64];
@@ -69,11 +83,11 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void seed_window_kernel(
 
     // the window: rows M1 above the first row of the earlier anchor diagonal to M2 below the last row of the later one
     const int dtA = (int)keyA - (int)a.key_bias, dtB = validB ? (int)keyB - (int)a.key_bias : dtA;
-    const int a0 = validA ? max(0, min(dtA, dtB) - a.sp.M1) : 0;
+    const int a0 = validA ? max(0, min(dtA - seed_rows_above(a.sp, (int)lenA), dtB - seed_rows_above(a.sp, (int)(validB ? lenB : lenA)))) : 0;
     const int b0 = validA ? min(R, max(dtA + (int)lenA, dtB + (int)(validB ? lenB : lenA)) + a.sp.M2) : 0;
-    int Tw = validA ? b0 - a0 : 0;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) Tw = max(Tw, __shfl_xor(Tw, d, 64));  // the wavefront's groups walk equally many rows
+    // rows of this lane group alone: the groups of a wavefront are independent (shuffles stay inside a group), so a group whose
+    // window is shorter simply leaves the row loop earlier; a0 + Tw <= R keeps every row access inside the tables' padding
+    const int Tw = validA ? b0 - a0 : 0;
     // the block's row table: rows [lo - (G - 1), hi + G) of the reference (real rows for the lanes' skewed last rows too)
     if (g == 0 && validA) {
         atomicMin(&s_lo, a0);
@@ -89,7 +103,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void seed_window_kernel(
         }
     }
     __syncthreads();
-    const int joff = validA ? a0 - blo + (G - 1) - g : 0;  // table entry of this lane's row at step t: joff + t
+    const int joff = (validA && staged) ? a0 - blo + (G - 1) - g : 0;  // table entry of this lane's row at step t: joff + t
 
     const uint32_t ge2 = a.ge2, gd2 = a.gd2;
     const uint32_t ge1 = ge2 & 0xffffu;
@@ -111,11 +125,16 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void seed_window_kernel(
     uint32_t snapD = 0;
     int rA = 0, rB = 0;  // window row of the lane's latest rise
     uint32_t Fout = Dr, Hlast = Dr, Hin_prev = Dr;
-    const int T = (staged && validA) ? Tw + G - 1 : 0;
-    uint2 w = rp[(staged && validA) ? joff : 0];
+    const int T = validA ? Tw + G - 1 : 0;
+    // the rows come from the block's LDS table, or — when the windows of the block's reads lie too far apart for one table (few
+    // reads against a long reference) — from the per-row table in global memory (L2), one step ahead either way
+    // (one loop over a generic pointer: two instantiations of the loop behind a lambda put the H / E / selector arrays into
+    // scratch memory)
+    const uint2* rows = staged ? static_cast<const uint2*>(rp) + joff : a.gtab + (SEED_GTAB_PAD + a0 - g);  // gtab[SEED_GTAB_PAD + r]: row r
+    uint2 w = rows[0];
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
-        const uint2 wn = rp[joff + t + 1];
+        const uint2 wn = rows[t + 1];
         const int row = t - g;  // row of the window
         const bool rebase = ge1 != 0 && row > 0 && (row & (int)(K - 1)) == 0;
         if (__ballot(rebase) != 0) {
@@ -215,16 +234,18 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void seed_window_kernel(
     // plus what the columns to the right can add in the rows below the window (seed_exit_bound) ----
     const int maxw = a.sp.maxw;
     int mA, strA, c0A, mB, strB, c0B;
-    seed_layout((int)lenA, a.sp.K, &mA, &strA, &c0A);
-    seed_layout((int)lenB, a.sp.K, &mB, &strB, &c0B);
+    seed_layout((int)lenA, a.sp.K, a.sp.spacer, &mA, &strA, &c0A);
+    seed_layout((int)lenB, a.sp.K, a.sp.spacer, &mB, &strB, &c0B);
     int* qA = sq + (tid / G) * 2 * (SEED_MAX_KMERS + 1);
     int* qB = qA + (SEED_MAX_KMERS + 1);
     if (g == 0) seed_suffix_q(mA, a.sp.K, c0A, strA, (int)lenA, maxw, validA ? a.masks[ridA] : 0u, seed_lambda(a.sp, strA), qA);
     if (g == (G > 1 ? 1 : 0)) seed_suffix_q(mB, a.sp.K, c0B, strB, (int)lenB, maxw, validB ? a.masks[ridB] : 0u, seed_lambda(a.sp, strB), qB);
-    __syncthreads();
+    __syncthreads();  // also: every wavefront of the block is done with the row table
     int v3A = -1, v3B = -1;
     if (a0 + Tw < R) {
         const int dA = (int)(Dr & 0xffffu), dB = (int)(Dr >> 16);
+#pragma unroll
+        for (int c = 0; c < C; ++c) she[c * BLOCK + tid] = pk_maxu(H[c], pk_subu(E[c], ge2));
         // the first sampled k-mer completely right of column x, as (index, its first column or len); x only grows below
         auto first_right = [](int x, int m, int c0, int stride, int len, int* i, int* ci) {
             *i = 0;
@@ -241,7 +262,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void seed_window_kernel(
         }
         first_right(g * C, mA, c0A, strA, (int)lenA, &iA, &ciA);
         first_right(g * C, mB, c0B, strB, (int)lenB, &iB, &ciB);
-#pragma unroll
+#pragma unroll 1
         for (int c = 0; c < C; ++c) {
             const int col = g * C + c;
             if (iA < mA && ciA <= col) {
@@ -252,7 +273,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void seed_window_kernel(
                 ++iB;
                 ciB = iB < mB ? ciB + strB : (int)lenB;
             }
-            const uint32_t he = pk_maxu(H[c], pk_subu(E[c], ge2));
+            const uint32_t he = she[c * BLOCK + tid];
             v3A = max(v3A, bound((int)(he & 0xffffu) - dA, col, (int)lenA, iA, ciA, qA));
             v3B = max(v3B, bound((int)(he >> 16) - dB, col, (int)lenB, iB, ciB, qB));
         }
@@ -279,7 +300,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void seed_window_kernel(
             const int bound = max(max(sb.above, sb.below), second ? v3B : v3A);
             // score only: a path outside the computed cells matters if it can score MORE than S; with ends also if it can score S
             // (it could end in an earlier row or column)
-            const bool redo = !staged || (MODE == 0 ? bound > S : bound >= S);
+            const bool redo = MODE == 0 ? bound > S : bound >= S;
             if (len == 0 || redo) {  // all cells for this read (an empty read gets its status there)
                 const uint32_t k = atomicAdd(a.fail_count, 1u);
                 a.fail_list[k] = id;

@@ -36,7 +36,7 @@
 
 namespace zsw {
 
-constexpr int SEED_MAX_KMERS = 8;
+constexpr int SEED_MAX_KMERS = 16;
 constexpr int SEED_WILD_MAX = 3;      // reference windows with up to this many non-good residues are indexed under every spelling
 constexpr uint32_t SEED_NONE = 0xffffffffu;
 
@@ -46,16 +46,19 @@ struct SeedParams {
     int lambda;       // least loss of a sampled k-mer that is spanned but not traversed exactly (before the spacer term)
     int ins_col;      // maxw + gap_extend: loss of one query column inside a running insertion
     int go, ge;       // positive magnitudes
-    int M1, M2;       // window rows above the anchor diagonal's first row / below its last row
+    int spacer;       // columns left free between two sampled k-mers, at least (so that an insertion that runs into a k-mer from
+                      // before its spacer costs lambda by the time it gets there)
+    int M1, M1_per8;  // window rows above the first row of the anchor diagonal: M1 + len * M1_per8 / 8
+    int M2;           // and below its last row
     int Dn;           // diagonals left of the anchor that still count as "near" (the read's own insertions)
     int tol;          // anchor vote: k-mers within this many diagonals support each other
     uint8_t code[32]; // residue index -> 2-bit code; 0xff: not a good residue
     uint8_t wp[32];   // residue index of the READ -> potential of a column holding it
 };
 
-// Sampled k-mers of a read of `len` bases: m of them at columns c0 + j * stride.
-ZSW_SEED_HD void seed_layout(int len, int K, int* m, int* stride, int* c0) {
-    int mm = (len + 10) / (K + 10);
+// Sampled k-mers of a read of `len` bases: m of them at columns c0 + j * stride, stride >= K + spacer.
+ZSW_SEED_HD void seed_layout(int len, int K, int spacer, int* m, int* stride, int* c0) {
+    int mm = len / (K + spacer);
     if (mm > SEED_MAX_KMERS) mm = SEED_MAX_KMERS;
     if (len < K) mm = 0;
     else if (mm < 1) mm = 1;
@@ -70,17 +73,22 @@ ZSW_SEED_HD int seed_lambda(const SeedParams& p, int stride) {
     return p.lambda < spacer ? p.lambda : spacer;
 }
 
-// Anchor diagonal: the candidate (first / last occurrence of a k-mer, as a diagonal) that most k-mers agree with.
-// has[j]: k-mer j is usable and occurs; dlo / dhi: diagonals of its first / last occurrence. Returns the support.
+// Anchor diagonal: the candidate (first / last occurrence of a k-mer, as a diagonal) that most k-mers agree with. Candidates
+// come from every k-mer when there are at most 8, from every other one above that (the anchor only decides which rows are
+// computed, never whether a result is accepted). has[j]: k-mer j is usable and occurs; dlo / dhi: diagonals of its first / last
+// occurrence. Returns the support. Loops of fixed length over arrays of SEED_MAX_KMERS: registers, not scratch memory.
 ZSW_SEED_HD int seed_vote(int m, const bool* has, const int* dlo, const int* dhi, int tol, int* dt) {
     int best = 0, bd = 0;
-    for (int i = 0; i < 2 * m; ++i) {
+    const int step = m > 8 ? 2 : 1;
+#pragma unroll
+    for (int i = 0; i < 2 * SEED_MAX_KMERS; ++i) {
         const int j = i >> 1;
-        if (!has[j] || ((i & 1) && dhi[j] == dlo[j])) continue;
+        if (j >= m || !has[j] || (j % step) != 0 || ((i & 1) && dhi[j] == dlo[j])) continue;
         const int d = (i & 1) ? dhi[j] : dlo[j];
         int sup = 0;
-        for (int k = 0; k < m; ++k) {
-            if (!has[k]) continue;
+#pragma unroll
+        for (int k = 0; k < SEED_MAX_KMERS; ++k) {
+            if (k >= m || !has[k]) continue;
             const int a = dlo[k] - d, b = dhi[k] - d;
             if ((a <= tol && a >= -tol) || (b <= tol && b >= -tol)) ++sup;
         }
@@ -97,18 +105,22 @@ ZSW_SEED_HD int seed_vote(int m, const bool* has, const int* dlo, const int* dhi
 ZSW_SEED_HD int seed_span_bound(int m, const int* pot_lo, const int* pot_hi, int t_all, const bool* set, int lambda) {
     // left cut a: 0 -> column 0 (k-mers a.. included); a = i + 1 -> column c_i + 1 (k-mer i excluded). pot_lo[i] = potential of
     // columns [0, c_i + 1). right cut b: m -> column len; b = i -> column c_i + K - 1 exclusive (k-mer i excluded). pot_hi[i] =
-    // potential of columns [0, c_i + K - 1).
-    int cnt[SEED_MAX_KMERS + 1];
-    cnt[0] = 0;
-    for (int j = 0; j < m; ++j) cnt[j + 1] = cnt[j] + (set[j] ? 1 : 0);
-    int best = 0;
-    for (int a = 0; a <= m; ++a) {
-        const int lo = a == 0 ? 0 : pot_lo[a - 1];
-        for (int b = a; b <= m; ++b) {  // k-mers a .. b-1 are inside
-            const int hi = b == m ? t_all : pot_hi[b];
-            const int v = hi - lo - lambda * (cnt[b] - cnt[a]);
-            if (v > best) best = v;
+    // potential of columns [0, c_i + K - 1). With left cut a and right cut b the k-mers a .. b-1 are inside.
+    // best = max_b ( hi(b) - lambda * cnt[b] - min_{a <= b} ( lo(a) - lambda * cnt[a] ) ), one sweep over b.
+    int best = 0, cnt = 0;
+    int low = 0;  // min over a <= b of lo(a) - lambda * cnt[a]; a = 0: lo = 0, cnt = 0
+#pragma unroll
+    for (int b = 0; b <= SEED_MAX_KMERS; ++b) {
+        if (b > m) continue;
+        // a = b enters: left cut just right of k-mer b-1's first column
+        if (b > 0) {
+            const int la = pot_lo[b - 1] - lambda * cnt;
+            low = la < low ? la : low;
         }
+        const int hi = b == m ? t_all : pot_hi[b < SEED_MAX_KMERS ? b : 0];
+        const int v = hi - lambda * cnt - low;
+        best = v > best ? v : best;
+        if (b < m && set[b < SEED_MAX_KMERS ? b : 0]) ++cnt;
     }
     return best;
 }
@@ -136,6 +148,10 @@ ZSW_SEED_HD int seed_exit_bound(int v, int x, int m, int c0, int stride, int len
     const int ci = i < m ? c0 + i * stride : len;
     return v + maxw * (ci - 1 - x) + q[i];
 }
+
+// window rows kept above the first row of a read's anchor diagonal: what a path pays to come down to the anchor from above the
+// window (gap_open + (rows - Dn) * gap_extend) should exceed what a read of this length loses to its own errors
+ZSW_SEED_HD int seed_rows_above(const SeedParams& p, int len) { return p.M1 + len * p.M1_per8 / 8; }
 
 struct SeedBounds {
     int above, below;  // -1: no such path exists (the window touches that end of the reference)
@@ -168,8 +184,12 @@ struct SeedRead {
     uint32_t bl_mask;  // bit j: sampled k-mer j is usable and does not occur at or below row dt + len + M2 (the exit bound's set)
 };
 
-template <class GetRes, class Lookup>
-ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetRes res, Lookup look) {
+// cell(c): what the seed kernel needs of query column c: potential Wp in bits 0-7, 2-bit code in bits 8-15 (0xff: the residue is
+// not a good one). look(code, &first1, &last1): the index entry of a k-mer.
+ZSW_SEED_HD uint32_t seed_cell(const SeedParams& p, int residue) { return (uint32_t)p.wp[residue & 31] | ((uint32_t)p.code[residue & 31] << 8); }
+
+template <class GetCell, class Lookup>
+ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetCell cell, Lookup look) {
     SeedRead out;
     out.ok = 0;
     out.dt = 0;
@@ -178,56 +198,52 @@ ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetRes res, Lookup 
     out.d_bl = 0;
     out.bl_mask = 0;
     int m, stride, c0;
-    seed_layout(len, p.K, &m, &stride, &c0);
-    int pot_lo[SEED_MAX_KMERS], pot_hi[SEED_MAX_KMERS];
-    uint32_t code[SEED_MAX_KMERS];
-    bool usable[SEED_MAX_KMERS];
+    seed_layout(len, p.K, p.spacer, &m, &stride, &c0);
+    // one sweep over the columns, k-mer by k-mer (the loops over the k-mers have a fixed trip count: their arrays stay in registers)
+    int pot_lo[SEED_MAX_KMERS], pot_hi[SEED_MAX_KMERS], dlo[SEED_MAX_KMERS], dhi[SEED_MAX_KMERS], last[SEED_MAX_KMERS];
+    bool usable[SEED_MAX_KMERS], has[SEED_MAX_KMERS];
+    int pot = 0, c = 0;
+#pragma unroll
     for (int j = 0; j < SEED_MAX_KMERS; ++j) {
-        pot_lo[j] = pot_hi[j] = 0;
-        code[j] = 0;
-        usable[j] = j < m;
-    }
-    int pot = 0, j = 0;
-    for (int c = 0; c < len; ++c) {
-        const int r = res(c) & 31;
-        pot += p.wp[r];
-        if (j < m) {
-            const int k = c - (c0 + j * stride);
-            if (k >= 0) {
-                const uint8_t cd = p.code[r];
-                if (cd == 0xff) usable[j] = false;
-                else code[j] |= (uint32_t)cd << (2 * k);
-                if (k == 0) pot_lo[j] = pot;
-                if (k == p.K - 2) pot_hi[j] = pot;
-                if (k == p.K - 1) ++j;
+        pot_lo[j] = pot_hi[j] = dlo[j] = dhi[j] = last[j] = 0;
+        usable[j] = has[j] = false;
+        if (j >= m) continue;
+        const int cj = c0 + j * stride;
+        for (; c < cj; ++c) pot += (int)(cell(c) & 0xffu);
+        uint32_t code = 0;
+        bool ok = true;
+        for (int k = 0; k < p.K; ++k, ++c) {
+            const uint32_t x = cell(c);
+            pot += (int)(x & 0xffu);
+            ok = ok && (x >> 8) != 0xffu;
+            code |= ((x >> 8) & 3u) << (2 * k);
+            if (k == 0) pot_lo[j] = pot;
+            if (k == p.K - 2) pot_hi[j] = pot;
+        }
+        usable[j] = ok;
+        if (ok) {
+            uint32_t f1 = 0, l1 = 0;
+            look(code, &f1, &l1);
+            if (f1 != 0) {
+                has[j] = true;
+                dlo[j] = (int)(f1 - 1) - cj;
+                dhi[j] = (int)(l1 - 1) - cj;
+                last[j] = (int)(l1 - 1);
             }
         }
     }
+    for (; c < len; ++c) pot += (int)(cell(c) & 0xffu);
     out.t_all = pot;
     if (m == 0) return out;
-    bool has[SEED_MAX_KMERS];
-    int dlo[SEED_MAX_KMERS], dhi[SEED_MAX_KMERS], last[SEED_MAX_KMERS];
-    for (int i = 0; i < SEED_MAX_KMERS; ++i) {
-        has[i] = false;
-        dlo[i] = dhi[i] = last[i] = 0;
-        if (i < m && usable[i]) {
-            uint32_t f1 = 0, l1 = 0;
-            look(code[i], &f1, &l1);
-            if (f1 != 0) {
-                has[i] = true;
-                dlo[i] = (int)(f1 - 1) - (c0 + i * stride);
-                dhi[i] = (int)(l1 - 1) - (c0 + i * stride);
-                last[i] = (int)(l1 - 1);
-            }
-        }
-    }
     int dt = 0;
     const int support = seed_vote(m, has, dlo, dhi, p.tol, &dt);
     if (support < (m >= 3 ? 2 : 1)) return out;
     bool fa[SEED_MAX_KMERS], bl[SEED_MAX_KMERS];
+#pragma unroll
     for (int i = 0; i < SEED_MAX_KMERS; ++i) {
         fa[i] = i < m && usable[i] && (!has[i] || dlo[i] >= dt - p.Dn);
         bl[i] = i < m && usable[i] && (!has[i] || last[i] < dt + len + p.M2);
+        out.bl_mask |= bl[i] ? 1u << i : 0u;
     }
     const int lam = seed_lambda(p, stride);
     const int u_fa = seed_span_bound(m, pot_lo, pot_hi, pot, fa, lam);
@@ -236,7 +252,6 @@ ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetRes res, Lookup 
     out.dt = dt;
     out.d_fa = pot - u_fa > 255 ? 255 : pot - u_fa;
     out.d_bl = pot - u_bl > 255 ? 255 : pot - u_bl;
-    for (int i = 0; i < m; ++i) out.bl_mask |= bl[i] ? 1u << i : 0u;
     return out;
 }
 
@@ -288,6 +303,8 @@ inline bool seed_analyze(int S, const int32_t* w, int go, int ge, const bool* re
     p->ins_col = maxw + ge;
     p->go = go;
     p->ge = ge;
+    p->spacer = 2;
+    while ((p->spacer + 1) * p->ins_col < lambda) ++p->spacer;
     return true;
 }
 
