@@ -4,7 +4,7 @@
 //   A  no path that STARTS above the window (row < a0) scores more than seed_bounds().above;
 //   B  no path that starts below it (row >= b1) scores more than seed_bounds().below;
 //   C  no path that starts inside and leaves through the last row scores more than the exit bound (H / E of the last row plus
-//      the potential of the columns to the right);
+//      what the columns to the right can add below the window), unless it only trails a gap from the last column (< S');
 //   D  hence: all three <= S' (the window's own maximum)  =>  S' is the read's score; all three < S'  =>  the window's first row
 //      and first column of the maximum are the true ones (tie rule of striped.rs:296-321).
 // A, B and C are checked for every read whether or not it passes (the true maxima of the three path classes come from DPs
@@ -122,7 +122,7 @@ bool check_read(const Scheme& s, const SeedParams& p, const std::vector<uint32_t
         int m, stride, c0, q[zsw::SEED_MAX_KMERS + 1];
         zsw::seed_layout(L, p.K, p.spacer, &m, &stride, &c0);
         zsw::seed_suffix_q(m, p.K, c0, stride, L, p.maxw, sr.bl_mask, zsw::seed_lambda(p, stride), q);
-        for (int c = 1; c <= L; ++c) {
+        for (int c = 1; c < L; ++c) {  // from the last column no path goes on below the window except by trailing a gap
             const int he = std::max(std::max(last_h[c], next_e[c]), 0);
             v3 = std::max(v3, zsw::seed_exit_bound(he, c - 1, m, c0, stride, L, p.maxw, q));
         }
@@ -140,7 +140,7 @@ bool check_read(const Scheme& s, const SeedParams& p, const std::vector<uint32_t
         printf("claim B violated: below %d > bound %d (dt %d b1 %d t_all %d d_bl %d)\n", true_below, sb.below, sr.dt, b1, sr.t_all, sr.d_bl);
         ok = false;
     }
-    if (b1 < R && true_exit > v3) {
+    if (b1 < R && true_exit > std::max(v3, win.best - 1)) {  // (a path that leaves from the last column only trails a gap: < window max)
         printf("claim C violated: exit %d > bound %d\n", true_exit, v3);
         ok = false;
     }

@@ -49,3 +49,16 @@ def test_pruning_bounds_model(tmp_path, seed):
     out = subprocess.run([_build(tmp_path, "prune_bounds"), "80", str(seed)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "prune_bounds OK" in out.stdout
+
+
+@pytest.mark.parametrize("seed", [20261004, 11, 314])
+def test_seeded_pass_bounds_model(tmp_path, seed):
+    """The claims the seeded exact pass rests on (zoe_amd/csrc/zsw_seed.hpp, compiled for the host as the kernels compile it),
+    with plain integers against the full Gotoh matrix: no path that starts above the window, starts below it, or leaves it through
+    the last row beats its bound — checked for every read against DPs restricted to each class of paths — and a read that passes
+    has the true maximum (with the strict checks: the true first row and column). Eight scoring schemes (free extension, N scored
+    -1 / +1), k = 3..6 on references of 60-420 bases so that chance k-mer hits abound, repeats, tandem repeats, N runs, chimeras,
+    long gaps, reads hanging over the ends."""
+    out = subprocess.run([_build(tmp_path, "seed_bounds"), "400", str(seed)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "seed_bounds OK" in out.stdout

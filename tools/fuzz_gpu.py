@@ -1,6 +1,6 @@
 """Randomised parity sweep: random scoring schemes, alphabets, lengths, lane counts and batch shapes through every GPU entry
 point (score, ends, ranges, cascades, exact and 3-pass alignment, SeqSrc inversion) against the oracle.
-usage: python tools/fuzz_gpu.py [iterations] [seed]     (FUZZ_PRUNE=1: with the column-pruned first pass; FUZZ_LONG_P: share of long-read cases)"""
+usage: python tools/fuzz_gpu.py [iterations] [seed]     (FUZZ_PRUNE=1: the seeded exact first pass for batches of every size, FUZZ_PRUNE=strip: the column-pruned one; FUZZ_LONG_P: share of long-read cases)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,7 +13,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 oracle.build()
 if os.environ.get("FUZZ_PRUNE"):  # every first pass that qualifies takes the column-pruned pass (batches of any size)
     from zoe_amd import _lib as _l
-    za.SwContext.get(0).debug_set(_l.DEBUG_SCORE_PRUNE | _l.DEBUG_SCORE_PRUNE_ANY_SIZE)
+    za.SwContext.get(0).debug_set(_l.DEBUG_SCORE_PRUNE_ANY_SIZE | (_l.DEBUG_PRUNE_STRIP if os.environ["FUZZ_PRUNE"] == "strip" else 0))
 
 
 def okey(a):

@@ -252,7 +252,9 @@ __global__ __launch_bounds__(BLOCK, seed_min_waves(C, MODE)) void seed_window_ke
             if (m > 0 && x >= c0) *i = min(m, (x - c0) / stride + 1);
             *ci = *i < m ? c0 + *i * stride : len;
         };
-        auto bound = [&](int v, int x, int len, int i, int ci, const int* q) { return x < len ? v + maxw * (ci - 1 - x) + q[i] : v; };
+        // x >= len - 1: no query column is left for the path to use below the window (a path that only trails a gap down there
+        // scores less than its last computed cell, which the window's maximum covers) — and padding columns carry copies of H
+        auto bound = [&](int v, int x, int len, int i, int ci, const int* q) { return x < len - 1 ? v + maxw * (ci - 1 - x) + q[i] : -1; };
         int iA, ciA, iB, ciB;
         if (g > 0) {  // the diagonal from the left neighbour's last column, one row up, into this lane's first column
             first_right(g * C - 1, mA, c0A, strA, (int)lenA, &iA, &ciA);
