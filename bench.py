@@ -8,7 +8,10 @@
 One process per GPU.  A "step" is one pass of the hot path (`read.into_local_profile(..).sw_score_from_i8(reference)`
 for every read, i.e. zsw_score_batch_from) over the rank's batch of synthetic reads, already resident in HBM,
 followed — for N > 1 — by the RCCL all-gather of the per-read scores and statuses (the only exchange the path
-has; one collective per step, zoe_amd/dist.py).  Workloads (BASELINE.json):
+has; one collective per step, zoe_amd/dist.py).  `value` is the library's default path: the seeded exact pass
+(zsw_score_seed.hip: k-mer anchors, the rows around them, bound checks, the full pass for the reads handed back —
+bit-identical to computing every cell, which the run verifies on ALL reads and reports beside it).
+Workloads (BASELINE.json):
   N = 1  configs[1]: 10 M reads on the GPU.
   N > 1  configs[3]: 500 M reads in total, sharded by contiguous index ranges [i*n/N, (i+1)*n/N) (62.5 M per GPU at
          N = 8); the counter-based generator lets every rank synthesise exactly its own shard on its own GPU.
@@ -33,11 +36,12 @@ sys.path.insert(0, ROOT)
 READ_LEN = 150
 REF_LEN = 2000
 ALGO_BYTES_PER_READ = READ_LEN + 4  # read bytes in + u32 score out
-# HBM bytes per read measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 fetch correction):
-# 1.500 GB read + 0.060 GB written per 10 M-read launch (status and tier bytes included). A CONSTANT from that profile,
-# not a measurement of this run (the bench line says so).
-PMC_HBM_BYTES_PER_READ = 159.4
-PMC_PROFILE = "profiles/r02_score_v2_summary.txt"  # 1.534 GB read + 0.060 GB written per 10 M-read launch (r01: 1.500 + 0.060)
+# seed_window_kernel<4,38,0> on the 10 M-read headline batch, from committed rocprofv3 --pmc passes (separate runs; FETCH_SIZE with
+# the gfx950 x2 correction for wide streaming reads is NOT applied to this kernel's scattered 150-byte read gathers: the raw
+# counter is reported). CONSTANTS from that profile, not measurements of this run (the bench line says so).
+PMC_PROFILE = "profiles/r03_seed_summary.txt"
+WINDOW_HBM_BYTES_PER_READ = 417.9  # FETCH_SIZE 323.6 + WRITE_SIZE 94.3 B per read (scattered 150-byte read gathers, 4-byte result scatters)
+WINDOW_VALU_PER_READ = 2047        # SQ_INSTS_VALU of the window kernel per read (2.047e10 per 10 M-read launch)
 VALU_PEAK_SOURCE = "profiles/r01_valu_issue_rates_ubench.txt"  # this repo's micro-benchmark (tools/ubench.hip), not a figure of the guide
 TOTAL_READS_MULTI_GPU = 500_000_000  # BASELINE.json configs[3]
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
@@ -59,7 +63,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=2048, help="reads checked against the oracle after the timed region")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short config-3 / config-5 measurements")
-    ap.add_argument("--no-pruned", action="store_true", help="skip the run of the headline workload with the opt-in column-pruned pass")
+    ap.add_argument("--no-full-pass", action="store_true", help="skip the run of the headline workload with every cell computed (and the comparison of all results)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on a one-GPU box together with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -177,17 +181,17 @@ def rooflines(algo_bytes: float, kernel_s: float, valu_instr: float = None, sour
     return out
 
 
-def pruned_headline(zoe_amd, ctx, profiles, reference, full, n_reads, steps):
-    """The headline workload again with the opt-in column-pruned pass (zsw_set_option(ZSW_OPTION_EXACT_PRUNING, 1),
-    zoe_amd/csrc/zsw_score_prune.hip): every score, status and tier must equal the full pass's (`full`), all n_reads of them.
-    Not part of `value`: `value` is the default path, which computes every cell."""
+def full_pass_headline(zoe_amd, ctx, profiles, reference, default, n_reads, steps):
+    """The headline workload again with every cell computed (zsw_set_option(ZSW_OPTION_EXACT_PRUNING, 0): score_kernel_v2 over
+    the whole batch, the path `value` measured in rounds 1-2). Every score, status and tier of the default path (`default`)
+    must equal it, all n_reads of them."""
     import torch
 
     from zoe_amd import _lib
 
-    ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
+    ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
     try:
-        got = profiles.sw_score_from_i8(reference)  # warm-up: workspace allocation
+        got = profiles.sw_score_from_i8(reference)
         torch.cuda.synchronize()
         ctx.timing_enable(True)
         t0 = time.perf_counter()
@@ -197,25 +201,19 @@ def pruned_headline(zoe_amd, ctx, profiles, reference, full, n_reads, steps):
         dt = time.perf_counter() - t0
         ks, launches = ctx.timing_read()
         ctx.timing_enable(False)
-        rescored = ctx.prune_rescored()
     finally:
-        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
-    same = bool(torch.equal(got.score, full.score) and torch.equal(got.status, full.status) and torch.equal(got.tier, full.tier))
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
+    same = bool(torch.equal(got.score, default.score) and torch.equal(got.status, default.status) and torch.equal(got.tier, default.tier))
     if not same:
-        raise SystemExit("PARITY FAILURE: the column-pruned pass differs from the full pass")
+        raise SystemExit("PARITY FAILURE: the default (seeded) pass differs from the full pass")
+    per_launch = ks / max(launches, 1)
+    cells = n_reads * READ_LEN * REF_LEN
     return {
         "reads_per_s": n_reads * steps / dt,
-        "ms_per_step": dt / steps * 1e3,
-        "kernels_ms_per_step": ks / max(launches, 1) * 1e3,
-        "identical_to_the_full_pass": f"all {n_reads} scores, statuses and tiers compared in this run",
-        "reads_rescored_over_all_cells": rescored,
-        "rescored_fraction": rescored / n_reads,
-        "how": "a 24-column strip over every reference row (prune_strip_kernel) + the other 126 columns in a window of rows around "
-               "the read's anchor (prune_window_kernel); three upper-bound checks per read decide whether any uncomputed cell could "
-               "matter; reads that fail are rescored by score_kernel_v2 over all their cells. Exact for every input; opt-in "
-               "(zsw_set_option(ctx, ZSW_OPTION_EXACT_PRUNING, 1)); see DESIGN.md 4.1d",
-        "work": "VALU wave-instructions issued / those of the full pass = 0.31 on this workload: strip 0.17, window 0.09, rescoring 0.05 ("
-                + file_tag("profiles/r02_prune_summary.txt") + ")",
+        "kernel": "zsw::score_kernel_v2<4,38,0>",
+        "kernel_ms": per_launch * 1e3,
+        "default_path_identical": f"all {n_reads} scores, statuses and tiers compared in this run",
+        "valu_roofline_frac": cells / per_launch / 2 * PACKED_OPS_PER_CELL_PAIR / VALU_LANE_OPS_PEAK if per_launch > 0 else None,
     }
 
 
@@ -246,15 +244,15 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
             del r
         return best
 
-    def with_pruning(fn):
-        """the same call with the opt-in column-pruned first pass (bit-identical)"""
+    def with_full_first_pass(fn):
+        """the same call with every cell of the first pass computed (ZSW_OPTION_EXACT_PRUNING 0): must be bit-identical"""
         from zoe_amd import _lib
 
-        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
         try:
             return timed(fn)
         finally:
-            ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
+            ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
 
     ctx.timing_enable(True)
     # configs[2]: 10 M reads, sw_simd_align with CIGAR, bit-exact vs the CPU path of the same <T, N>
@@ -267,11 +265,11 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     entry = {"reads_per_s_end_to_end_incl_d2h": n_full / dt, "pass2_kernel_ms": ks * 1e3, "pass2_kernel_ms_per_1M_reads": ks * 1e3 / (n_full / 1e6),
              "ciglets": n_cig, "aligned_reads": n_some,
              "call": "into_local_profile(..).sw_align_from_i8(SeqSrc::Reference(ref)) (CIGAR of the i16x16 / i8x32 tier), 10 M reads (BASELINE.json configs[2] at full size)",
-             "kernel": "zsw::align_kernel_pk<16,10> (+ <32,5> for the reads that answer at i8x32); pass 1 = score_kernel_v2<4,38,1>"}
+             "kernel": "zsw::align_kernel_pk<16,10> (+ <32,5> for the reads that answer at i8x32); pass 1 = the seeded exact pass (seed_window_kernel<4,38,1>)"}
     # algorithmic bytes: read in, record out (score, 4 coordinates, 2 lengths, count, offset = 40 B), 5 B per ciglet
     entry.update(rooflines(n_full * (READ_LEN + 4.0) + n_some * 40.0 + n_cig * 5.0, ks, ALIGN_PK_VALU_PER_READ * n_full, ALIGN_PK_PROFILE))
-    ap, dtp, ksp = with_pruning(lambda: prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref2k)))
-    entry["with_pruned_first_pass"] = {"reads_per_s_end_to_end_incl_d2h": n_full / dtp, "pass2_kernel_ms": ksp * 1e3,
+    ap, dtp, ksp = with_full_first_pass(lambda: prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref2k)))
+    entry["with_full_first_pass"] = {"reads_per_s_end_to_end_incl_d2h": n_full / dtp, "pass2_kernel_ms": ksp * 1e3,
                                        "identical": bool(np.array_equal(ap.status, a.status) and np.array_equal(ap.records, a.records)
                                                          and np.array_equal(ap.inc, a.inc) and np.array_equal(ap.op, a.op))}
     del ap
@@ -285,8 +283,8 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     entry = {"reads_per_s_end_to_end_incl_d2h": 1_000_000 / dt, "kernels_ms": ks * 1e3, "ciglets": int(len(a3.inc)),
              "call": "into_local_profile(..).sw_align_from_i8_3pass(SeqSrc::Reference(ref)) (three_pass.rs: ranges, then no-gaps / banded / scalar in the box)"}
     entry.update(rooflines(1e6 * (READ_LEN + 4.0) + float((a3.status == 0).sum()) * 40.0 + len(a3.inc) * 5.0, ks))
-    ap, dtp, ksp = with_pruning(lambda: prof.sw_align_from_i8_3pass(zoe_amd.SeqSrc.Reference(ref2k)))
-    entry["with_pruned_first_pass"] = {"reads_per_s_end_to_end_incl_d2h": 1_000_000 / dtp, "kernels_ms": ksp * 1e3,
+    ap, dtp, ksp = with_full_first_pass(lambda: prof.sw_align_from_i8_3pass(zoe_amd.SeqSrc.Reference(ref2k)))
+    entry["with_full_first_pass"] = {"reads_per_s_end_to_end_incl_d2h": 1_000_000 / dtp, "kernels_ms": ksp * 1e3,
                                        "identical": bool(np.array_equal(ap.status, a3.status) and np.array_equal(ap.records, a3.records)
                                                          and np.array_equal(ap.inc, a3.inc) and np.array_equal(ap.op, a3.op))}
     out["align_3pass_1M_x_150bp_vs_2kb"] = entry
@@ -296,8 +294,8 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     rg, dt, ks = timed(lambda: sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k)))
     entry = {"reads_per_s": 1_000_000 / dt, "kernels_ms": ks * 1e3, "call": "StripedProfile::<i16,16,5>::sw_score_ranges(SeqSrc::Reference(ref))"}
     entry.update(rooflines(1e6 * (READ_LEN + 4.0 + 16.0), max(ks, 1e-9) if ks > 0 else dt))
-    rp_, dtp, ksp = with_pruning(lambda: sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k)))
-    entry["with_pruned_first_pass"] = {"reads_per_s": 1_000_000 / dtp, "kernels_ms": ksp * 1e3,
+    rp_, dtp, ksp = with_full_first_pass(lambda: sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k)))
+    entry["with_full_first_pass"] = {"reads_per_s": 1_000_000 / dtp, "kernels_ms": ksp * 1e3,
                                        "identical": all(bool(torch.equal(getattr(rp_, f), getattr(rg, f)))
                                                         for f in ("score", "status", "ref_start", "ref_end", "query_start", "query_end"))}
     del rp_
@@ -319,56 +317,25 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     ctx.timing_enable(False)
     total_bases = float(rr.offsets[-1])
     cells = total_bases * 30000
-    entry = {"reads_per_s": 1_000_000 / dt, "gcups": cells / dt / 1e9, "kernel_ms": ks * 1e3,
-             "call": "sw_score_from_i8, reads bucketed by strip configuration on the device"}
-    entry.update(mixed_padding_report(rr, 30000))
+    entry = {"reads_per_s": 1_000_000 / dt, "kernel_ms": ks * 1e3,
+             "call": "sw_score_from_i8, reads bucketed by strip configuration on the device, seeded exact pass per length class"}
     entry.update(rooflines(total_bases + 1e6 * (8.0 + 4.0), dt))
-    lane_ops = cells / dt / 2 * PACKED_OPS_PER_CELL_PAIR
-    entry["valu_roofline"] = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": VALU_LANE_OPS_PEAK / 1e12,
-                              "unit": "T lane-ops/s of USEFUL cells (7.5 packed VALU per two cells; padding columns and rows not counted)",
-                              "frac": lane_ops / VALU_LANE_OPS_PEAK, "valu_peak_source": VALU_PEAK_SOURCE}
+    entry["gcups"] = "equivalent: the cells of the full matrices per second (the seeded pass computes about one in ninety of them)"
+    entry["gcups_equivalent"] = cells / dt / 1e9
+    del entry["gcups"]
     ctx.timing_enable(True)
-    full_mixed = pm.sw_score_from_i8(ref30k)
-    got, dtp, ksp = with_pruning(lambda: pm.sw_score_from_i8(ref30k))
+    seeded_mixed = pm.sw_score_from_i8(ref30k)
+    handed_back = ctx.prune_rescored()
+    got, dtp, ksp = with_full_first_pass(lambda: pm.sw_score_from_i8(ref30k))
     ctx.timing_enable(False)
-    entry["with_pruned_first_pass"] = {"reads_per_s": 1_000_000 / dtp, "tcups_equivalent": cells / dtp / 1e12, "kernels_ms": ksp * 1e3,
-                                       "identical": bool(torch.equal(got.score, full_mixed.score) and torch.equal(got.status, full_mixed.status)
-                                                         and torch.equal(got.tier, full_mixed.tier))}
+    lane_ops = cells / dtp / 2 * PACKED_OPS_PER_CELL_PAIR
+    entry["handed_back_fraction"] = handed_back / 1_000_000
+    entry["with_full_first_pass"] = {"reads_per_s": 1_000_000 / dtp, "gcups": cells / dtp / 1e9, "kernels_ms": ksp * 1e3,
+                                     "valu_roofline_frac_useful_cells": lane_ops / VALU_LANE_OPS_PEAK,
+                                     "identical": bool(torch.equal(got.score, seeded_mixed.score) and torch.equal(got.status, seeded_mixed.status)
+                                                       and torch.equal(got.tier, seeded_mixed.tier))}
     out["score_mixed_1M_x_75_400bp_vs_30kb"] = entry
     return out
-
-
-def mixed_padding_report(rr, ref_len: int):
-    """cells launched / cells needed per strip configuration of the ragged batch (zsw_score.hip: a read runs in the smallest
-    G x C columns that hold it, and a lane group walks ref_len + G - 1 rows because of the skew)."""
-    import numpy as np
-
-    lens = (rr.offsets[1:] - rr.offsets[:-1]).cpu().numpy().astype(np.int64)
-    # the length classes of a ragged batch, read from the kernel sources (zsw_score_v2.hpp: the strip configurations;
-    # zsw_score.hip: kBucketCfg, the ones a ragged batch is bucketed into)
-    import re
-
-    csrc = os.path.join(ROOT, "zoe_amd", "csrc")
-    with open(os.path.join(csrc, "zsw_score_v2.hpp")) as f:
-        cfgs = [(int(g), int(c)) for g, c in re.findall(r"X\((\d+), (\d+)\)", f.read().split("#define ZSW_FOR_EACH_STRIP_CONFIG(X)")[1].split("constexpr")[0])]
-    with open(os.path.join(csrc, "zsw_score.hip")) as f:
-        idx_list = [int(x) for x in re.search(r"kBucketCfg\[\] = \{([^}]*)\}", f.read()).group(1).split(",")]
-    classes = [cfgs[i] for i in idx_list]
-    caps = np.array(sorted(set(g * c for g, c in classes)))
-    per = {}
-    need_total = launched_total = 0
-    idx = np.searchsorted(caps, lens)
-    for k, cap in enumerate(caps):
-        sel = lens[idx == k]
-        if sel.size == 0:
-            continue
-        g = min(gg for gg, cc in classes if gg * cc == cap)
-        need = int(sel.sum()) * ref_len
-        launched = int(sel.size) * int(cap) * (ref_len + g - 1)
-        per[str(int(cap))] = {"reads": int(sel.size), "cells_launched_over_needed": launched / need}
-        need_total += need
-        launched_total += launched
-    return {"padding": {"cells_launched_over_needed": launched_total / max(need_total, 1), "per_columns_class": per}}
 
 
 def main():
@@ -468,7 +435,9 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kern_s, launches = ctx.timing_read()
+    win_s, win_launches = ctx.timing_read_window()
     ctx.timing_enable(False)
+    handed_back = ctx.prune_rescored()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if gather_on_host else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -502,10 +471,12 @@ def main():
     if rank == 0:
         total_reads = n_total * args.steps
         value = total_reads / dt
-        per_launch_s = kern_s / max(launches, 1)
-        achieved = ALGO_BYTES_PER_READ * n_local / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
-        cells_per_s_gpu = n_local * READ_LEN * REF_LEN / per_launch_s if per_launch_s > 0 else 0.0
-        lane_ops = cells_per_s_gpu / 2 * PACKED_OPS_PER_CELL_PAIR
+        pass_s = kern_s / max(launches, 1)             # the whole first pass: seed + sort + window + full pass over the handed-back reads
+        seeded = win_launches > 0
+        kern = win_s / win_launches if seeded else pass_s  # the dominant kernel alone
+        kernel_name = "zsw::seed_window_kernel<4,38,0>" if seeded else "zsw::score_kernel_v2<4,38,0>"
+        achieved = ALGO_BYTES_PER_READ * n_local / kern / 1e9 if kern > 0 else 0.0
+        traffic = WINDOW_HBM_BYTES_PER_READ * n_local if (seeded and WINDOW_HBM_BYTES_PER_READ) else None
         out = {
             "metric": "read-alignments/sec (150 bp vs 2 kb ref)",
             "value": value,
@@ -529,36 +500,40 @@ def main():
                                 f"{slab_bytes(shard_capacity(n_total, world))} B slab per rank (u32 scores + u8 statuses), issued under the next step's kernel"
                                 if world > 1 else "single GPU"),
             },
-            "gcups": value * READ_LEN * REF_LEN / 1e9,
+            "path": {
+                "default": "seeded exact pass (zsw_score_seed.hip): k-mer anchors -> rows around the anchor -> bound checks -> full pass for the reads handed back; "
+                           "bit-identical to computing every cell" if seeded else "full pass (every cell)",
+                "handed_back_fraction": handed_back / max(n_local, 1),
+                "first_pass_ms": pass_s * 1e3,
+                "gcups_equivalent": value * READ_LEN * REF_LEN / 1e9,
+            },
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": PMC_HBM_BYTES_PER_READ * n_local / per_launch_s / 1e9 if per_launch_s > 0 else None,
-                "traffic_bytes_per_launch": PMC_HBM_BYTES_PER_READ * n_local,
+                "traffic": traffic / kern / 1e9 if (traffic and kern > 0) else None,
+                "traffic_bytes_per_launch": traffic,
                 "traffic_measured_in_this_run": False,
-                "traffic_source": "constant 159.4 B/read from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of the same kernel and workload: " + file_tag(PMC_PROFILE),
-                "kernel": "zsw::score_kernel_v2<4,38,0>",
-                "kernel_ms": per_launch_s * 1e3,
+                "traffic_source": ("constant from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of the same kernel and workload: " + file_tag(PMC_PROFILE))
+                                  if traffic else None,
+                "kernel": kernel_name,
+                "kernel_ms": kern * 1e3,
                 "kernel_ms_source": "HIP events recorded around the kernel on its stream, inside this run",
                 "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
-                "note": "HBM is not the binding roof: 7.5 packed VALU ops per 2 cells at 4 cycles each, see valu_roofline",
-            },
-            "valu_roofline": {
-                "bound": "valu",
-                "achieved": lane_ops / 1e12,
-                "peak": VALU_LANE_OPS_PEAK / 1e12,
-                "unit": "T lane-ops/s (32-bit lanes of packed-i16 VALU; each lane-op advances 2 cells)",
-                "frac": lane_ops / VALU_LANE_OPS_PEAK,
-                "valu_peak_source": "one wave64 packed/perm/max3 instruction per 4 cycles per SIMD, measured by this repo's micro-benchmark: "
-                                    + file_tag(VALU_PEAK_SOURCE) + " (MI355X_MICROARCH.md lists only v_fma_f32)",
+                "note": "HBM is not the binding roof: packed-i16 VALU issue is (valu_roofline); the seeded pass raises the rate by computing fewer cells",
             },
             "parity_checked_reads": args.verify if verified else 0,
         }
-        if world == 1 and not args.no_pruned:
-            out["exact_pruning"] = pruned_headline(zoe_amd, ctx, profiles, reference, last, n_local, args.steps)
+        if seeded and WINDOW_VALU_PER_READ:
+            instr = WINDOW_VALU_PER_READ * n_local
+            out["valu_roofline"] = {"bound": "valu", "achieved": instr / kern / 1e9, "peak": WAVE_INSTR_PEAK / 1e9,
+                                    "unit": "G wave64 VALU instructions/s", "frac": instr / kern / WAVE_INSTR_PEAK, "kernel": kernel_name,
+                                    "instruction_count_source": file_tag(PMC_PROFILE), "instruction_count_measured_in_this_run": False,
+                                    "valu_peak_source": "one wave64 packed/perm/max3 instruction per 4 cycles per SIMD: " + file_tag(VALU_PEAK_SOURCE)}
+        if world == 1 and not args.no_full_pass:
+            out["full_pass_every_cell"] = full_pass_headline(zoe_amd, ctx, profiles, reference, last, n_local, args.steps)
         if not args.no_secondary and world == 1:
             del reads, profiles, last
             torch.cuda.empty_cache()

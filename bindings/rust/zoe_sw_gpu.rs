@@ -126,6 +126,7 @@ unsafe extern "C" {
     fn zsw_synth_reads_ragged_host(seed: u64, first: u64, n: u64, min_len: u32, max_len: u32, offsets: *const u64, reference: *const u8, r: u32, out: *mut u8);
     fn zsw_timing_enable(ctx: *mut ZswContext, enable: i32) -> i32;
     fn zsw_timing_read(ctx: *mut ZswContext, seconds: *mut f64, launches: *mut u64) -> i32;
+    fn zsw_timing_read_window(ctx: *mut ZswContext, seconds: *mut f64, launches: *mut u64) -> i32;
     fn zsw_debug_set(ctx: *mut ZswContext, flags: u32) -> i32;
     fn zsw_prune_rescored(ctx: *mut ZswContext, out_reads: *mut u64) -> i32;
     fn zsw_set_option(ctx: *mut ZswContext, option: i32, value: i64) -> i32;
@@ -555,6 +556,14 @@ impl GpuContext {
         // SAFETY: valid out-pointers
         self.check(unsafe { zsw_timing_read(self.raw, &mut seconds, &mut launches) }, 0, 0)?;
         self.check(unsafe { zsw_timing_enable(self.raw, i32::from(enable)) }, 0, 0)?;
+        Ok((seconds, launches))
+    }
+
+    /// Time of the seeded pass's window kernel alone since the last read (`zsw_timing_read_window`).
+    pub fn timing_window(&self) -> Result<(f64, u64), GpuError> {
+        let (mut seconds, mut launches) = (0f64, 0u64);
+        // SAFETY: valid out-pointers
+        self.check(unsafe { zsw_timing_read_window(self.raw, &mut seconds, &mut launches) }, 0, 0)?;
         Ok((seconds, launches))
     }
 

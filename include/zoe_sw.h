@@ -248,11 +248,15 @@ void zsw_synth_reads_host(uint64_t seed, uint64_t first, uint64_t n, uint32_t le
 void zsw_synth_reads_ragged_host(uint64_t seed, uint64_t first, uint64_t n, uint32_t min_len, uint32_t max_len,
                                  const uint64_t* offsets, const uint8_t* ref, uint32_t R, uint8_t* out);
 
-/* HIP-event timing of the dominant kernel of each *_batch call, recorded on the call's stream.
+/* HIP-event timing of the kernels of each *_batch call (its whole first pass for score calls), recorded on the call's stream.
  * zsw_timing_read synchronises on the recorded events, returns the summed kernel seconds and the
  * number of launches since the last read, and resets. For bench.py's roofline line. */
 zsw_error zsw_timing_enable(zsw_context* ctx, int enable);
 zsw_error zsw_timing_read(zsw_context* ctx, double* seconds, uint64_t* launches);
+/* The same for the one kernel that dominates a score call on the default path: seed_window_kernel of the seeded exact pass
+ * (events around that launch alone, on its stream; a ragged batch has one launch per length class). 0 launches if the calls
+ * since the last read took another path. For bench.py's roofline of that kernel. */
+zsw_error zsw_timing_read_window(zsw_context* ctx, double* seconds, uint64_t* launches);
 
 /* Options of a context. ZSW_OPTION_EXACT_PRUNING (value 0 / 1, default 1): the seeded exact first pass (zsw_score_seed.hip;
  * DESIGN.md 4.1e). sw_simd_score returns only the maximum of the DP matrix (striped.rs:65-142), so every entry point that starts

@@ -261,9 +261,17 @@ def test_config3_large_batch_properties(za, oracle, debug):
     rb = synth.reads_device(ctx, ref, 1_000_000, n, 150)
     dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
     a = za.into_local_profile(rb, dna, -10, -1).sw_align_from_i8(za.SeqSrc.Reference(ref))
+    assert 0 < ctx.prune_rescored() < n // 20  # pass 1 took the default path: the seeded exact pass with the end row (r03)
     rec, st = a.records, a.status
     some = st == S_
-    ends = za.StripedProfileBatch(rb, dna, -10, -1, "i16", 16).sw_score_ends(za.SeqSrc.Reference(ref))
+    from zoe_amd import _lib
+
+    ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)  # score + ends from the full pass, every cell of every read
+    try:
+        ends = za.StripedProfileBatch(rb, dna, -10, -1, "i16", 16).sw_score_ends(za.SeqSrc.Reference(ref))
+        assert ctx.prune_rescored() == 0
+    finally:
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
     assert np.array_equal(st, ends.status.cpu().numpy())
     assert np.array_equal(rec["score"][some], ends.score.cpu().numpy()[some].view(np.uint32))
     assert np.array_equal(rec["ref_end"][some], ends.ref_end.cpu().numpy()[some].view(np.uint32))

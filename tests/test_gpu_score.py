@@ -328,13 +328,15 @@ def test_config5_full_size_1m_mixed_reads_properties(za, oracle, dna, debug):
     prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
     debug.set(0)
     a = prof.sw_score_from_i8(ref)
+    assert 0 < ctx.prune_rescored() < n // 20  # the default path: the seeded exact pass, per length class (r03)
     s2, st2, t2 = a.score.clone(), a.status.clone(), a.tier.clone()
     b = prof.sw_score_from_i8(ref)
     assert torch.equal(b.score, s2) and torch.equal(b.status, st2)
     debug.set(debug.SCORE_V1)
     c = prof.sw_score_from_i8(ref)
+    assert ctx.prune_rescored() == 0  # v1: every cell of every read
     debug.set(0)
-    assert torch.equal(c.score, s2) and torch.equal(c.status, st2) and torch.equal(c.tier, t2)  # v1 == v2 on all reads
+    assert torch.equal(c.score, s2) and torch.equal(c.status, st2) and torch.equal(c.tier, t2)  # v1 == default on all reads
     assert int(s2.min()) >= 0 and bool((s2.to(torch.int64) <= 2 * lens).all())
     assert torch.equal(st2 == 0, s2 > 0) and torch.equal(t2[st2 == 0] == 8, s2[st2 == 0] < 255)
     sc = osc(oracle, dna, -10, -1)
@@ -480,13 +482,25 @@ def test_full_size_10m_reads_properties(za, oracle, dna, debug):
     prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
     debug.set(0)
     a = prof.sw_score_from_i8(ref)
+    assert 0 < ctx.prune_rescored() < n // 20  # the default path: the seeded exact pass (r03)
     s2, st2, t2 = a.score.clone(), a.status.clone(), a.tier.clone()
     b = prof.sw_score_from_i8(ref)
     assert torch.equal(b.score, s2) and torch.equal(b.status, st2)  # deterministic
     debug.set(debug.SCORE_V1)
     c = prof.sw_score_from_i8(ref)
-    assert torch.equal(c.score, s2) and torch.equal(c.status, st2) and torch.equal(c.tier, t2)  # v1 == v2 on all 10 M reads
+    assert ctx.prune_rescored() == 0  # v1: every cell of every read
+    assert torch.equal(c.score, s2) and torch.equal(c.status, st2) and torch.equal(c.tier, t2)  # v1 == default on all 10 M reads
     debug.set(0)
+    from zoe_amd import _lib
+
+    ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)  # and the v2 full pass
+    try:
+        f = prof.sw_score_from_i8(ref)
+        assert ctx.prune_rescored() == 0
+    finally:
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
+    assert torch.equal(f.score, s2) and torch.equal(f.status, st2) and torch.equal(f.tier, t2)
+    del f
     # bounds: 0 <= score <= 2 * L; status Some <=> score > 0; tier 8 <=> score < 255
     assert int(s2.max()) <= 300 and int(s2.min()) >= 0
     assert torch.equal(st2 == 0, s2 > 0) and torch.equal(t2 == 8, s2 < 255)

@@ -1,0 +1,173 @@
+"""GPU tests of the seeded exact pass as the DEFAULT path (zsw_score_seed.hip): what switches it on and off, what it costs
+when it cannot help, and the inputs its index has to get right. (Parity on adversarial read sets, both pruned passes:
+tests/test_gpu_prune.py; the arithmetic against the full Gotoh matrix, no GPU: tests/test_align_models.py.)"""
+import time
+
+import numpy as np
+import pytest
+
+from conftest import stable_seed
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def za():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests need an MI355X")
+    import zoe_amd
+
+    return zoe_amd
+
+
+def _batch(za, reads2d):
+    import torch
+
+    n, L = reads2d.shape
+    return za.ReadBatch.from_fixed(torch.from_numpy(np.ascontiguousarray(reads2d).reshape(-1)).cuda(), L)
+
+
+def _oracle_check(za, oracle, reads2d, matrix, go, ge, ref):
+    sc = oracle.Scoring(matrix.signed_weights(), matrix.mapping.index_map, go, ge)
+    ws, wst, wt = oracle.batch_score_w256(8, sc, reads2d, ref, fixed_len=reads2d.shape[1], threads=8)
+    got = za.LocalProfilesBatch.new_with_w256(_batch(za, reads2d), matrix, go, ge).sw_score_from_i8(ref)
+    assert np.array_equal(got.status.cpu().numpy(), wst)
+    assert np.array_equal(got.score.cpu().numpy().view(np.uint32), ws)
+    assert np.array_equal(got.tier.cpu().numpy(), wt)
+    return za.SwContext.get(0).prune_rescored()
+
+
+def test_unrelated_reads_cost_the_full_pass_and_nothing_more(za):
+    """The bail-out: reads without an anchor go straight from the seed kernel to the full pass. 2 M random reads must cost at
+    most 1.05 x the full pass (plus 1 ms), with identical results."""
+    import torch
+
+    from zoe_amd import _lib, synth
+
+    ctx = za.SwContext.get(0)
+    n, L = 2_000_000, 150
+    ref = synth.reference_host(2000)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    bases = torch.randint(0, 4, (n * L,), device="cuda", generator=g, dtype=torch.int32)
+    bases = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")[bases.long()]
+    prof = za.LocalProfilesBatch.new_with_w256(za.ReadBatch.from_fixed(bases, L), za.WeightMatrix.new_dna_matrix(2, -5, b"N"), -10, -1)
+
+    def timed(reps=3):
+        prof.sw_score_from_i8(ref)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = prof.sw_score_from_i8(ref)
+        torch.cuda.synchronize()
+        return r, (time.perf_counter() - t0) / reps
+
+    seeded, t_seeded = timed()
+    handed_back = ctx.prune_rescored()
+    ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
+    try:
+        full, t_full = timed()
+    finally:
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
+    assert torch.equal(seeded.score, full.score) and torch.equal(seeded.status, full.status) and torch.equal(seeded.tier, full.tier)
+    assert handed_back > 0.95 * n  # random 150-mers: a chance pair of agreeing 8-mers is rare
+    assert t_seeded <= 1.05 * t_full + 1e-3, (t_seeded, t_full)
+
+
+def test_the_index_follows_the_reference_and_the_matrix(za, oracle):
+    """zsw_set_reference / zsw_set_scoring invalidate the k-mer index: the same reads against reference A, B, A again, then A
+    under another matrix (other good residues, other lambda), always equal to the oracle and mostly seeded."""
+    from zoe_amd import synth
+
+    ref_a = synth.reference_host(2000)
+    ref_b = bytes(reversed(synth.reference_host(3100)))
+    reads = np.concatenate([synth.reads_host(ref_a, 0, 1500, 150), synth.reads_host(ref_b, 7, 1500, 150)])
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    other = za.WeightMatrix.new_dna_matrix(3, -4, None)
+    for ref, m, go, ge in ((ref_a, dna, -10, -1), (ref_b, dna, -10, -1), (ref_a, dna, -10, -1), (ref_a, other, -6, -2), (ref_b, other, -6, -2)):
+        back = _oracle_check(za, oracle, reads, m, go, ge, ref)
+        assert 1400 < back < 1700  # the half sampled from the other reference has no anchor
+
+
+@pytest.mark.parametrize("kind", ["n_singles", "n_runs", "lower_case", "iupac_bytes"])
+def test_references_with_bytes_that_are_not_good_residues(za, oracle, kind):
+    """N (and any byte the map sends to the catch-all) in the reference: windows with up to three of them are indexed under
+    every spelling, longer runs cost a path more than a k-mer is worth; reads with N sample fewer usable k-mers."""
+    from zoe_amd import synth
+
+    rng = np.random.default_rng(stable_seed("seedref", kind))
+    ref = bytearray(synth.reference_host(2500))
+    if kind == "n_singles":
+        for p in rng.choice(len(ref), 120, replace=False):
+            ref[p] = ord("N")
+    elif kind == "n_runs":
+        for p in rng.choice(len(ref) - 40, 12, replace=False):
+            ref[p : p + int(rng.integers(2, 30))] = b"N" * 40
+        ref = ref[:2500]
+    elif kind == "lower_case":
+        ref = bytearray(bytes(ref).lower())
+    else:
+        for p in rng.choice(len(ref), 200, replace=False):
+            ref[p] = int(rng.choice(list(b"RYKMSWBDHVU-")))
+    ref = bytes(ref)
+    reads = synth.reads_host(ref, 3, 3000, 150)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    back = _oracle_check(za, oracle, reads, dna, -10, -1, ref)
+    assert back < 3000
+    # and with N scored like a mismatch (no ignored residue): N is then an ordinary non-good residue with its own loss
+    plain = za.WeightMatrix.new_dna_matrix(2, -3, None)
+    _oracle_check(za, oracle, reads, plain, -5, -1, ref)
+
+
+@pytest.mark.parametrize("R", [1, 7, 8, 9, 23, 60, 149, 150, 151])
+def test_references_shorter_than_a_kmer_a_read_or_the_window(za, oracle, R):
+    from zoe_amd import synth
+
+    big = synth.reference_host(4000)
+    ref = big[1000 : 1000 + R]
+    reads = synth.reads_host(big, 2, 1200, 150)
+    reads[:600] = synth.reads_host(big[900:1300], 4, 600, 150)  # overlap the short reference
+    _oracle_check(za, oracle, reads, za.WeightMatrix.new_dna_matrix(2, -5, b"N"), -10, -1, ref)
+
+
+def test_batches_below_the_size_threshold_take_the_full_pass(za, oracle):
+    from zoe_amd import synth
+
+    ctx = za.SwContext.get(0)
+    ref = synth.reference_host(2000)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    assert _oracle_check(za, oracle, synth.reads_host(ref, 0, 1023, 150), dna, -10, -1, ref) == 0
+    assert 0 < _oracle_check(za, oracle, synth.reads_host(ref, 0, 1024, 150), dna, -10, -1, ref) < 200
+
+
+def test_matrices_the_index_cannot_spell_take_the_full_pass(za, oracle):
+    """More than four residues that score the maximum against themselves (a 5-letter identity matrix), a mismatch that scores
+    the maximum, free gaps: seed_analyze declines, every cell is computed, the results are the oracle's."""
+    from zoe_amd import synth
+
+    ctx = za.SwContext.get(0)
+    ref = synth.reference_host(2000)
+    reads = synth.reads_host(ref, 0, 2000, 150)
+    m5 = za.WeightMatrix.new_dna_matrix(2, -5, None)  # N scores +2 against N: five good residues
+    assert _oracle_check(za, oracle, reads, m5, -10, -1, ref) == 0
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    assert _oracle_check(za, oracle, reads, dna, 0, 0, ref) == 0  # free gaps
+    w = np.array(dna.signed_weights(), dtype=np.int8).reshape(5, 5).copy()
+    w[0, 1] = w[1, 0] = 2  # A and C are interchangeable: a mismatch at the maximum
+    same = za.WeightMatrix.new_custom(dna.mapping, w)
+    assert _oracle_check(za, oracle, reads, same, -10, -1, ref) == 0
+
+
+def test_long_reads_take_the_wide_window_configurations(za, oracle):
+    """Reads of 500-2,400 bases vs a 30 kb reference: 16 x 38 and 64-lane window configurations (a window of len + ~100 rows of
+    the 30,000)."""
+    from zoe_amd import synth
+
+    ref = synth.reference_host(30000)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    for L in (500, 608, 1216, 2400):
+        reads = synth.reads_host(ref, L, 1100, L)
+        back = _oracle_check(za, oracle, reads, dna, -10, -1, ref)
+        assert back < 600, (L, back)

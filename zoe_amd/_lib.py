@@ -35,7 +35,7 @@ SYMBOLS = [
     "zsw_create", "zsw_destroy", "zsw_last_error_string", "zsw_device_count", "zsw_set_scoring", "zsw_set_reference",
     "zsw_score_batch", "zsw_score_batch_from", "zsw_score_ends_batch", "zsw_score_ranges_batch", "zsw_score_ranges_batch_from", "zsw_align_batch", "zsw_align_batch_from", "zsw_align_3pass_batch", "zsw_align_3pass_batch_from", "zsw_sneaky_snake_batch",
     "zsw_synth_reads", "zsw_synth_reads_ragged", "zsw_synth_length", "zsw_synth_reference_host", "zsw_synth_reads_host",
-    "zsw_synth_reads_ragged_host", "zsw_selftest", "zsw_timing_enable", "zsw_timing_read", "zsw_debug_set", "zsw_prune_rescored", "zsw_set_option",
+    "zsw_synth_reads_ragged_host", "zsw_selftest", "zsw_timing_enable", "zsw_timing_read", "zsw_timing_read_window", "zsw_debug_set", "zsw_prune_rescored", "zsw_set_option",
     "zsw_group_create", "zsw_group_destroy", "zsw_group_size", "zsw_group_context", "zsw_group_last_error_string", "zsw_group_set_scoring",
     "zsw_group_set_reference", "zsw_group_score_batch_from", "zsw_group_score_batch_from_device", "zsw_group_align_batch_from",
     "zsw_group_align_3pass_batch_from",
@@ -120,6 +120,7 @@ def load() -> C.CDLL:
     lib.zsw_selftest.argtypes = [vp]
     lib.zsw_timing_enable.argtypes = [vp, C.c_int]
     lib.zsw_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    lib.zsw_timing_read_window.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.zsw_debug_set.argtypes = [vp, C.c_uint32]
     lib.zsw_prune_rescored.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.zsw_set_option.argtypes = [vp, C.c_int, C.c_int64]

@@ -255,11 +255,11 @@ class SwContext:
         self.check(self.lib.zsw_debug_set(self.h, int(flags)))
 
     def set_option(self, option: int, value: int):
-        """zsw_set_option, e.g. set_option(_lib.OPTION_EXACT_PRUNING, 1): the exact column-pruned first pass (same results)."""
+        """zsw_set_option, e.g. set_option(_lib.OPTION_EXACT_PRUNING, 0): every cell of every read instead of the seeded exact pass."""
         self.check(self.lib.zsw_set_option(self.h, int(option), int(value)), profile_errors=False)
 
     def prune_rescored(self) -> int:
-        """zsw_prune_rescored: reads of the last column-pruned score call that were rescored over all their cells."""
+        """zsw_prune_rescored: reads the last score call's seeded (or column-pruned) pass handed back to the full pass."""
         v = C.c_uint64(0)
         self.check(self.lib.zsw_prune_rescored(self.h, C.byref(v)))
         return int(v.value)
@@ -270,6 +270,12 @@ class SwContext:
     def timing_read(self):
         s, n = C.c_double(0), C.c_uint64(0)
         self.check(self.lib.zsw_timing_read(self.h, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
+    def timing_read_window(self):
+        """zsw_timing_read_window: seconds and launches of the seeded pass's window kernel since the last read."""
+        s, n = C.c_double(0), C.c_uint64(0)
+        self.check(self.lib.zsw_timing_read_window(self.h, C.byref(s), C.byref(n)))
         return s.value, n.value
 
 

@@ -67,6 +67,7 @@ struct zsw_context {
     // score_ranges workspace
     DevBuf r_ws[20];
     KernelTimer timer;
+    KernelTimer timer_window;  // seed_window_kernel launches alone
     std::string err;
     uint32_t debug = 0;    // zsw_debug_set (kernel-selection overrides for tests)
     uint32_t options = ZSW_DEBUG_SCORE_PRUNE;  // zsw_set_option, as ZSW_DEBUG_* bits; exact pruning is on by default
@@ -354,6 +355,7 @@ ScoreWorkspace score_ws(zsw_context* ctx) {
         w.seed_work = ctx->d_seed_work.as<uint8_t>();
         w.seed_bytes = ctx->d_seed_work.cap;
         w.seed_gtab = ctx->d_seed_gtab.as<uint2>();
+        w.window_timer = &ctx->timer_window;
         w.prune_fail_list = ctx->d_prune_list.as<uint32_t>();
         w.prune_fail_count = ctx->d_prune_count.as<uint32_t>();
     }
@@ -1014,6 +1016,7 @@ void zsw_destroy(zsw_context* ctx) {
     for (DevBuf& b : ctx->r_ws) b.release();
     seed_index_release(&ctx->seed);
     ctx->timer.destroy();
+    ctx->timer_window.destroy();
     if (ctx->side) {
         (void)hipEventDestroy(ctx->side->fork);
         for (int i = 0; i < SideStreams::N; ++i) {
@@ -1308,8 +1311,16 @@ zsw_error zsw_prune_rescored(zsw_context* ctx, uint64_t* out_reads) {
 
 zsw_error zsw_timing_enable(zsw_context* ctx, int enable) {
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
-    ctx->timer.enabled = enable != 0;
-    ctx->timer.used = 0;
+    ctx->timer.enabled = ctx->timer_window.enabled = enable != 0;
+    ctx->timer.used = ctx->timer_window.used = 0;
+    return ZSW_OK;
+}
+
+zsw_error zsw_timing_read_window(zsw_context* ctx, double* seconds, uint64_t* launches) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx || !seconds || !launches) return ZSW_ERR_INVALID_ARGUMENT;
+    ZSW_HIP(ctx, hipSetDevice(ctx->device));
+    ZSW_HIP(ctx, ctx->timer_window.collect(seconds, launches));
     return ZSW_OK;
 }
 

@@ -544,7 +544,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         if (pe != hipSuccess) return pe;
         ap.b = bb;
         pe = launch_score_seeded(ap, g, c, *ws.seed, ws.seed_work + work_off, seed_workspace_bytes(bb.n_items), ws.seed_gtab,
-                                 ws.prune_fail_list + list_off, counter, mode, stream);
+                                 ws.prune_fail_list + list_off, counter, mode, stream, ws.window_timer);
         if (pe != hipSuccess) return pe;
         ap.b.items = ws.prune_fail_list + list_off;
         ap.n_items_dev = counter;

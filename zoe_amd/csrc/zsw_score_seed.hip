@@ -14,6 +14,7 @@
 
 #include "zsw_score_seed.hpp"
 #include "zsw_score_v2.hpp"
+#include "zsw_timer.hpp"
 
 namespace zsw {
 
@@ -110,7 +111,7 @@ bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, ui
 }
 
 hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIndex& ix, uint8_t* work, size_t work_bytes, uint2* gtab,
-                               uint32_t* fail_list, uint32_t* fail_count, int mode, hipStream_t stream) {
+                               uint32_t* fail_list, uint32_t* fail_count, int mode, hipStream_t stream, KernelTimer* window_timer) {
     const uint32_t n = a2.b.n_items;
     if (n == 0) return hipSuccess;
     if (!work || !gtab || work_bytes < seed_workspace_bytes(n)) return hipErrorNotSupported;
@@ -175,9 +176,10 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIn
     w.fail_key = fail_key;
     w.fail_list = fail_list;
     w.fail_count = fail_count;
-    if (mode == 0) return launch_seed_window_m0(w, G, C, stream);
-    if (mode == 1) return launch_seed_window_m1(w, G, C, stream);
-    return launch_seed_window_m2(w, G, C, stream);
+    if (window_timer) window_timer->begin(stream);
+    e = mode == 0 ? launch_seed_window_m0(w, G, C, stream) : mode == 1 ? launch_seed_window_m1(w, G, C, stream) : launch_seed_window_m2(w, G, C, stream);
+    if (window_timer) window_timer->end(stream);
+    return e;
 }
 
 hipError_t seed_build_gtab(const ScoreArgsV2& a2, uint2* gtab, hipStream_t stream) {

@@ -59,7 +59,7 @@ bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, ui
 // gtab: (ref_len + 2 * SEED_GTAB_PAD) uint2, filled by seed_build_gtab (once per call of launch_score, from a2's tables).
 hipError_t seed_build_gtab(const ScoreArgsV2& a2, uint2* gtab, hipStream_t stream);
 hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIndex& ix, uint8_t* work, size_t work_bytes, uint2* gtab,
-                               uint32_t* fail_list, uint32_t* fail_count, int mode, hipStream_t stream);
+                               uint32_t* fail_list, uint32_t* fail_count, int mode, hipStream_t stream, KernelTimer* window_timer);
 // (Re)builds the index for a reference given as residue indices on the host.
 hipError_t seed_index_update(SeedIndex* ix, const ScoringDev& sc, const uint8_t* h_ref, size_t ref_len);
 void seed_index_release(SeedIndex* ix);
