@@ -287,7 +287,10 @@ typedef enum zsw_debug_flag {
      * strip of query columns against every reference row, the other columns in a window of rows around the strip's best row,
      * bound checks, the full pass for the reads that fail one. Reads of 65..400 bases, batches of 98,304 reads or more (or
      * ANY_SIZE), up to 32 GiB of workspace. Kept as a cross-check of the seeded pass. */
-    ZSW_DEBUG_PRUNE_STRIP = 512
+    ZSW_DEBUG_PRUNE_STRIP = 512,
+    /* align: the second pass starts warmup_rows before the first kept row for every read (round 2), not at the row the seeded
+     * first pass certifies (zsw_seed.hpp: seed_safe_start) */
+    ZSW_DEBUG_ALIGN_LONG_WARMUP = 1024
 } zsw_debug_flag;
 zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags);
 

@@ -62,3 +62,14 @@ def test_seeded_pass_bounds_model(tmp_path, seed):
     out = subprocess.run([_build(tmp_path, "seed_bounds"), "400", str(seed)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "seed_bounds OK" in out.stdout
+
+
+@pytest.mark.parametrize("seed", [20261004, 23])
+def test_late_start_certificate_model(tmp_path, seed):
+    """The certificate that lets the alignment's second pass start a few rows above the alignment instead of warmup_rows above
+    it (zsw_seed.hpp: seed_safe_start): Zoe's own striped alignment (the oracle's sw_simd_align at <i16, 4 / 8 / 16>) of a read
+    against reference[r0..] equals its alignment against the whole reference, shifted by r0 — score, ranges and CIGAR — for every
+    read that gets a certificate; seven scoring schemes, repeats, tandem repeats, N, junk prefixes, long deletions."""
+    out = subprocess.run([_build(tmp_path, "seed_warmup"), "400", str(seed)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "seed_warmup OK" in out.stdout

@@ -605,8 +605,10 @@ hipError_t align_pass2(int N, uint32_t nv, const BatchDev& b, const uint8_t* d_r
                        int S, const uint32_t* d_score, const uint32_t* d_ref_end, const uint8_t* d_status, uint32_t W,
                        uint32_t maxc, uint8_t* d_ring, uint32_t grid, uint32_t* d_cig, uint64_t pool_base, int by_item,
                        uint64_t* d_cig_start, uint32_t* d_cig_raw, zsw_alignment* d_aln, uint32_t* d_fb_list,
-                       uint32_t* d_fb_count, int invert, hipStream_t stream) {
+                       uint32_t* d_fb_count, int invert, hipStream_t stream, const uint32_t* d_safe_row) {
+    (void)d_safe_row;  // the 32-bit kernels keep the warm-up bound (they serve the reruns and the odd groups)
     AlignArgs a;
+    a.safe_row = nullptr;
     a.b = b;
     a.ref = d_ref;
     a.ref_len = ref_len;
@@ -681,8 +683,9 @@ hipError_t align_pass2_pk(int N, uint32_t nv, const BatchDev& b, const uint8_t* 
                           int S, const uint32_t* d_score, const uint32_t* d_ref_end, const uint8_t* d_status, uint32_t W,
                           uint32_t maxc, uint8_t* d_ring, uint32_t grid, uint32_t* d_cig, uint64_t pool_base, int by_item,
                           uint64_t* d_cig_start, uint32_t* d_cig_raw, zsw_alignment* d_aln, uint32_t* d_fb_list,
-                          uint32_t* d_fb_count, int invert, hipStream_t stream) {
+                          uint32_t* d_fb_count, int invert, hipStream_t stream, const uint32_t* d_safe_row) {
     AlignArgs a;
+    a.safe_row = d_safe_row;
     a.b = b;
     a.ref = d_ref;
     a.ref_len = ref_len;

@@ -9,7 +9,7 @@ hipError_t align_pass2(int N, uint32_t nv, const BatchDev& b, const uint8_t* d_r
                        int S, const uint32_t* d_score, const uint32_t* d_ref_end, const uint8_t* d_status, uint32_t W,
                        uint32_t maxc, uint8_t* d_ring, uint32_t grid, uint32_t* d_cig, uint64_t pool_base, int by_item,
                        uint64_t* d_cig_start, uint32_t* d_cig_raw, zsw_alignment* d_aln, uint32_t* d_fb_list,
-                       uint32_t* d_fb_count, int invert, hipStream_t stream);
+                       uint32_t* d_fb_count, int invert, hipStream_t stream, const uint32_t* d_safe_row = nullptr);
 size_t align_ring_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid);
 size_t align_lds_need(uint32_t nv, int S);
 // count_only: per-block sums + total of n_ciglets; otherwise the packed write (and range inversion).
@@ -27,12 +27,12 @@ hipError_t align_pass2_pk(int N, uint32_t nv, const BatchDev& b, const uint8_t* 
                           int S, const uint32_t* d_score, const uint32_t* d_ref_end, const uint8_t* d_status, uint32_t W,
                           uint32_t maxc, uint8_t* d_ring, uint32_t grid, uint32_t* d_cig, uint64_t pool_base, int by_item,
                           uint64_t* d_cig_start, uint32_t* d_cig_raw, zsw_alignment* d_aln, uint32_t* d_fb_list,
-                          uint32_t* d_fb_count, int invert, hipStream_t stream);
+                          uint32_t* d_fb_count, int invert, hipStream_t stream, const uint32_t* d_safe_row = nullptr);
 
 // Device-side grouping (zsw_group.hip): read ids sorted by (N, packed/wide, nv, ref_end) + the table of group starts.
 size_t group_temp_bytes(uint32_t n);
 hipError_t group_reads(const BatchDev& b, const uint8_t* d_status, const uint8_t* d_tier, const uint32_t* d_ref_end, const uint32_t* d_score,
-                       int lanes_w8, int lanes_w16, int lanes_w32, uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* items_out,
+                       const uint32_t* d_safe_row /* may be null */, int lanes_w8, int lanes_w16, int lanes_w32, uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* items_out,
                        void* temp, size_t temp_bytes, uint32_t* table, uint32_t* table_count, uint32_t cap, hipStream_t stream);
 
 // Third pass of sw_align_3pass (zsw_threepass.hip). list == null: classify pass over all reads (resolves the no-gaps

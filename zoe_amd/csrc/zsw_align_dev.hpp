@@ -29,6 +29,9 @@ struct AlignArgs {
     int invert;
     uint8_t* rows;  // GLOBAL_ROWS kernels: per-block H/E/profile/flag rows in HBM (null otherwise)
     uint32_t* next_item;  // packed kernel: work counter (zeroed before the launch); a wavefront takes its next reads from it
+    // optional, per read: the row from which the recompute may start with a zero state (seed_safe_start, zsw_seed.hpp: the
+    // first pass's k-mer certificate), 0xffffffff = none: the warm-up bound below applies
+    const uint32_t* safe_row;
 };
 
 // Late start of pass 2. The state after row r (the H and E rows) is a (max,+) function of earlier rows in which every

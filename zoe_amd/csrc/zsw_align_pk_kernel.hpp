@@ -124,6 +124,7 @@ __global__ __launch_bounds__(64, NV <= 10 ? 3 : 1) void align_kernel_pk(AlignArg
         uint32_t id[2], len[2], item[2];
         uint64_t off[2];
         int rend[2], keep0[2], wrows[2];  // last row, first row whose flags the read keeps, rows kept
+        long long start[2];               // row from which the read's state must be computed
         int32_t best[2];
         bool active[2];
 #pragma unroll
@@ -138,6 +139,10 @@ __global__ __launch_bounds__(64, NV <= 10 ? 3 : 1) void align_kernel_pk(AlignArg
             best[h] = active[h] ? (int32_t)a.score[id[h]] : 0;
             wrows[h] = flag_rows_needed(W, (int)len[h], maxw, best[h], (int)a.sc->gap_open, (int)c.ge);
             keep0[h] = active[h] ? rend[h] - wrows[h] + 1 : 0x7fffffff;
+            // late start: with the first pass's certificate (seed_safe_start) from that row, otherwise warmup_rows before the
+            // first kept row
+            const uint32_t safe = (active[h] && a.safe_row) ? a.safe_row[id[h]] : 0xffffffffu;
+            start[h] = !active[h] ? 0x7fffffffll : safe != 0xffffffffu ? min((long long)keep0[h] - 1, (long long)safe) : (long long)keep0[h] - 1 - warm;
         }
         // StripedProfile::new_unchecked (profile.rs:270-306): position q = v + lane*nv, padding scores 0 (the bias)
 #pragma unroll
@@ -157,15 +162,17 @@ __global__ __launch_bounds__(64, NV <= 10 ? 3 : 1) void align_kernel_pk(AlignArg
         int cend[2] = {0x7fffffff, 0x7fffffff};
         int rmax_v = max(rend[0], rend[1]);
         int rmin_v = min(keep0[0], keep0[1]);
+        int rstart_v = (int)max(-1ll, min(min(start[0], start[1]), 0x7fffffffll));
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             rmax_v = max(rmax_v, __shfl_xor(rmax_v, d, 64));
             rmin_v = min(rmin_v, __shfl_xor(rmin_v, d, 64));
+            rstart_v = min(rstart_v, __shfl_xor(rstart_v, d, 64));
         }
         const int rmax = __builtin_amdgcn_readfirstlane(rmax_v);
         const int rmin = __builtin_amdgcn_readfirstlane(rmin_v);
         const int rflag = max(0, rmin);  // first row whose flags some read of the wave keeps (rmin: the smallest keep0)
-        const int r0 = (int)max(0ll, min((long long)rmin - 1 - warm, (long long)rmax));  // late start (warmup_rows)
+        const int r0 = max(0, min(__builtin_amdgcn_readfirstlane(rstart_v), rmax));  // late start: the earliest row any read of the wave needs
         uint8_t* ring0 = a.ring + ((size_t)blockIdx.x * RPW + (size_t)grp * 2) * (size_t)W * row_bytes;
         uint8_t* ring1 = ring0 + (size_t)W * row_bytes;
 

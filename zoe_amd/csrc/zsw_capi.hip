@@ -63,7 +63,7 @@ struct zsw_context {
     // staging for host-memory batches
     DevBuf s_bases, s_offsets, s_score, s_status, s_tier, s_rend, s_qend;
     // alignment workspace (zsw_align.hip)
-    DevBuf a_ws[28];
+    DevBuf a_ws[30];
     // score_ranges workspace
     DevBuf r_ws[20];
     KernelTimer timer;
@@ -561,7 +561,7 @@ zsw_error run_ranges(zsw_context* ctx, const zsw_batch* reads, const ResultRule&
 
 enum { WS_SCORE = 0, WS_STATUS, WS_TIER, WS_REND, WS_ITEMS, WS_RING, WS_CIG, WS_ALN, WS_CIGSTART, WS_CIGRAW, WS_BSUMS, WS_TOTAL,
        WS_FBLIST, WS_FBCOUNT, WS_OINC, WS_OOP, WS_CIG2, WS_RING2, WS_KEYS_IN, WS_KEYS_OUT, WS_VALS_IN, WS_SORT_TMP, WS_GTABLE, WS_FBMETA,
-       WS_ITEMS2 };
+       WS_ITEMS2, WS_SAFE };
 
 __global__ void count_some_kernel(const uint8_t* status, uint32_t n, uint32_t* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -651,6 +651,10 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     so.query_end = nullptr;
     so.fb_list = ctx->d_fb_list.as<uint32_t>();
     so.fb_count = ctx->d_fb_count.as<uint32_t>();
+    // the seeded first pass leaves, per read it accepts, the row from which pass 2 may start with a zero state
+    ZSW_HIP(ctx, ws[WS_SAFE].ensure((size_t)n * 4 + 4));
+    ZSW_HIP(ctx, hipMemsetAsync(ws[WS_SAFE].p, 0xff, (size_t)n * 4, stream));
+    so.safe_row = (ctx->flags() & ZSW_DEBUG_ALIGN_LONG_WARMUP) ? nullptr : ws[WS_SAFE].as<uint32_t>();
     hipError_t e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(),
                                 (uint32_t)ctx->ref_len, rule, so, score_ws(ctx), stream, nullptr, 1);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align pass 1", e);
@@ -672,7 +676,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     const size_t sort_bytes = group_temp_bytes(n);
     ZSW_HIP(ctx, ws[WS_SORT_TMP].ensure(sort_bytes + 256));
     ZSW_HIP(ctx, ws[WS_GTABLE].ensure((size_t)TABLE_CAP * 8 + 8));
-    e = group_reads(st.b, so.status, so.tier, so.ref_end, so.score, lanes_w8, lanes_w16, lanes_w32, ws[WS_KEYS_IN].as<uint64_t>(),
+    e = group_reads(st.b, so.status, so.tier, so.ref_end, so.score, so.safe_row, lanes_w8, lanes_w16, lanes_w32, ws[WS_KEYS_IN].as<uint64_t>(),
                     ws[WS_KEYS_OUT].as<uint64_t>(), ws[WS_VALS_IN].as<uint32_t>(), ws[WS_ITEMS].as<uint32_t>(), ws[WS_SORT_TMP].p,
                     sort_bytes, ws[WS_GTABLE].as<uint32_t>() + 2, ws[WS_GTABLE].as<uint32_t>(), TABLE_CAP - 1, stream);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align grouping", e);
@@ -762,7 +766,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
                                         so.score, so.ref_end, so.status, W, maxc, ringbuf.as<uint8_t>(), grid_of(g, full),
                                         cigbuf.as<uint32_t>(), pool, full ? 1 : 0, ws[WS_CIGSTART].as<uint64_t>(),
                                         ws[WS_CIGRAW].as<uint32_t>(), ws[WS_ALN].as<zsw_alignment>(),
-                                        ws[WS_FBLIST].as<uint32_t>(), ws[WS_FBCOUNT].as<uint32_t>(), invert, stream);
+                                        ws[WS_FBLIST].as<uint32_t>(), ws[WS_FBCOUNT].as<uint32_t>(), invert, stream, full ? nullptr : so.safe_row);
             if (he != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align pass 2", he);
             if (full) pool += (uint64_t)g.count * maxc;
         }

@@ -64,6 +64,9 @@ struct ScoreOut {
     uint32_t* query_end;
     uint32_t* fb_list;  // reads that need the exact 32-bit kernel
     uint32_t* fb_count;
+    // optional (alignment's first pass): per read, the row from which the second pass may start with a zero state
+    // (seed_safe_start, zsw_seed.hpp); the caller presets 0xffffffff = no certificate, the seeded window kernel fills the rest
+    uint32_t* safe_row = nullptr;
 };
 
 struct KernelTimer;

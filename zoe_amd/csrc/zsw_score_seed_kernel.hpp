@@ -316,6 +316,8 @@ __global__ __launch_bounds__(BLOCK, seed_min_waves(C, MODE)) void seed_window_ke
                 const bool some = status == ZSW_STATUS_SOME;
                 if (MODE != 0 && a.out.ref_end) a.out.ref_end[id] = some ? (second ? reB : reA) : 0;
                 if (MODE == 2 && a.out.query_end) a.out.query_end[id] = some ? (second ? qeB : qeA) : 0;
+                if (MODE != 0 && a.out.safe_row)  // sw_simd_align's second pass may start this late (or 0xffffffff: no certificate)
+                    a.out.safe_row[id] = (uint32_t)seed_safe_start(a.sp, (int)(info & 0xffffu), (int)((info >> 16) & 0xffu), second ? dtB : dtA, S);
             }
         }
     }

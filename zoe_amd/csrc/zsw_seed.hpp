@@ -255,6 +255,29 @@ ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetCell cell, Looku
     return out;
 }
 
+// Certificate for the late start of the alignment's second pass (sw_simd_align's flags, striped.rs:449-598, recomputed for the
+// rows the traceback can visit). Every quantity of the striped recurrence at a cell (H, the E entering it, the F of a lazy-F
+// round) is a maximum over alignment paths ending there; starting the recompute at row r0 with a zero state drops the paths
+// that start above r0. Such a path, continued by the remainder of the optimal path after a cell x the traceback visits, is a
+// valid path that scores at least (its value at x) + S - (optimal path's value at x) - (gap_open - gap_extend) (the remainder
+// may have to open a gap the optimal path was merely extending), and at most B_above(r0). A flag of x differs only if a
+// dropped path reaches H(x) - gap_open + gap_extend + 1 or more there (the lowest of the thresholds E == H, F == H,
+// E - ge > H - go, F - ge > H - go), hence not while B_above(r0) <= S - 2 * gap_open - 1; the same bound keeps every
+// dropped path below S in the last row, where the walk finds its first column.
+// Returns the largest such r0 (>= 0), or -1 if the read's k-mers do not allow one (the caller then uses the warm-up bound of
+// zsw_align_dev.hpp). t_all, d_fa, dt: the read's SeedRead values; S: its score.
+ZSW_SEED_HD int seed_safe_start(const SeedParams& p, int t_all, int d_fa, int dt, int S) {
+    const int x = t_all - S + 2 * p.go + 1;  // what both terms of B_above must take off t_all
+    if (d_fa < x) return -1;
+    int rows = 0;                            // dt - Dn - r0 + 1 >= 1 deleted rows, so that gap_open + (rows - 1) * gap_extend >= x
+    if (x > p.go) {
+        if (p.ge <= 0) return -1;
+        rows = (x - p.go + p.ge - 1) / p.ge;
+    }
+    const int r0 = dt - p.Dn - rows;
+    return r0 < 0 ? 0 : r0;
+}
+
 // ---- host side: what the matrix allows, and the reference index ------------------------------------------------------------
 
 // Fills p->maxw / lambda / ins_col / go / ge / code / wp from the S x S matrix (row = reference residue). `ref_has[x]`: residue
