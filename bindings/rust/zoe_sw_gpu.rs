@@ -105,6 +105,14 @@ unsafe extern "C" {
     fn zsw_align_batch_from(ctx: *mut ZswContext, reads: *const ZswBatch, from_width: i32, preset_bits: i32, invert: i32, out_aln: *mut ZswAlignment, out_status: *mut u8, out_tier: *mut u8, out_inc: *mut u32, out_op: *mut u8, ciglet_cap: u64, out_n_ciglets: *mut u64, stream: *mut c_void) -> i32;
     fn zsw_align_3pass_batch(ctx: *mut ZswContext, reads: *const ZswBatch, int_type: i32, lanes: i32, invert: i32, out_aln: *mut ZswAlignment, out_status: *mut u8, out_inc: *mut u32, out_op: *mut u8, ciglet_cap: u64, out_n_ciglets: *mut u64, stream: *mut c_void) -> i32;
     fn zsw_align_3pass_batch_from(ctx: *mut ZswContext, reads: *const ZswBatch, from_width: i32, preset_bits: i32, invert: i32, out_aln: *mut ZswAlignment, out_status: *mut u8, out_tier: *mut u8, out_inc: *mut u32, out_op: *mut u8, ciglet_cap: u64, out_n_ciglets: *mut u64, stream: *mut c_void) -> i32;
+    fn zsw_set_profile_sequence(ctx: *mut ZswContext, sequence: *const u8, len: usize, mem: i32) -> i32;
+    fn zsw_score_shared_batch(ctx: *mut ZswContext, reads: *const ZswBatch, int_type: i32, lanes: i32, out_score: *mut u32, out_status: *mut u8, stream: *mut c_void) -> i32;
+    fn zsw_score_shared_batch_from(ctx: *mut ZswContext, reads: *const ZswBatch, from_width: i32, preset_bits: i32, out_score: *mut u32, out_status: *mut u8, out_tier: *mut u8, stream: *mut c_void) -> i32;
+    fn zsw_score_ends_shared_batch(ctx: *mut ZswContext, reads: *const ZswBatch, int_type: i32, lanes: i32, out_score: *mut u32, out_ref_end: *mut u32, out_query_end: *mut u32, out_status: *mut u8, stream: *mut c_void) -> i32;
+    fn zsw_score_ranges_shared_batch(ctx: *mut ZswContext, reads: *const ZswBatch, int_type: i32, lanes: i32, out_score: *mut u32, out_ref_start: *mut u32, out_ref_end: *mut u32, out_query_start: *mut u32, out_query_end: *mut u32, out_status: *mut u8, stream: *mut c_void) -> i32;
+    fn zsw_score_ranges_shared_batch_from(ctx: *mut ZswContext, reads: *const ZswBatch, from_width: i32, preset_bits: i32, out_score: *mut u32, out_ref_start: *mut u32, out_ref_end: *mut u32, out_query_start: *mut u32, out_query_end: *mut u32, out_status: *mut u8, out_tier: *mut u8, stream: *mut c_void) -> i32;
+    fn zsw_align_shared_batch(ctx: *mut ZswContext, reads: *const ZswBatch, int_type: i32, lanes: i32, invert: i32, out_aln: *mut ZswAlignment, out_status: *mut u8, out_inc: *mut u32, out_op: *mut u8, ciglet_cap: u64, out_n_ciglets: *mut u64, stream: *mut c_void) -> i32;
+    fn zsw_align_shared_batch_from(ctx: *mut ZswContext, reads: *const ZswBatch, from_width: i32, preset_bits: i32, invert: i32, out_aln: *mut ZswAlignment, out_status: *mut u8, out_tier: *mut u8, out_inc: *mut u32, out_op: *mut u8, ciglet_cap: u64, out_n_ciglets: *mut u64, stream: *mut c_void) -> i32;
     fn zsw_sneaky_snake_batch(ctx: *mut ZswContext, reads: *const ZswBatch, ref_start: *const u32, ref_len: *const u32, threshold: f32, out_pass: *mut u8, stream: *mut c_void) -> i32;
     fn zsw_group_create(device_ids: *const i32, n_devices: i32, out: *mut *mut ZswGroup) -> i32;
     fn zsw_group_destroy(group: *mut ZswGroup);
@@ -441,6 +449,133 @@ impl GpuContext {
         };
         self.check(code, scoring.gap_open, scoring.gap_extend)?;
         Ok(Self::ranges_out(n, &status, &score, &rs, &re, &qs, &qe))
+    }
+
+    // ---- the one-profile-many-sequences role: `sequence.into_shared_profile(..)` once, every read against it ----
+    // (sw/mod.rs:63-67, profile_set.rs:552-560, nucleotides/mod.rs:295-299). In the results the READ is the reference of
+    // sw_simd_* unless `other` is `OtherSeq::Query`, which is `SeqSrc::Query(read)` (alignment/mod.rs:176-190).
+
+    fn configure_shared<const S: usize>(&self, scoring: &Scoring<'_, S>, sequence: &[u8]) -> Result<(), GpuError> {
+        let w = scoring.flat_weights();
+        let map = scoring.index_map();
+        let (go, ge) = (scoring.gap_open, scoring.gap_extend);
+        // SAFETY: pointers are valid for S*S / 256 / sequence.len() bytes for the duration of the calls
+        self.check(unsafe { zsw_set_scoring(self.raw, w.as_ptr(), S as i32, map.as_ptr(), i32::from(go), i32::from(ge)) }, go, ge)?;
+        let p = if sequence.is_empty() { [0u8].as_ptr() } else { sequence.as_ptr() };
+        // an empty sequence comes back as ProfileError::EmptySequence through check()
+        self.check(unsafe { zsw_set_profile_sequence(self.raw, p, sequence.len(), ZSW_MEM_HOST) }, go, ge)
+    }
+
+    /// Per read: `StripedProfile::<T, N, S>::new(sequence, ..)?.sw_score(read)`.
+    pub fn sw_score_shared_batch<const S: usize, Q: AsRef<[u8]>>(
+        &self, sequence: &[u8], reads: &[Q], scoring: &Scoring<'_, S>, int_type: ZswIntType, lanes: i32,
+    ) -> Result<Vec<Result<MaybeAligned<u32>, ProfileError>>, GpuError> {
+        self.configure_shared(scoring, sequence)?;
+        let batch = HostBatch::new(reads);
+        let n = reads.len();
+        let (mut score, mut status) = (vec![0u32; n.max(1)], vec![0u8; n.max(1)]);
+        // SAFETY: output arrays hold n entries
+        let code = unsafe { zsw_score_shared_batch(self.raw, &batch.as_c(), int_type as i32, lanes, score.as_mut_ptr(), status.as_mut_ptr(), ptr::null_mut()) };
+        self.check(code, scoring.gap_open, scoring.gap_extend)?;
+        Ok((0..n).map(|i| maybe(status[i], || score[i])).collect())
+    }
+
+    /// Per read: `shared_profiles.sw_score_from_i{from_width}(read)`; the second vector is the width that answered.
+    pub fn sw_score_shared_from_batch<const S: usize, Q: AsRef<[u8]>>(
+        &self, sequence: &[u8], reads: &[Q], scoring: &Scoring<'_, S>, cascade: Cascade,
+    ) -> Result<(Vec<Result<MaybeAligned<u32>, ProfileError>>, Vec<u8>), GpuError> {
+        self.configure_shared(scoring, sequence)?;
+        let batch = HostBatch::new(reads);
+        let n = reads.len();
+        let (mut score, mut status, mut tier) = (vec![0u32; n.max(1)], vec![0u8; n.max(1)], vec![0u8; n.max(1)]);
+        // SAFETY: as above
+        let code = unsafe {
+            zsw_score_shared_batch_from(self.raw, &batch.as_c(), cascade.from_width, cascade.preset_bits, score.as_mut_ptr(), status.as_mut_ptr(), tier.as_mut_ptr(), ptr::null_mut())
+        };
+        self.check(code, scoring.gap_open, scoring.gap_extend)?;
+        Ok(((0..n).map(|i| maybe(status[i], || score[i])).collect(), tier))
+    }
+
+    /// Per read: `profile.sw_score_ends(SeqSrc::Reference(read))`: `ref_end` in the read, `query_end` in the sequence.
+    pub fn sw_score_ends_shared_batch<const S: usize, Q: AsRef<[u8]>>(
+        &self, sequence: &[u8], reads: &[Q], scoring: &Scoring<'_, S>, int_type: ZswIntType, lanes: i32,
+    ) -> Result<Vec<Result<MaybeAligned<ScoreEnds<u32>>, ProfileError>>, GpuError> {
+        self.configure_shared(scoring, sequence)?;
+        let batch = HostBatch::new(reads);
+        let n = reads.len();
+        let (mut score, mut r_end, mut q_end, mut status) = (vec![0u32; n.max(1)], vec![0u32; n.max(1)], vec![0u32; n.max(1)], vec![0u8; n.max(1)]);
+        // SAFETY: as above
+        let code = unsafe {
+            zsw_score_ends_shared_batch(self.raw, &batch.as_c(), int_type as i32, lanes, score.as_mut_ptr(), r_end.as_mut_ptr(), q_end.as_mut_ptr(), status.as_mut_ptr(), ptr::null_mut())
+        };
+        self.check(code, scoring.gap_open, scoring.gap_extend)?;
+        Ok((0..n)
+            .map(|i| maybe(status[i], || ScoreEnds { score: score[i], ref_end: r_end[i] as usize, query_end: q_end[i] as usize }))
+            .collect())
+    }
+
+    /// Per read: `profile.sw_score_ranges(SeqSrc::Reference(read))` at `<T, N>`.
+    pub fn sw_score_ranges_shared_batch<const S: usize, Q: AsRef<[u8]>>(
+        &self, sequence: &[u8], reads: &[Q], scoring: &Scoring<'_, S>, int_type: ZswIntType, lanes: i32,
+    ) -> Result<Vec<Result<MaybeAligned<ScoreAndRanges<u32>>, ProfileError>>, GpuError> {
+        self.configure_shared(scoring, sequence)?;
+        let batch = HostBatch::new(reads);
+        let n = reads.len();
+        let m = n.max(1);
+        let (mut score, mut rs, mut re, mut qs, mut qe, mut status) = (vec![0u32; m], vec![0u32; m], vec![0u32; m], vec![0u32; m], vec![0u32; m], vec![0u8; m]);
+        // SAFETY: as above
+        let code = unsafe {
+            zsw_score_ranges_shared_batch(self.raw, &batch.as_c(), int_type as i32, lanes, score.as_mut_ptr(), rs.as_mut_ptr(), re.as_mut_ptr(), qs.as_mut_ptr(), qe.as_mut_ptr(), status.as_mut_ptr(), ptr::null_mut())
+        };
+        self.check(code, scoring.gap_open, scoring.gap_extend)?;
+        Ok(Self::ranges_out(n, &status, &score, &rs, &re, &qs, &qe))
+    }
+
+    /// Per read: `shared_profiles.sw_score_ranges_from_i{from_width}(SeqSrc::Reference(read))`.
+    pub fn sw_score_ranges_shared_from_batch<const S: usize, Q: AsRef<[u8]>>(
+        &self, sequence: &[u8], reads: &[Q], scoring: &Scoring<'_, S>, cascade: Cascade,
+    ) -> Result<Vec<Result<MaybeAligned<ScoreAndRanges<u32>>, ProfileError>>, GpuError> {
+        self.configure_shared(scoring, sequence)?;
+        let batch = HostBatch::new(reads);
+        let n = reads.len();
+        let m = n.max(1);
+        let (mut score, mut rs, mut re, mut qs, mut qe, mut status, mut tier) = (vec![0u32; m], vec![0u32; m], vec![0u32; m], vec![0u32; m], vec![0u32; m], vec![0u8; m], vec![0u8; m]);
+        // SAFETY: as above
+        let code = unsafe {
+            zsw_score_ranges_shared_batch_from(self.raw, &batch.as_c(), cascade.from_width, cascade.preset_bits, score.as_mut_ptr(), rs.as_mut_ptr(), re.as_mut_ptr(), qs.as_mut_ptr(), qe.as_mut_ptr(), status.as_mut_ptr(), tier.as_mut_ptr(), ptr::null_mut())
+        };
+        self.check(code, scoring.gap_open, scoring.gap_extend)?;
+        Ok(Self::ranges_out(n, &status, &score, &rs, &re, &qs, &qe))
+    }
+
+    /// Per read: `profile.sw_align(SeqSrc::Query(read))` (or `SeqSrc::Reference`) with the profile of `sequence` at `<T, N>`.
+    pub fn sw_align_shared_batch<const S: usize, Q: AsRef<[u8]>>(
+        &self, sequence: &[u8], reads: &[Q], scoring: &Scoring<'_, S>, int_type: ZswIntType, lanes: i32, other: OtherSeq,
+    ) -> Result<Vec<Result<MaybeAligned<Alignment<u32>>, ProfileError>>, GpuError> {
+        self.configure_shared(scoring, sequence)?;
+        let batch = HostBatch::new(reads);
+        let c = batch.as_c();
+        let invert = i32::from(other == OtherSeq::Query);
+        let (out, _) = self.align_with(reads.len(), scoring.gap_open, scoring.gap_extend, |aln, st, _tier, inc, op, cap, need| {
+            // SAFETY: all arrays were sized by align_with
+            unsafe { zsw_align_shared_batch(self.raw, &c, int_type as i32, lanes, invert, aln, st, inc, op, cap, need, ptr::null_mut()) }
+        })?;
+        Ok(out)
+    }
+
+    /// Per read: `sequence.into_shared_profile(..)?.sw_align_from_i{from_width}(SeqSrc::Query(read))`; the second vector is the
+    /// width that answered.
+    pub fn sw_align_shared_from_batch<const S: usize, Q: AsRef<[u8]>>(
+        &self, sequence: &[u8], reads: &[Q], scoring: &Scoring<'_, S>, cascade: Cascade, other: OtherSeq,
+    ) -> Result<(Vec<Result<MaybeAligned<Alignment<u32>>, ProfileError>>, Vec<u8>), GpuError> {
+        self.configure_shared(scoring, sequence)?;
+        let batch = HostBatch::new(reads);
+        let c = batch.as_c();
+        let invert = i32::from(other == OtherSeq::Query);
+        self.align_with(reads.len(), scoring.gap_open, scoring.gap_extend, |aln, st, tier, inc, op, cap, need| {
+            // SAFETY: as above
+            unsafe { zsw_align_shared_batch_from(self.raw, &c, cascade.from_width, cascade.preset_bits, invert, aln, st, tier, inc, op, cap, need, ptr::null_mut()) }
+        })
     }
 
     /// Shared tail of the alignment calls: the library reports the number of ciglets it needs when the arrays

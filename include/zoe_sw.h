@@ -169,6 +169,44 @@ zsw_error zsw_align_3pass_batch_from(zsw_context* ctx, const zsw_batch* reads, i
                                      zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc,
                                      uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream);
 
+/* ---- shared profile: one profile, many sequences ------------------------------------------- */
+/* The other role of the striped functions (sw/mod.rs:63-67: "the profile can be aligned against any number of different
+ * sequences"; SharedProfiles, profile_set.rs:552-560; Nucleotides::into_shared_profile, nucleotides/mod.rs:295-299): the
+ * profile is built ONCE from a sequence the context holds — typically the reference — and read i is the sequence
+ * sw_simd_* walks row by row. Scores are the numbers of the entry points above; ends, ranges and CIGARs are not in tie
+ * cases, because the tie rule (first row, then first column) and the striping <T, N, nv = ceil(len / N)> now run over the
+ * other sequence. In the results `ref_*` is the non-profile sequence, i.e. the READ, and `query_*` the profile sequence, as
+ * sw_simd_* return them; invert != 0 is SeqSrc::Query(read_i) (alignment/mod.rs:176-190), which hands the roles back.
+ *
+ * zsw_set_profile_sequence: StripedProfile::new's sequence argument; len == 0 -> ZSW_ERR_EMPTY_SEQUENCE (profile.rs:32-44).
+ * An empty READ is an empty `reference` argument here: status ZSW_STATUS_UNMAPPED (striped.rs:219-221).
+ * Reads of up to 6,800 bases; the alignment calls keep plen x (longest read) flag bytes per read in flight. */
+zsw_error zsw_set_profile_sequence(zsw_context* ctx, const uint8_t* sequence, size_t len, zsw_mem mem);
+/* StripedProfile::<int_type,lanes,S>::new(sequence).sw_score(read_i) / ProfileSets::sw_score_from_i{from_width} */
+zsw_error zsw_score_shared_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, uint32_t* out_score,
+                                 uint8_t* out_status, void* stream);
+zsw_error zsw_score_shared_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, uint32_t* out_score,
+                                      uint8_t* out_status, uint8_t* out_tier, void* stream);
+/* sw_simd_score_ends(reference = read_i, profile of the sequence): out_ref_end = exclusive end in the READ, out_query_end =
+ * exclusive end in the profile sequence; first read position holding the maximum, then the first sequence position. */
+zsw_error zsw_score_ends_shared_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, uint32_t* out_score,
+                                      uint32_t* out_ref_end, uint32_t* out_query_end, uint8_t* out_status, void* stream);
+/* sw_simd_score_ranges / ProfileSets::sw_score_ranges_from_i{from_width}: ref range = in the read, query range = in the sequence */
+zsw_error zsw_score_ranges_shared_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, uint32_t* out_score,
+                                        uint32_t* out_ref_start, uint32_t* out_ref_end, uint32_t* out_query_start, uint32_t* out_query_end,
+                                        uint8_t* out_status, void* stream);
+zsw_error zsw_score_ranges_shared_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, uint32_t* out_score,
+                                             uint32_t* out_ref_start, uint32_t* out_ref_end, uint32_t* out_query_start, uint32_t* out_query_end,
+                                             uint8_t* out_status, uint8_t* out_tier, void* stream);
+/* sw_simd_align / ProfileSets::sw_align_from_i{from_width} with the shared profile; invert = 1 is the usual call,
+ * `sequence.into_shared_profile(..).sw_align_from_i8(SeqSrc::Query(read_i))`. Outputs as zsw_align_batch(_from). */
+zsw_error zsw_align_shared_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, int invert, zsw_alignment* out_aln,
+                                 uint8_t* out_status, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets,
+                                 void* stream);
+zsw_error zsw_align_shared_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, int invert,
+                                      zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op,
+                                      uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream);
+
 /* ---- pre-alignment filter ------------------------------------------------------------------ */
 /* out_pass[i] = sneaky_snake(&reference[ref_start[i] .. ref_start[i]+ref_len[i]], read_i, threshold)
  * (src/alignment/sneaky_snake.rs:78-131): the SneakySnake edit-distance filter between a read and a candidate window of the

@@ -1,0 +1,226 @@
+"""GPU parity tests of the one-profile-many-sequences role (zsw_*_shared_batch; zsw_shared.hip, align_kernel<N, ., SHARED>): the
+profile is built once from a sequence (Nucleotides::into_shared_profile, nucleotides/mod.rs:295-299; SharedProfiles,
+profile_set.rs:552-560) and every read is aligned against it (sw/mod.rs:63-67). Checker: oracle/ with the SAME roles — the
+oracle's functions take (profile sequence, other sequence) — at the same <T, N> / preset, so the tie rule of the ends and the
+striping of the traceback run over the profile sequence exactly as in the reference."""
+import numpy as np
+import pytest
+
+from conftest import stable_seed
+
+pytestmark = pytest.mark.gpu
+S_ = 0
+
+
+@pytest.fixture(scope="module")
+def za():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests need an MI355X")
+    import zoe_amd
+
+    return zoe_amd
+
+
+def osc(oracle, m, go, ge):
+    return oracle.Scoring(m.signed_weights(), m.mapping.index_map, go, ge)
+
+
+def okey(a):
+    return a.key() if a.status == S_ else (a.status, 0, (0, 0), (0, 0), "", 0, 0)
+
+
+def _reads_like_config1(n, seed, ref, L=150):
+    from zoe_amd import synth
+
+    return [bytes(r) for r in synth.reads_host(ref, seed, n, L)]
+
+
+@pytest.mark.parametrize("T,N", [("i16", 16), ("i8", 32), ("i16", 8), ("i32", 8)])
+def test_shared_striped_profile_vs_oracle(za, oracle, T, N):
+    """score, ends, ranges and alignment (SeqSrc::Query: the usual call) of 3,000 synthetic reads against the profile of the
+    2 kb reference at <T, N>; every read's ends and ranges, every fifth read's CIGAR."""
+    from zoe_amd import synth
+
+    ref = synth.reference_host(2000)
+    reads = _reads_like_config1(3000, 11, ref)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    sc = osc(oracle, dna, -10, -1)
+    prof = za.SharedStripedProfile(ref, dna, -10, -1, T, N)
+    s = prof.sw_score(reads)
+    e = prof.sw_score_ends(za.SeqBatchSrc.Reference(reads))
+    r = prof.sw_score_ranges(za.SeqBatchSrc.Reference(reads))
+    rq = prof.sw_score_ranges(za.SeqBatchSrc.Query(reads))
+    a = prof.sw_align(za.SeqBatchSrc.Query(reads))
+    ar = prof.sw_align(za.SeqBatchSrc.Reference(reads[:300]))
+    for i, rd in enumerate(reads):
+        st, sv = oracle.score(T, N, sc, ref, rd)
+        assert (int(s.status[i]), int(s.score[i]) if st == S_ else 0) == (st, sv if st == S_ else 0), i
+        st, (sv, re_, qe) = oracle.score_ends(T, N, sc, ref, rd)
+        assert int(e.status[i]) == st, i
+        if st == S_:
+            assert (int(e.score[i]), int(e.ref_end[i]), int(e.query_end[i])) == (sv, re_, qe), i
+        st, sv, rr, qr = oracle.score_ranges(T, N, sc, ref, rd)
+        assert int(r.status[i]) == st, i
+        if st == S_:
+            assert (int(r.score[i]), (int(r.ref_start[i]), int(r.ref_end[i])), (int(r.query_start[i]), int(r.query_end[i]))) == (sv, rr, qr), i
+            assert ((int(rq.query_start[i]), int(rq.query_end[i])), (int(rq.ref_start[i]), int(rq.ref_end[i]))) == (rr, qr), i
+        if i % 5 == 0:
+            assert a.key(i) == okey(oracle.align(T, N, sc, ref, rd, other_is_query=True)), i
+        if i < 300 and i % 3 == 0:
+            assert ar.key(i) == okey(oracle.align(T, N, sc, ref, rd, other_is_query=False)), i
+
+
+@pytest.mark.parametrize("preset", [128, 256, 512])
+def test_shared_profiles_cascade_vs_oracle(za, oracle, preset):
+    """sequence.into_shared_profile(..) semantics at the three presets: sw_score_from_i8, sw_score_ranges_from_i8 and
+    sw_align_from_i8(SeqSrc::Query(read)): tiers, ranges and CIGARs of the tier that answered."""
+    from zoe_amd import synth
+
+    ref = synth.reference_host(2000)
+    reads = _reads_like_config1(1500, 5, ref) + _reads_like_config1(300, 9, ref, L=90)  # the short ones answer at i8
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    sc = osc(oracle, dna, -10, -1)
+    prof = za.SharedProfilesBatch(ref, dna, -10, -1, preset) if preset != 256 else za.into_shared_profile(ref, dna, -10, -1)
+    s = prof.sw_score_from_i8(reads)
+    r = prof.sw_score_ranges_from_i8(za.SeqBatchSrc.Reference(reads))
+    a = prof.sw_align_from_i8(za.SeqBatchSrc.Query(reads))
+    tiers = set()
+    for i, rd in enumerate(reads):
+        st, sv, tier = oracle.cascade_score(8, preset, sc, ref, rd)
+        assert (int(s.status[i]), int(s.tier[i])) == (st, tier), i
+        if st == S_:
+            assert int(s.score[i]) == sv, i
+        tiers.add(tier)
+        if i % 4 == 0:
+            st, sv, rr, qr, tier = oracle.cascade_score_ranges(8, preset, sc, ref, rd)
+            assert int(r.status[i]) == st, i
+            if st == S_:
+                assert (int(r.score[i]), (int(r.ref_start[i]), int(r.ref_end[i])), (int(r.query_start[i]), int(r.query_end[i])), int(r.tier[i])) == (sv, rr, qr, tier), i
+            want, wt = oracle.cascade_align(8, preset, sc, ref, rd, other_is_query=True)
+            assert a.key(i) == okey(want), i
+            assert int(a.tier[i]) == wt, i
+    assert {8, 16} <= tiers
+
+
+def test_layout_dependent_pairs_with_the_roles_swapped(za, oracle):
+    """SURVEY.md §7 hard part 1 from the other side: the long sequence carries the profile, the short one is walked row by row;
+    every lane count must give the oracle's CIGAR of that lane count, in both SeqSrc directions."""
+    cases = [
+        (4, -2, -3, -1, b"GGACTAAGCTAACACAGGTAGGCTTTATAAAAGGTTAAAGTGCGTGAGCTAGGGTGGCTCTCACT", b"TATAAAAGGTTAAAGTGCTGTAGCTTAGGGTTGCTCTC"),
+        (3, -1, -4, -1, b"TGGGGCATTTATGCGATGCAAGACAGGTCTAATATTGAAATTTATTCTAGACTATGCGAGGCCGCTCAAAGGAACCATTACCTTTTTCCGTAGGTCTCCCGATCGCGGCTAACTACTGC", b"ATAGCGATCGCAGCGCCAGGTCT"),
+    ]
+    for ma, mi, go, ge, long_seq, short_seq in cases:
+        m = za.WeightMatrix.new_dna_matrix(ma, mi, b"N")
+        sc = osc(oracle, m, go, ge)
+        for N in (2, 4, 8, 16, 32, 64):
+            prof = za.SharedStripedProfile(long_seq, m, go, ge, "i16", N)
+            for is_query in (False, True):
+                src = (za.SeqBatchSrc.Query if is_query else za.SeqBatchSrc.Reference)([short_seq, short_seq[::-1], long_seq[5:40]])
+                got = prof.sw_align(src)
+                for i, other in enumerate((short_seq, short_seq[::-1], long_seq[5:40])):
+                    assert got.key(i) == okey(oracle.align("i16", N, sc, long_seq, other, other_is_query=is_query)), (N, is_query, i)
+
+
+@pytest.mark.parametrize("scheme", [(4, -2, -3, -1), (2, -5, -10, -1), (3, -1, 0, 0), (1, -1, -1, -1), (5, -4, -2, 0)])
+def test_random_pairs_ragged_reads_ties_and_low_complexity(za, oracle, scheme):
+    """Ragged batches, reads with N and lower case, low-complexity reads against a low-complexity sequence (ties in every row):
+    ends, ranges and CIGARs at <i16, 4 / 16>."""
+    ma, mi, go, ge = scheme
+    rng = np.random.default_rng(stable_seed("shared", scheme))
+    m = za.WeightMatrix.new_dna_matrix(ma, mi, b"N")
+    sc = osc(oracle, m, go, ge)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seq = bytes(rng.choice(alpha, 300)) + b"ACACACACACACACAC" + bytes(rng.choice(alpha[:2], 60)) + bytes(rng.choice(alpha, 200))
+    reads = []
+    for _ in range(150):
+        L = int(rng.integers(1, 90))
+        t = rng.random()
+        if t < 0.6:
+            s0 = int(rng.integers(0, len(seq) - L))
+            r = bytearray(seq[s0 : s0 + L])
+            for _ in range(int(rng.integers(0, 4))):
+                k = int(rng.integers(0, len(r)))
+                u = rng.random()
+                if u < 0.4:
+                    r[k] = int(rng.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8)))
+                elif u < 0.7 and len(r) > 1:
+                    del r[k]
+                else:
+                    r.insert(k, int(rng.choice(alpha)))
+            reads.append(bytes(r))
+        elif t < 0.85:
+            reads.append(bytes(rng.choice(alpha[:2], L)))
+        else:
+            reads.append(bytes(rng.choice(alpha, L)))
+    for N in (4, 16):
+        prof = za.SharedStripedProfile(seq, m, go, ge, "i16", N)
+        e = prof.sw_score_ends(za.SeqBatchSrc.Reference(reads))
+        r = prof.sw_score_ranges(za.SeqBatchSrc.Reference(reads))
+        a = prof.sw_align(za.SeqBatchSrc.Query(reads))
+        for i, rd in enumerate(reads):
+            st, (sv, re_, qe) = oracle.score_ends("i16", N, sc, seq, rd)
+            assert int(e.status[i]) == st, (N, i)
+            if st == S_:
+                assert (int(e.score[i]), int(e.ref_end[i]), int(e.query_end[i])) == (sv, re_, qe), (N, i)
+            st, sv, rr, qr = oracle.score_ranges("i16", N, sc, seq, rd)
+            assert int(r.status[i]) == st, (N, i)
+            if st == S_:
+                assert (int(r.score[i]), (int(r.ref_start[i]), int(r.ref_end[i])), (int(r.query_start[i]), int(r.query_end[i]))) == (sv, rr, qr), (N, i)
+            assert a.key(i) == okey(oracle.align("i16", N, sc, seq, rd, other_is_query=True)), (N, i)
+
+
+def test_long_profile_sequence_takes_several_tiles_and_rows_in_hbm(za, oracle):
+    """A 5 kb profile sequence: three 2,048-column tiles in the ends kernel, nv = 313 at <i16, 16> (DP rows behind the flag ring)."""
+    from zoe_amd import synth
+
+    seq = synth.reference_host(5000)
+    reads = _reads_like_config1(200, 3, seq, L=120)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    sc = osc(oracle, dna, -10, -1)
+    prof = za.SharedStripedProfile(seq, dna, -10, -1, "i16", 16)
+    r = prof.sw_score_ranges(za.SeqBatchSrc.Reference(reads))
+    a = prof.sw_align(za.SeqBatchSrc.Query(reads))
+    for i, rd in enumerate(reads):
+        st, sv, rr, qr = oracle.score_ranges("i16", 16, sc, seq, rd)
+        assert int(r.status[i]) == st, i
+        if st == S_:
+            assert (int(r.score[i]), (int(r.ref_start[i]), int(r.ref_end[i])), (int(r.query_start[i]), int(r.query_end[i]))) == (sv, rr, qr), i
+        if i % 4 == 0:
+            assert a.key(i) == okey(oracle.align("i16", 16, sc, seq, rd, other_is_query=True)), i
+
+
+def test_empty_inputs_and_errors(za, oracle):
+    import torch
+
+    from zoe_amd import _lib
+
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    with pytest.raises(za.ProfileError):
+        za.SharedStripedProfile(b"", dna, -10, -1)  # StripedProfile::new(empty) -> ProfileError::EmptySequence
+    prof = za.SharedStripedProfile(b"ACGTACGTTTGACA", dna, -10, -1, "i16", 16)
+    # an empty read is an empty `reference` argument: Unmapped (striped.rs:219-221), in a ragged batch with ordinary reads
+    reads = [b"ACGTTTG", b"", b"TTTT"]
+    off = torch.tensor([0, 7, 7, 11], dtype=torch.int64, device="cuda")
+    rb = za.ReadBatch(torch.frombuffer(bytearray(b"".join(reads)), dtype=torch.uint8).cuda(), 3, offsets=off)
+    s = prof.sw_score(rb)
+    e = prof.sw_score_ends(za.SeqBatchSrc.Reference(rb))
+    a = prof.sw_align(za.SeqBatchSrc.Query(rb))
+    assert [int(x) for x in s.status] == [0, 2, 2] or [int(x) for x in s.status][1] == 2
+    assert int(e.status[1]) == 2 and int(a.status[1]) == 2
+    sc = osc(oracle, dna, -10, -1)
+    assert a.key(0) == okey(oracle.align("i16", 16, sc, b"ACGTACGTTTGACA", reads[0], other_is_query=True))
+    ctx = za.SwContext.get(0)
+    fresh = _lib.load()
+    import ctypes as C
+
+    h = C.c_void_p()
+    assert fresh.zsw_create(0, C.byref(h)) == 0
+    try:  # the shared entry points need a profile sequence
+        b = rb.c_batch()
+        sc_t = torch.zeros(3, dtype=torch.int32, device="cuda")
+        st_t = torch.zeros(3, dtype=torch.uint8, device="cuda")
+        assert fresh.zsw_score_shared_batch(h, C.byref(b), 1, 16, sc_t.data_ptr(), st_t.data_ptr(), None) == -5  # ZSW_ERR_NOT_CONFIGURED
+    finally:
+        fresh.zsw_destroy(h)

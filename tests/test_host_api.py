@@ -57,10 +57,15 @@ def test_shard_range():
             assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
 
 
-def test_shared_profiles_mirror_is_the_local_one_under_another_name():
-    # profile_set.rs:552-700: SharedProfiles has the methods of LocalProfiles (ProfileSets trait)
+def test_shared_profiles_mirror_has_the_profile_set_methods():
+    # profile_set.rs:552-700: SharedProfiles carries the ProfileSets methods; here it is built from ONE sequence and its methods
+    # take the batch of reads (the one-profile-many-sequences role, zsw_*_shared_batch)
     import zoe_amd
 
-    assert issubclass(zoe_amd.SharedProfilesBatch, zoe_amd.LocalProfilesBatch)
-    for name in ("sw_score_from_i8", "sw_align_from_i16", "sw_align_from_i32_3pass", "sw_score_ranges_from_i8"):
+    for name in ("sw_score_from_i8", "sw_score_from_i32", "sw_align_from_i16", "sw_score_ranges_from_i8", "new_with_w128", "new_with_w512"):
         assert hasattr(zoe_amd.SharedProfilesBatch, name)
+    for name in ("sw_score", "sw_score_ends", "sw_score_ranges", "sw_align"):
+        assert hasattr(zoe_amd.SharedStripedProfile, name)
+    import inspect
+
+    assert list(inspect.signature(zoe_amd.into_shared_profile).parameters)[:4] == ["sequence", "matrix", "gap_open", "gap_extend"]

@@ -254,6 +254,15 @@ class SwContext:
         """zsw_debug_set: kernel-selection overrides (_lib.DEBUG_*) for the parity tests; 0 restores the defaults."""
         self.check(self.lib.zsw_debug_set(self.h, int(flags)))
 
+    def set_profile_sequence(self, sequence: bytes):
+        """zsw_set_profile_sequence: the sequence the shared profile is built from (skipped when it is the one already set)"""
+        sequence = bytes(sequence)
+        if getattr(self, "_pseq", None) == sequence:
+            return
+        buf = (C.c_uint8 * max(len(sequence), 1)).from_buffer_copy(sequence if sequence else b"\0")
+        self.check(self.lib.zsw_set_profile_sequence(self.h, buf, len(sequence), _lib.MEM_HOST))
+        self._pseq = sequence
+
     def set_option(self, option: int, value: int):
         """zsw_set_option, e.g. set_option(_lib.OPTION_EXACT_PRUNING, 0): every cell of every read instead of the seeded exact pass."""
         self.check(self.lib.zsw_set_option(self.h, int(option), int(value)), profile_errors=False)
@@ -734,11 +743,223 @@ def into_local_profile(reads, matrix: WeightMatrix, gap_open: int, gap_extend: i
     return LocalProfilesBatch.new_with_w256(reads, matrix, gap_open, gap_extend, device)
 
 
-class SharedProfilesBatch(LocalProfilesBatch):
-    """`SharedProfiles` (profile_set.rs:552-700): the same lazily built i8/i16/i32 profile set, `Sync` in the reference.
-    A batch object here holds no lazily initialised state, so the two mirrors only differ in name."""
+class _SharedBase:
+    """The one-profile-many-sequences role: the profile is built ONCE from `sequence` (sw/mod.rs:63-67 "the profile can be
+    aligned against any number of different sequences") and every read of a batch is the sequence it is aligned against,
+    walked row by row. Results follow the reference's conventions: `ref_*` is the non-profile sequence (the read) unless the
+    reads are passed as `SeqSrc.Query(reads)`, which swaps the roles back (alignment/mod.rs:176-190)."""
+
+    def __init__(self, sequence, matrix: WeightMatrix, gap_open: int, gap_extend: int, device: int = 0):
+        sequence = bytes(sequence)
+        validate_profile_args(len(sequence), gap_open, gap_extend)
+        self.sequence = sequence
+        self.matrix = matrix
+        self.gap_open = gap_open
+        self.gap_extend = gap_extend
+        self.device = device
+        self.ctx = SwContext.get(device)
+
+    def _prep(self):
+        self.ctx.set_scoring(self.matrix, self.gap_open, self.gap_extend)
+        self.ctx.set_profile_sequence(self.sequence)
+
+    @staticmethod
+    def _reads_of(seq):
+        """reads, or SeqSrc.Reference(reads) / SeqSrc.Query(reads) with a ReadBatch or a list of byte strings inside"""
+        if isinstance(seq, SeqBatchSrc):
+            return seq.reads, seq.is_query
+        return seq, False
+
+    def _ends(self, seq, direct) -> ScoreBatch:
+        torch = _torch()
+        reads, is_query = self._reads_of(seq)
+        rb = _as_batch(reads, self.device)
+        self._prep()
+        n, dev = rb.n_reads, rb.bases.device
+        score = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        rend = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        qend = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        b = rb.c_batch()
+        self.ctx.check(self.ctx.lib.zsw_score_ends_shared_batch(self.ctx.h, C.byref(b), direct[0], direct[1], score.data_ptr(), rend.data_ptr(),
+                                                                qend.data_ptr(), status.data_ptr(), self.ctx.stream()))
+        if is_query:
+            rend, qend = qend, rend
+        return ScoreBatch(score[:n], status[:n], ref_end=rend[:n], query_end=qend[:n])
+
+    def _ranges(self, seq, direct=None, from_width=None, preset=None) -> ScoreBatch:
+        torch = _torch()
+        reads, is_query = self._reads_of(seq)
+        rb = _as_batch(reads, self.device)
+        self._prep()
+        n, dev = rb.n_reads, rb.bases.device
+        o = [torch.empty(max(n, 1), dtype=torch.int32, device=dev) for _ in range(5)]
+        status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        tier = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        b = rb.c_batch()
+        if direct is not None:
+            self.ctx.check(self.ctx.lib.zsw_score_ranges_shared_batch(self.ctx.h, C.byref(b), direct[0], direct[1], o[0].data_ptr(), o[1].data_ptr(),
+                                                                      o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(), status.data_ptr(),
+                                                                      self.ctx.stream()))
+        else:
+            self.ctx.check(self.ctx.lib.zsw_score_ranges_shared_batch_from(self.ctx.h, C.byref(b), from_width, preset, o[0].data_ptr(), o[1].data_ptr(),
+                                                                           o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(), status.data_ptr(),
+                                                                           tier.data_ptr(), self.ctx.stream()))
+        rs, re_, qs, qe = (x[:n] for x in o[1:])
+        if is_query:
+            rs, re_, qs, qe = qs, qe, rs, re_
+        return ScoreBatch(o[0][:n], status[:n], tier=tier[:n] if direct is None else None, ref_start=rs, ref_end=re_, query_start=qs, query_end=qe)
+
+    def _align(self, seq, direct=None, from_width=None, preset=None) -> AlignmentBatch:
+        torch = _torch()
+        reads, is_query = self._reads_of(seq)
+        rb = _as_batch(reads, self.device)
+        self._prep()
+        n, dev = rb.n_reads, rb.bases.device
+        aln = torch.zeros(max(n, 1) * ALN_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        status = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+        tier = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+        cap = max(8 * n, 64)
+        b = rb.c_batch()
+        total = C.c_uint64(0)
+        while True:
+            inc = torch.empty(cap, dtype=torch.int32, device=dev)
+            op = torch.empty(cap, dtype=torch.uint8, device=dev)
+            if direct is not None:
+                rc = self.ctx.lib.zsw_align_shared_batch(self.ctx.h, C.byref(b), direct[0], direct[1], int(is_query), aln.data_ptr(), status.data_ptr(),
+                                                         inc.data_ptr(), op.data_ptr(), cap, C.byref(total), self.ctx.stream())
+            else:
+                rc = self.ctx.lib.zsw_align_shared_batch_from(self.ctx.h, C.byref(b), from_width, preset, int(is_query), aln.data_ptr(), status.data_ptr(),
+                                                              tier.data_ptr(), inc.data_ptr(), op.data_ptr(), cap, C.byref(total), self.ctx.stream())
+            if rc == -1 and total.value > cap:
+                cap = int(total.value)
+                continue
+            self.ctx.check(rc)
+            break
+        torch.cuda.synchronize(dev)
+        t = int(total.value)
+        rec = aln[: n * ALN_DTYPE.itemsize].cpu().numpy().view(ALN_DTYPE)
+        return AlignmentBatch(status[:n].cpu().numpy(), rec, inc[:t].cpu().numpy().view(np.uint32), op[:t].cpu().numpy(),
+                              tier[:n].cpu().numpy() if direct is None else None)
 
 
-def into_shared_profile(reads, matrix: WeightMatrix, gap_open: int, gap_extend: int, device: int = 0) -> SharedProfilesBatch:
-    """Nucleotides::into_shared_profile (nucleotides/mod.rs:295-299): SharedProfiles<32, 16, 8, S>"""
-    return SharedProfilesBatch(reads, matrix, gap_open, gap_extend, preset=256, device=device)
+@dataclass
+class SeqBatchSrc:
+    """SeqSrc (alignment/mod.rs:161-166) over a batch of reads: which role the non-profile sequences play in the results."""
+
+    reads: "object"
+    is_query: bool
+
+    @staticmethod
+    def Reference(reads) -> "SeqBatchSrc":
+        return SeqBatchSrc(reads, False)
+
+    @staticmethod
+    def Query(reads) -> "SeqBatchSrc":
+        return SeqBatchSrc(reads, True)
+
+
+class SharedStripedProfile(_SharedBase):
+    """`StripedProfile::<T, N, S>::new(sequence, &matrix, gap_open, gap_extend)` once, used against every read of a batch
+    (profile.rs:239-306, 440-552): sw_score(reads), sw_score_ends / sw_score_ranges / sw_align(SeqBatchSrc)."""
+
+    def __init__(self, sequence, matrix: WeightMatrix, gap_open: int, gap_extend: int, T: str = "i16", N: int = 16, device: int = 0):
+        if T not in _lib.INT_TYPES:
+            raise ValueError(f"T must be one of {list(_lib.INT_TYPES)}")
+        if T.startswith("u") and matrix.signed:
+            raise ValueError("unsigned T needs matrix.to_biased_matrix() (profile.rs:215-219)")
+        if T.startswith("i") and not matrix.signed:
+            raise ValueError("signed T needs the signed matrix")
+        super().__init__(sequence, matrix, gap_open, gap_extend, device)
+        self.T, self.N = T, N
+
+    def sw_score(self, reads) -> ScoreBatch:
+        torch = _torch()
+        rb = _as_batch(reads, self.device)
+        self._prep()
+        n, dev = rb.n_reads, rb.bases.device
+        score = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        b = rb.c_batch()
+        self.ctx.check(self.ctx.lib.zsw_score_shared_batch(self.ctx.h, C.byref(b), _lib.INT_TYPES[self.T], self.N, score.data_ptr(), status.data_ptr(),
+                                                           self.ctx.stream()))
+        return ScoreBatch(score[:n], status[:n])
+
+    def sw_score_ends(self, seq) -> ScoreBatch:
+        return self._ends(seq, (_lib.INT_TYPES[self.T], self.N))
+
+    def sw_score_ranges(self, seq) -> ScoreBatch:
+        return self._ranges(seq, direct=(_lib.INT_TYPES[self.T], self.N))
+
+    def sw_align(self, seq) -> AlignmentBatch:
+        return self._align(seq, direct=(_lib.INT_TYPES[self.T], self.N))
+
+
+class SharedProfilesBatch(_SharedBase):
+    """`SharedProfiles::new_with_w{128,256,512}(sequence, &matrix, gap_open, gap_extend)` (profile_set.rs:552-700) used against
+    every read of a batch: the i8 -> i16 -> i32 cascade of `sw_score_from_i*`, `sw_score_ranges_from_i*`, `sw_align_from_i*`."""
+
+    def __init__(self, sequence, matrix: WeightMatrix, gap_open: int, gap_extend: int, preset: int = 256, device: int = 0):
+        if not matrix.signed:
+            raise ValueError("profile sets take the signed matrix (profile_set.rs:552-560)")
+        if preset not in (128, 256, 512):
+            raise ValueError("preset must be 128, 256 or 512")
+        super().__init__(sequence, matrix, gap_open, gap_extend, device)
+        self.preset = preset
+
+    @classmethod
+    def new_with_w128(cls, sequence, matrix, gap_open, gap_extend, device=0):
+        return cls(sequence, matrix, gap_open, gap_extend, 128, device)
+
+    @classmethod
+    def new_with_w256(cls, sequence, matrix, gap_open, gap_extend, device=0):
+        return cls(sequence, matrix, gap_open, gap_extend, 256, device)
+
+    @classmethod
+    def new_with_w512(cls, sequence, matrix, gap_open, gap_extend, device=0):
+        return cls(sequence, matrix, gap_open, gap_extend, 512, device)
+
+    def _score_from(self, reads, width: int) -> ScoreBatch:
+        torch = _torch()
+        rb = _as_batch(reads, self.device)
+        self._prep()
+        n, dev = rb.n_reads, rb.bases.device
+        score = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        tier = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        b = rb.c_batch()
+        self.ctx.check(self.ctx.lib.zsw_score_shared_batch_from(self.ctx.h, C.byref(b), width, self.preset, score.data_ptr(), status.data_ptr(),
+                                                                tier.data_ptr(), self.ctx.stream()))
+        return ScoreBatch(score[:n], status[:n], tier=tier[:n])
+
+    def sw_score_from_i8(self, reads) -> ScoreBatch:
+        return self._score_from(reads, 8)
+
+    def sw_score_from_i16(self, reads) -> ScoreBatch:
+        return self._score_from(reads, 16)
+
+    def sw_score_from_i32(self, reads) -> ScoreBatch:
+        return self._score_from(reads, 32)
+
+    def sw_score_ranges_from_i8(self, seq) -> ScoreBatch:
+        return self._ranges(seq, from_width=8, preset=self.preset)
+
+    def sw_score_ranges_from_i16(self, seq) -> ScoreBatch:
+        return self._ranges(seq, from_width=16, preset=self.preset)
+
+    def sw_score_ranges_from_i32(self, seq) -> ScoreBatch:
+        return self._ranges(seq, from_width=32, preset=self.preset)
+
+    def sw_align_from_i8(self, seq) -> AlignmentBatch:
+        return self._align(seq, from_width=8, preset=self.preset)
+
+    def sw_align_from_i16(self, seq) -> AlignmentBatch:
+        return self._align(seq, from_width=16, preset=self.preset)
+
+    def sw_align_from_i32(self, seq) -> AlignmentBatch:
+        return self._align(seq, from_width=32, preset=self.preset)
+
+
+def into_shared_profile(sequence, matrix: WeightMatrix, gap_open: int, gap_extend: int, device: int = 0) -> SharedProfilesBatch:
+    """Nucleotides::into_shared_profile (nucleotides/mod.rs:295-299): SharedProfiles<32, 16, 8, S> of `sequence` (the w256 preset)"""
+    return SharedProfilesBatch(sequence, matrix, gap_open, gap_extend, preset=256, device=device)

@@ -24,12 +24,15 @@
 #include <vector>
 
 #include "zsw_align_dev.hpp"
+#include "zsw_shared.hpp"
 
 namespace zsw {
 
 // Generic form: any nv, DP rows in LDS — or, for profiles too long for one wavefront's LDS (nv above ~250), in a per-block
 // region of HBM behind the flag ring (GLOBAL_ROWS).
-template <int N, bool GLOBAL_ROWS = false>
+// SHARED: the one-profile-many-sequences role (zsw_shared.hpp): the profile of every item is striped over a.prof_seq, the rows
+// are the bases of read i, and every row's flags are kept (W >= the longest read).
+template <int N, bool GLOBAL_ROWS = false, bool SHARED = false>
 __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
     extern __shared__ __align__(16) uint8_t smem_lds[];
     uint8_t* smem = GLOBAL_ROWS ? a.rows + (size_t)blockIdx.x * align_rows_bytes(a.nv) : smem_lds;
@@ -66,15 +69,17 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
         const bool valid = item < a.b.n_items;
         const uint32_t id = valid ? (a.b.items ? a.b.items[item] : item) : 0;
         uint64_t off = 0;
-        const uint32_t len = valid ? read_len(a.b, id, &off) : 0;
-        const bool active = valid && a.status[id] == ZSW_STATUS_SOME && len > 0 && (len + N - 1) / N == nv;
+        const uint32_t rlen = valid ? read_len(a.b, id, &off) : 0;  // the read
+        const uint32_t len = SHARED ? a.prof_len : rlen;            // the sequence the profile is built from
+        const bool active = valid && a.status[id] == ZSW_STATUS_SOME && len > 0 && rlen > 0 && (len + N - 1) / N == nv;
         const int rend = active ? (int)a.ref_end[id] - 1 : -1;
         const int32_t best = active ? (int32_t)a.score[id] : 0;
+        const uint8_t* pbase = SHARED ? a.prof_seq : a.b.bases + off;
 
         // StripedProfile::new_unchecked (profile.rs:270-306): position q = v + lane*nv; padding scores bias (= true 0)
         for (uint32_t v = 0; v < nv; ++v) {
             const uint32_t q = v + (uint32_t)li * nv;
-            kq[v * 64 + lane] = (active && q < len) ? lut[a.b.bases[off + q]] : (uint8_t)S;
+            kq[v * 64 + lane] = (active && q < len) ? lut[pbase[q]] : (uint8_t)S;
             Hs[v * 64 + lane] = 0;
             Es[v * 64 + lane] = 0;
         }
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
 
         for (int r = r0; r <= rmax; ++r) {
             const bool act = r <= rend;
-            const int ri = lut[a.ref[r]];
+            const int ri = lut[SHARED ? (act ? a.b.bases[off + (uint32_t)r] : (uint8_t)0) : a.ref[r]];
             const int32_t* wrow = wpad + ri * (S + 1);
             // main pass (striped.rs:481-526)
             int32_t F = 0;
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
                 return __hip_atomic_load(ring + (size_t)(rr % (int)a.W) * row_bytes + (size_t)(cc % (int)nv) * N + (size_t)(cc / (int)nv),
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
-            traceback_emit(a, id, item, len, rend, cend, best, cell, (int)a.W);
+            traceback_emit(a, id, item, len, rend, cend, best, cell, (int)a.W, SHARED ? rlen : a.ref_len);
         }
     }
 }
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(64) void align_kernel_x(AlignArgs a) {
                 return __hip_atomic_load(ring + (size_t)(rr % W) * row_bytes + (size_t)(cc / nv) * (size_t)NVQ * 4 + (size_t)(cc % nv),
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
-            traceback_emit(a, id, item, len, rend, cend, best, cell, (int)a.W);
+            traceback_emit(a, id, item, len, rend, cend, best, cell, (int)a.W, a.ref_len);
         }
     }
 }
@@ -609,6 +614,8 @@ hipError_t align_pass2(int N, uint32_t nv, const BatchDev& b, const uint8_t* d_r
     (void)d_safe_row;  // the 32-bit kernels keep the warm-up bound (they serve the reruns and the odd groups)
     AlignArgs a;
     a.safe_row = nullptr;
+    a.prof_seq = nullptr;
+    a.prof_len = 0;
     a.b = b;
     a.ref = d_ref;
     a.ref_len = ref_len;
@@ -646,6 +653,70 @@ size_t align_ring_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid) {
     if (nv > 32 && align_rows_bytes(nv) > ALIGN_LDS_LIMIT) bytes += (size_t)grid * align_rows_bytes(nv);
     return bytes;
 }
+// ---- the one-profile-many-sequences role (zsw_shared.hpp): generic kernel, rows in LDS or behind the ring ----
+size_t align_shared_ring_bytes(int N, uint32_t plen, uint32_t W, uint32_t grid, int S) {
+    const uint32_t nv = (plen + (uint32_t)N - 1) / (uint32_t)N;
+    size_t bytes = ((size_t)grid * (64 / N) * (size_t)W * ((size_t)N * nv) + 255) / 256 * 256;
+    if (align_lds_bytes(nv, S) > ALIGN_LDS_LIMIT) bytes += (size_t)grid * align_rows_bytes(nv);
+    return bytes;
+}
+
+template <int N>
+static hipError_t launch_align_shared_n(const AlignArgs& a, int S, uint32_t grid, hipStream_t stream) {
+    if (align_lds_bytes(a.nv, S) > ALIGN_LDS_LIMIT) {
+        hipLaunchKernelGGL((align_kernel<N, true, true>), dim3(grid), dim3(64), 0, stream, a);
+        return hipGetLastError();
+    }
+    return launch_with_lds(&align_kernel<N, false, true>, a, grid, align_lds_bytes(a.nv, S), stream);
+}
+
+hipError_t align_pass2_shared(int N, const uint8_t* d_pseq, uint32_t plen, const BatchDev& b, const ScoringDev* d_sc, int S,
+                              const uint32_t* d_score, const uint32_t* d_ref_end, const uint8_t* d_status, uint32_t W, uint32_t maxc,
+                              uint8_t* d_ring, uint32_t grid, uint32_t* d_cig, uint64_t pool_base, int by_item, uint64_t* d_cig_start,
+                              uint32_t* d_cig_raw, zsw_alignment* d_aln, uint32_t* d_fb_list, uint32_t* d_fb_count, int invert,
+                              hipStream_t stream) {
+    const uint32_t nv = (plen + (uint32_t)N - 1) / (uint32_t)N;
+    AlignArgs a;
+    a.b = b;
+    a.ref = nullptr;
+    a.ref_len = 0;
+    a.sc = d_sc;
+    a.score = d_score;
+    a.ref_end = d_ref_end;
+    a.status = d_status;
+    a.nv = nv;
+    a.W = W;
+    a.maxc = maxc;
+    a.ring = d_ring;
+    a.cig = d_cig;
+    a.pool_base = pool_base;
+    a.by_item = by_item;
+    a.cig_start = d_cig_start;
+    a.cig_raw = d_cig_raw;
+    a.aln = d_aln;
+    a.fb_list = d_fb_list;
+    a.fb_count = d_fb_count;
+    a.invert = invert;
+    a.safe_row = nullptr;
+    a.prof_seq = d_pseq;
+    a.prof_len = plen;
+    a.rows = align_lds_bytes(nv, S) > ALIGN_LDS_LIMIT
+                 ? d_ring + ((size_t)grid * (64 / N) * (size_t)W * ((size_t)N * nv) + 255) / 256 * 256
+                 : nullptr;
+    a.next_item = d_fb_count + 1;
+    hipError_t ce = hipMemsetAsync(a.next_item, 0, 4, stream);
+    if (ce != hipSuccess) return ce;
+    switch (N) {
+        case 2: return launch_align_shared_n<2>(a, S, grid, stream);
+        case 4: return launch_align_shared_n<4>(a, S, grid, stream);
+        case 8: return launch_align_shared_n<8>(a, S, grid, stream);
+        case 16: return launch_align_shared_n<16>(a, S, grid, stream);
+        case 32: return launch_align_shared_n<32>(a, S, grid, stream);
+        case 64: return launch_align_shared_n<64>(a, S, grid, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
 // ---- packed kernel (zsw_align_pk{8,16,32,64}.hip) ----
 hipError_t align_pk_occupancy_8(uint32_t nv, size_t lds, int* blocks_per_cu);
 hipError_t align_pk_occupancy_16(uint32_t nv, size_t lds, int* blocks_per_cu);
@@ -686,6 +757,8 @@ hipError_t align_pass2_pk(int N, uint32_t nv, const BatchDev& b, const uint8_t* 
                           uint32_t* d_fb_count, int invert, hipStream_t stream, const uint32_t* d_safe_row) {
     AlignArgs a;
     a.safe_row = d_safe_row;
+    a.prof_seq = nullptr;
+    a.prof_len = 0;
     a.b = b;
     a.ref = d_ref;
     a.ref_len = ref_len;

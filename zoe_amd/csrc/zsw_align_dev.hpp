@@ -32,6 +32,10 @@ struct AlignArgs {
     // optional, per read: the row from which the recompute may start with a zero state (seed_safe_start, zsw_seed.hpp: the
     // first pass's k-mer certificate), 0xffffffff = none: the warm-up bound below applies
     const uint32_t* safe_row;
+    // SHARED kernels (one profile, many sequences: zsw_shared.hpp): the profile is striped over prof_seq for every item and the
+    // rows are the bases of read i; null otherwise
+    const uint8_t* prof_seq;
+    uint32_t prof_len;
 };
 
 // Late start of pass 2. The state after row r (the H and E rows) is a (max,+) function of earlier rows in which every
@@ -89,7 +93,7 @@ __device__ __forceinline__ uint32_t read_len(const BatchDev& b, uint32_t id, uin
 // run by one lane per read. `cell(r, c)` returns the flag byte of DP cell (r, c) from the retained window.
 template <typename CellFn>
 __device__ __forceinline__ void traceback_emit(const AlignArgs& a, uint32_t id, uint32_t item, uint32_t len, int rend, int cend,
-                                               int32_t best, CellFn cell, int window) {
+                                               int32_t best, CellFn cell, int window, uint32_t ref_len) {
     const uint64_t slot0 = a.pool_base + (uint64_t)(a.by_item ? item : id) * a.maxc;
     uint32_t* cig = a.cig + slot0;
     uint32_t ncig = 0, cur_op = 0, cur_inc = 0;
@@ -154,10 +158,10 @@ __device__ __forceinline__ void traceback_emit(const AlignArgs& a, uint32_t id, 
         out.ref_end = (uint32_t)r_end1;
         out.query_start = (uint32_t)c;
         out.query_end = (uint32_t)c_end1;
-        out.ref_len = a.ref_len;
+        out.ref_len = ref_len;
         out.query_len = len;
         // forward count; inverted: clips re-derived from ref_range (output.rs:399-414)
-        out.n_ciglets = a.invert ? n_nons + (r > 0 ? 1u : 0u) + (a.ref_len > (uint32_t)r_end1 ? 1u : 0u) : ncig;
+        out.n_ciglets = a.invert ? n_nons + (r > 0 ? 1u : 0u) + (ref_len > (uint32_t)r_end1 ? 1u : 0u) : ncig;
         out.ciglet_offset = 0;  // filled by write_ciglets_kernel
         a.aln[id] = out;
         a.cig_start[id] = (uint64_t)(uintptr_t)cig;

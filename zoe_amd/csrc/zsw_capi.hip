@@ -1,155 +1,17 @@
 // zsw_capi.hip — the C ABI (include/zoe_sw.h): context, scoring/reference upload, batched entry points.
-#include <stdio.h>
-#include <string.h>
-
-#include <algorithm>
 #include <map>
 #include <new>
 #include <utility>
-#include <vector>
 
-#include "zsw_align.hpp"
-#include "zsw_internal.hpp"
-#include "zsw_score_prune.hpp"
-#include "zsw_score_seed.hpp"
+#include "zsw_context.hpp"
 #include "zsw_synth.h"
-#include "zsw_timer.hpp"
 
 using namespace zsw;
+using namespace zsw::capi;
 
-namespace {
+namespace zsw {
+namespace capi {
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = bytes + bytes / 4 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    template <typename T> T* as() { return reinterpret_cast<T*>(p); }
-};
-
-}  // namespace
-
-struct zsw_context {
-    int device = 0;
-    uint32_t cu_count = 256;
-    bool scoring_set = false, reference_set = false;
-    ScoringDev h_sc{};
-    int bias = 0;
-    DevBuf d_sc, d_ref, d_fb_list, d_fb_count, d_scratch, d_maxlen, d_bucket_items, d_bucket_counts, d_tile_buf, d_tile_state;
-    DevBuf d_prune, d_prune_list, d_prune_count;  // column-pruned score pass; the worklist and its counters also serve the seeded pass
-    uint32_t prune_chunk = 0;
-    // seeded exact score pass (zsw_score_seed.hip): index of the reference under the current matrix (built with the first batch
-    // that can use it, rebuilt after zsw_set_scoring / zsw_set_reference), a host copy of the reference to build it from
-    SeedIndex seed;
-    std::vector<uint8_t> h_ref;
-    DevBuf d_seed_work, d_seed_gtab;
-    bool seed_ready = false;  // this call's batch takes the seeded pass (workspace and worklist are in place)
-    size_t ref_len = 0;
-    uint32_t scratch_len = 0;
-    size_t exact_slots = 0;
-    // staging for host-memory batches
-    DevBuf s_bases, s_offsets, s_score, s_status, s_tier, s_rend, s_qend;
-    // alignment workspace (zsw_align.hip)
-    DevBuf a_ws[30];
-    // score_ranges workspace
-    DevBuf r_ws[20];
-    KernelTimer timer;
-    KernelTimer timer_window;  // seed_window_kernel launches alone
-    std::string err;
-    uint32_t debug = 0;    // zsw_debug_set (kernel-selection overrides for tests)
-    uint32_t options = ZSW_DEBUG_SCORE_PRUNE;  // zsw_set_option, as ZSW_DEBUG_* bits; exact pruning is on by default
-    uint32_t flags() const { return debug | options; }
-    // host batches: reads of chunk k+1 cross PCIe on this stream while chunk k computes
-    hipStream_t copy_stream = nullptr;
-    std::vector<hipEvent_t> copy_events;
-    // ragged batches: the length classes run on these (created with the first ragged batch)
-    SideStreams* side = nullptr;
-};
-
-namespace {
-
-constexpr size_t EXACT_SLOTS = 64 * 256;               // rows of the exact 32-bit kernel that run at once, at most
-constexpr size_t EXACT_SCRATCH_BUDGET = size_t(1) << 30;  // bytes of its H/E rows, at most (longer reads get fewer slots)
-constexpr uint32_t LONGEST_STRIP = 64 * 38;  // columns of the widest strip configuration (zsw_score_v2.hpp)
-
-zsw_error fail(zsw_context* ctx, zsw_error code, const char* what, hipError_t e = hipSuccess) {
-    if (ctx) {
-        ctx->err = what;
-        if (e != hipSuccess) {
-            ctx->err += ": ";
-            ctx->err += hipGetErrorString(e);
-        }
-    }
-    return code;
-}
-
-// Makes the context's GPU current for the duration of a public call and puts the caller's device back afterwards: a
-// single-process multi-GPU host (zsw_group, or PyTorch with several devices) must not find its current device changed.
-struct DeviceGuard {
-    int prev = -1;
-    explicit DeviceGuard(const zsw_context* ctx) {
-        if (!ctx) return;
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != ctx->device) (void)hipSetDevice(ctx->device);
-        else prev = -1;  // nothing to restore
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-    DeviceGuard(const DeviceGuard&) = delete;
-    DeviceGuard& operator=(const DeviceGuard&) = delete;
-};
-
-#define ZSW_HIP(ctx, call)                                                     \
-    do {                                                                       \
-        hipError_t _e = (call);                                                \
-        if (_e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, #call, _e);        \
-    } while (0)
-
-bool valid_lanes(int lanes) { return lanes == 2 || lanes == 4 || lanes == 8 || lanes == 16 || lanes == 32 || lanes == 64; }
-
-uint64_t signed_thr(int bits) { return bits == 8 ? 255ull : bits == 16 ? 65535ull : 4294967295ull; }
-
-// score_to_maybe_aligned (striped.rs:610-633) as a threshold on the true score:
-//   signed T  : Overflowed  <=>  best >= T::MAX            <=>  s >= 2^bits - 1
-//   unsigned T: Overflowed  <=>  best + bias + 1 > T::MAX  <=>  s >= T::MAX - bias
-bool rule_direct(zsw_int_type t, int bias, ResultRule* r) {
-    r->n_tiers = 1;
-    switch (t) {
-        case ZSW_I8: r->thr[0] = signed_thr(8); r->tier_code[0] = 8; return true;
-        case ZSW_I16: r->thr[0] = signed_thr(16); r->tier_code[0] = 16; return true;
-        case ZSW_I32: r->thr[0] = signed_thr(32); r->tier_code[0] = 32; return true;
-        case ZSW_U8: r->thr[0] = 255ull - (uint64_t)bias; r->tier_code[0] = 8; return bias < 255;
-        case ZSW_U16: r->thr[0] = 65535ull - (uint64_t)bias; r->tier_code[0] = 16; return true;
-        case ZSW_U32: r->thr[0] = 4294967295ull - (uint64_t)bias; r->tier_code[0] = 32; return true;
-    }
-    return false;
-}
-
-// or_else_overflowed chain (profile_set.rs:71-107): i8 -> i16 -> i32 from `from_width`
-bool rule_cascade(int from_width, ResultRule* r) {
-    if (from_width != 8 && from_width != 16 && from_width != 32) return false;
-    r->n_tiers = 0;
-    for (int w = from_width; w <= 32; w *= 2) {
-        r->thr[r->n_tiers] = signed_thr(w);
-        r->tier_code[r->n_tiers] = (uint8_t)w;
-        ++r->n_tiers;
-    }
-    return true;
-}
 
 __global__ void maxlen_kernel(const uint64_t* offsets, uint32_t n, uint32_t* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -186,20 +48,12 @@ __global__ void selftest_kernel(uint32_t* out) {
     out[192 + lane] = __builtin_bit_cast(uint32_t, d);
 }
 
-struct Staged {
-    BatchDev b{};
-    uint32_t max_len = 0;
-    uint32_t* d_score = nullptr;
-    uint8_t* d_status = nullptr;
-    uint8_t* d_tier = nullptr;
-    uint32_t* d_rend = nullptr;
-    uint32_t* d_qend = nullptr;
-};
+
 
 // Brings a batch to the device (or validates device pointers), finds the longest read and sizes the workspace.
 zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bool want_tier, bool want_ends,
                 uint32_t* out_score, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_rend, uint32_t* out_qend,
-                Staged* st, bool defer_bases_copy = false) {
+                Staged* st, bool defer_bases_copy) {
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     if (!ctx->scoring_set || !ctx->reference_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "scoring/reference not set");
     if (!reads || !out_score || !out_status) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
@@ -290,7 +144,7 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     ctx->seed_ready = false;
     const uint32_t flags = ctx->flags();
     const bool any_size = (flags & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE) != 0;
-    if ((flags & ZSW_DEBUG_SCORE_PRUNE) && !(flags & ZSW_DEBUG_PRUNE_STRIP) && n > 0 && (n >= SEED_MIN_READS || any_size) && ctx->ref_len > 0 &&
+    if (!ctx->shared_call && (flags & ZSW_DEBUG_SCORE_PRUNE) && !(flags & ZSW_DEBUG_PRUNE_STRIP) && n > 0 && (n >= SEED_MIN_READS || any_size) && ctx->ref_len > 0 &&
         st->max_len >= SEED_MIN_LEN) {
         // the seeded exact pass: index of the reference (first use after a change of reference or matrix), 20 bytes of workspace
         // per read and the worklist of the reads it hands back. If the device cannot spare them the full pass runs.
@@ -309,7 +163,7 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
             }
         }
     }
-    if ((flags & ZSW_DEBUG_SCORE_PRUNE) && (flags & ZSW_DEBUG_PRUNE_STRIP) && n > 0 && (n >= PR_MIN_READS || any_size) &&
+    if (!ctx->shared_call && (flags & ZSW_DEBUG_SCORE_PRUNE) && (flags & ZSW_DEBUG_PRUNE_STRIP) && n > 0 && (n >= PR_MIN_READS || any_size) &&
         ctx->ref_len > 0 && (reads->offsets ? st->max_len > 64 : prune_class_for(st->max_len) >= 0)) {
         const uint32_t chunk = prune_chunk_reads((uint32_t)n, (uint32_t)ctx->ref_len);
         // a reference so long that the boundary streams of a round's reads no longer fill the chip: the full pass
@@ -472,8 +326,6 @@ __global__ void ranges_combine_kernel(uint32_t n, const uint32_t* fscore, const 
     out_qe[i] = some ? fqend[i] : 0;
 }
 
-enum { RW_FSCORE = 0, RW_FSTATUS, RW_FREND, RW_FQEND, RW_RSCORE, RW_RSTATUS, RW_RRS, RW_RQS, RW_QEM, RW_GTAB, RW_MIS, RW_O0, RW_O1,
-       RW_O2, RW_O3, RW_O4, RW_O5, RW_FTIER };
 
 struct RangesDev {  // device arrays of sw_simd_score_ranges for every read (library workspace)
     uint32_t *score, *rs, *re, *qs, *qe;
@@ -559,9 +411,6 @@ zsw_error run_ranges(zsw_context* ctx, const zsw_batch* reads, const ResultRule&
     return ZSW_OK;
 }
 
-enum { WS_SCORE = 0, WS_STATUS, WS_TIER, WS_REND, WS_ITEMS, WS_RING, WS_CIG, WS_ALN, WS_CIGSTART, WS_CIGRAW, WS_BSUMS, WS_TOTAL,
-       WS_FBLIST, WS_FBCOUNT, WS_OINC, WS_OOP, WS_CIG2, WS_RING2, WS_KEYS_IN, WS_KEYS_OUT, WS_VALS_IN, WS_SORT_TMP, WS_GTABLE, WS_FBMETA,
-       WS_ITEMS2, WS_SAFE };
 
 __global__ void count_some_kernel(const uint8_t* status, uint32_t n, uint32_t* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -936,7 +785,23 @@ zsw_error run_threepass(zsw_context* ctx, const zsw_batch* reads, const ResultRu
                              out_n_ciglets, stream);
 }
 
-}  // namespace
+hipError_t launch_ranges_prep(uint32_t n, const uint8_t* fstatus, const uint32_t* fqend, uint32_t* qe_masked, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(ranges_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, fstatus, fqend, qe_masked);
+    return hipGetLastError();
+}
+
+hipError_t launch_ranges_combine(uint32_t n, const uint32_t* fscore, const uint8_t* fstatus, const uint32_t* frend, const uint32_t* fqend,
+                                 const uint32_t* rscore, const uint8_t* rstatus, const uint32_t* rrstart, const uint32_t* rqstart,
+                                 uint32_t* out_score, uint32_t* out_rs, uint32_t* out_re, uint32_t* out_qs, uint32_t* out_qe,
+                                 uint8_t* out_status, uint32_t* mismatch, hipStream_t stream) {
+    if (n)
+        hipLaunchKernelGGL(ranges_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, fscore, fstatus, frend, fqend, rscore, rstatus,
+                           rrstart, rqstart, out_score, out_rs, out_re, out_qs, out_qe, out_status, mismatch);
+    return hipGetLastError();
+}
+
+}  // namespace capi
+}  // namespace zsw
 
 extern "C" {
 
@@ -1013,11 +878,12 @@ void zsw_destroy(zsw_context* ctx) {
     DeviceGuard device_guard(ctx);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state, &ctx->d_prune, &ctx->d_prune_list, &ctx->d_prune_count, &ctx->d_seed_work, &ctx->d_seed_gtab,
+    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state, &ctx->d_prune, &ctx->d_prune_list, &ctx->d_prune_count, &ctx->d_seed_work, &ctx->d_seed_gtab, &ctx->d_pseq, &ctx->d_sc_t,
                       &ctx->s_bases, &ctx->s_offsets, &ctx->s_score, &ctx->s_status, &ctx->s_tier, &ctx->s_rend, &ctx->s_qend};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->a_ws) b.release();
     for (DevBuf& b : ctx->r_ws) b.release();
+    for (DevBuf& b : ctx->sh_ws) b.release();
     seed_index_release(&ctx->seed);
     ctx->timer.destroy();
     ctx->timer_window.destroy();
@@ -1065,6 +931,13 @@ zsw_error zsw_set_scoring(zsw_context* ctx, const int8_t* weights, int S, const 
     if (ctx->scoring_set) ZSW_HIP(ctx, hipDeviceSynchronize());
     ZSW_HIP(ctx, ctx->d_sc.ensure(sizeof(ScoringDev)));
     ZSW_HIP(ctx, hipMemcpy(ctx->d_sc.p, &s, sizeof(ScoringDev), hipMemcpyHostToDevice));
+    {  // the same scoring with the matrix transposed, for the score-only calls of the shared-profile role
+        ScoringDev t = s;
+        for (int r = 0; r < S; ++r)
+            for (int q = 0; q < S; ++q) t.w[r * S + q] = s.w[q * S + r];
+        ZSW_HIP(ctx, ctx->d_sc_t.ensure(sizeof(ScoringDev)));
+        ZSW_HIP(ctx, hipMemcpy(ctx->d_sc_t.p, &t, sizeof(ScoringDev), hipMemcpyHostToDevice));
+    }
     ctx->scoring_set = true;
     ctx->seed.valid = false;  // the index spells k-mers with the matrix's good residues
     return ZSW_OK;

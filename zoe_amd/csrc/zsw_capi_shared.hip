@@ -1,0 +1,400 @@
+// zsw_capi_shared.hip — C ABI of the one-profile-many-sequences role (include/zoe_sw.h, "shared profile" section):
+// zsw_set_profile_sequence and the *_shared_batch entry points. The profile is built from the sequence the context holds
+// (Nucleotides::into_shared_profile, nucleotides/mod.rs:295-299; SharedProfiles, profile_set.rs:552-560) and read i is the
+// sequence it is aligned against (sw/mod.rs:63-67), row by row. Kernels: zsw_shared.hip (score + ends, ranges),
+// align_kernel<N, ., SHARED> (zsw_align.hip); the score-only calls swap the roles and use the ordinary kernels with the
+// transposed matrix (the score of a pair does not depend on which sequence the profile is built from).
+#include <map>
+#include <utility>
+
+#include "zsw_context.hpp"
+
+using namespace zsw;
+using namespace zsw::capi;
+
+namespace {
+
+enum { SH_SCORE = 0, SH_STATUS, SH_TIER, SH_REND, SH_QEND, SH_QEM, SH_RSCORE, SH_RSTATUS, SH_RRS, SH_RQS, SH_MIS, SH_LIST };
+
+__global__ void empty_is_unmapped_kernel(uint32_t n, uint8_t* status) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // an empty read is an empty `reference` here: sw_simd_score returns Unmapped (striped.rs:219-221), not a profile error
+    if (i < n && status[i] == ZSW_STATUS_EMPTY) status[i] = ZSW_STATUS_UNMAPPED;
+}
+
+__global__ void iota_some_kernel(uint32_t n, const uint8_t* status, const uint8_t* tier, uint8_t want_tier, uint32_t* list, uint32_t* count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool take = i < n && status[i] == ZSW_STATUS_SOME && tier[i] == want_tier;
+    const unsigned long long m = __ballot(take);
+    if (m) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (take) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    }
+}
+
+zsw_error check_shared(zsw_context* ctx) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!ctx->scoring_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "scoring not set");
+    if (!ctx->pseq_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "profile sequence not set (zsw_set_profile_sequence)");
+    return ZSW_OK;
+}
+
+// stage() wants a reference: the shared calls have none of their own, the profile sequence stands in (its length sizes nothing
+// that matters here) — and the seeded pass must stay off: its index describes the reference.
+struct SharedStage {
+    zsw_context* ctx;
+    bool ref_was_set;
+    size_t ref_len;
+    explicit SharedStage(zsw_context* c) : ctx(c), ref_was_set(c->reference_set), ref_len(c->ref_len) {
+        ctx->shared_call = true;
+        ctx->reference_set = true;
+        if (!ref_was_set) ctx->ref_len = ctx->pseq_len;
+    }
+    ~SharedStage() {
+        ctx->shared_call = false;
+        ctx->reference_set = ref_was_set;
+        ctx->ref_len = ref_len;
+    }
+};
+
+// score + ends of every read against the shared profile, on the device
+zsw_error shared_ends_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, const ScoreOut& out, hipStream_t stream) {
+    if (st.max_len > shared_max_rows()) return fail(ctx, ZSW_ERR_UNSUPPORTED, "read too long for the shared-profile kernels");
+    hipError_t e = launch_shared_ends(st.b, std::max<uint32_t>(st.max_len, 1), ctx->d_pseq.as<uint8_t>(), (uint32_t)ctx->pseq_len,
+                                      ctx->d_sc.as<ScoringDev>(), rule, out, nullptr, nullptr, stream);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "shared ends kernel", e);
+    return ZSW_OK;
+}
+
+zsw_error run_score_shared(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, uint32_t* out_score, uint8_t* out_status,
+                           uint8_t* out_tier, void* stream_) {
+    zsw_error ze = check_shared(ctx);
+    if (ze != ZSW_OK) return ze;
+    DeviceGuard device_guard(ctx);
+    hipStream_t stream = (hipStream_t)stream_;
+    SharedStage guard(ctx);
+    Staged st;
+    ze = stage(ctx, reads, stream, out_tier != nullptr, false, out_score, out_status, out_tier, nullptr, nullptr, &st);
+    if (ze != ZSW_OK) return ze;
+    if (reads->n_reads == 0) return ZSW_OK;
+    // roles swapped: the read is the profile of the ordinary kernels, the shared sequence their reference, the matrix transposed
+    ScoringDev h_t = ctx->h_sc;
+    for (int r = 0; r < h_t.S; ++r)
+        for (int q = 0; q < h_t.S; ++q) h_t.w[r * h_t.S + q] = ctx->h_sc.w[q * h_t.S + r];
+    ScoreOut out;
+    out.score = st.d_score;
+    out.status = st.d_status;
+    out.tier = st.d_tier;
+    out.ref_end = nullptr;
+    out.query_end = nullptr;
+    out.fb_list = ctx->d_fb_list.as<uint32_t>();
+    out.fb_count = ctx->d_fb_count.as<uint32_t>();
+    hipError_t e = launch_score(ctx->d_sc_t.as<ScoringDev>(), h_t, st.b, st.max_len, ctx->d_pseq.as<uint8_t>(), (uint32_t)ctx->pseq_len, rule, out,
+                                score_ws(ctx), stream, &ctx->timer, 0);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "shared score launch", e);
+    const uint32_t n = (uint32_t)reads->n_reads;
+    hipLaunchKernelGGL(empty_is_unmapped_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, st.d_status);
+    return unstage(ctx, reads, stream, st, out_score, out_status, out_tier, nullptr, nullptr);
+}
+
+zsw_error run_ends_shared(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, uint32_t* out_score, uint32_t* out_rend,
+                          uint32_t* out_qend, uint8_t* out_status, void* stream_) {
+    zsw_error ze = check_shared(ctx);
+    if (ze != ZSW_OK) return ze;
+    if (!out_rend || !out_qend) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard device_guard(ctx);
+    hipStream_t stream = (hipStream_t)stream_;
+    SharedStage guard(ctx);
+    Staged st;
+    ze = stage(ctx, reads, stream, false, true, out_score, out_status, nullptr, out_rend, out_qend, &st);
+    if (ze != ZSW_OK) return ze;
+    if (reads->n_reads == 0) return ZSW_OK;
+    ScoreOut out;
+    out.score = st.d_score;
+    out.status = st.d_status;
+    out.tier = nullptr;
+    out.ref_end = st.d_rend;
+    out.query_end = st.d_qend;
+    out.fb_list = nullptr;
+    out.fb_count = nullptr;
+    ctx->timer.begin(stream);
+    ze = shared_ends_device(ctx, st, rule, out, stream);
+    ctx->timer.end(stream);
+    if (ze != ZSW_OK) return ze;
+    return unstage(ctx, reads, stream, st, out_score, out_status, nullptr, out_rend, out_qend);
+}
+
+zsw_error run_ranges_shared(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, uint32_t* out_score, uint32_t* out_rs,
+                            uint32_t* out_re, uint32_t* out_qs, uint32_t* out_qe, uint8_t* out_status, uint8_t* out_tier, void* stream_) {
+    zsw_error ze = check_shared(ctx);
+    if (ze != ZSW_OK) return ze;
+    if (!reads || !out_score || !out_rs || !out_re || !out_qs || !out_qe || !out_status) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard device_guard(ctx);
+    hipStream_t stream = (hipStream_t)stream_;
+    SharedStage guard(ctx);
+    Staged st;
+    {
+        uint32_t dummy_score = 0;
+        uint8_t dummy_status = 0;
+        ze = stage(ctx, reads, stream, false, false, &dummy_score, &dummy_status, nullptr, nullptr, nullptr, &st);
+        if (ze != ZSW_OK) return ze;
+    }
+    const uint32_t n = (uint32_t)reads->n_reads;
+    if (n == 0) return ZSW_OK;
+    DevBuf* ws = ctx->sh_ws;
+    DevBuf* rw = ctx->r_ws;  // the output arrays of the ordinary ranges path
+    for (int k : {SH_SCORE, SH_REND, SH_QEND, SH_QEM, SH_RSCORE, SH_RRS, SH_RQS}) ZSW_HIP(ctx, ws[k].ensure((size_t)n * 4 + 4));
+    for (int k : {SH_STATUS, SH_TIER, SH_RSTATUS}) ZSW_HIP(ctx, ws[k].ensure((size_t)n + 4));
+    ZSW_HIP(ctx, ws[SH_MIS].ensure(4));
+    for (int k : {RW_O0, RW_O1, RW_O2, RW_O3, RW_O4}) ZSW_HIP(ctx, rw[k].ensure((size_t)n * 4 + 4));
+    ZSW_HIP(ctx, rw[RW_O5].ensure((size_t)n + 4));
+    ScoreOut fo;
+    fo.score = ws[SH_SCORE].as<uint32_t>();
+    fo.status = ws[SH_STATUS].as<uint8_t>();
+    fo.tier = ws[SH_TIER].as<uint8_t>();
+    fo.ref_end = ws[SH_REND].as<uint32_t>();
+    fo.query_end = ws[SH_QEND].as<uint32_t>();
+    fo.fb_list = nullptr;
+    fo.fb_count = nullptr;
+    ctx->timer.begin(stream);
+    ze = shared_ends_device(ctx, st, rule, fo, stream);
+    if (ze != ZSW_OK) return ze;
+    // reverse pass on the prefixes the forward pass found (reads without an alignment take part with empty prefixes)
+    ZSW_HIP(ctx, launch_ranges_prep(n, fo.status, fo.query_end, ws[SH_QEM].as<uint32_t>(), stream));
+    ScoreOut ro;
+    ro.score = ws[SH_RSCORE].as<uint32_t>();
+    ro.status = ws[SH_RSTATUS].as<uint8_t>();
+    ro.tier = nullptr;
+    ro.ref_end = ws[SH_RRS].as<uint32_t>();
+    ro.query_end = ws[SH_RQS].as<uint32_t>();
+    ro.fb_list = nullptr;
+    ro.fb_count = nullptr;
+    hipError_t e = launch_shared_ends(st.b, std::max<uint32_t>(st.max_len, 1), ctx->d_pseq.as<uint8_t>(), (uint32_t)ctx->pseq_len,
+                                      ctx->d_sc.as<ScoringDev>(), rule, ro, fo.ref_end, ws[SH_QEM].as<uint32_t>(), stream);
+    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "shared ranges reverse pass", e);
+    ZSW_HIP(ctx, hipMemsetAsync(ws[SH_MIS].p, 0, 4, stream));
+    ZSW_HIP(ctx, launch_ranges_combine(n, fo.score, fo.status, fo.ref_end, fo.query_end, ro.score, ro.status, ro.ref_end, ro.query_end,
+                                       rw[RW_O0].as<uint32_t>(), rw[RW_O1].as<uint32_t>(), rw[RW_O2].as<uint32_t>(), rw[RW_O3].as<uint32_t>(),
+                                       rw[RW_O4].as<uint32_t>(), rw[RW_O5].as<uint8_t>(), ws[SH_MIS].as<uint32_t>(), stream));
+    ctx->timer.end(stream);
+    const hipMemcpyKind kind = reads->mem == ZSW_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    uint32_t* outs[5] = {out_score, out_rs, out_re, out_qs, out_qe};
+    const int devs[5] = {RW_O0, RW_O1, RW_O2, RW_O3, RW_O4};
+    for (int k = 0; k < 5; ++k) ZSW_HIP(ctx, hipMemcpyAsync(outs[k], rw[devs[k]].p, (size_t)n * 4, kind, stream));
+    ZSW_HIP(ctx, hipMemcpyAsync(out_status, rw[RW_O5].p, n, kind, stream));
+    if (out_tier) ZSW_HIP(ctx, hipMemcpyAsync(out_tier, fo.tier, n, kind, stream));
+    if (reads->mem == ZSW_MEM_HOST) ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    return ZSW_OK;
+}
+
+zsw_error run_align_shared(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, int lanes_w8, int lanes_w16, int lanes_w32, int invert,
+                           zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap,
+                           uint64_t* out_n_ciglets, void* stream_) {
+    zsw_error ze = check_shared(ctx);
+    if (ze != ZSW_OK) return ze;
+    if (!reads || !out_aln || !out_status || !out_n_ciglets || (ciglet_cap && (!out_inc || !out_op)))
+        return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard device_guard(ctx);
+    hipStream_t stream = (hipStream_t)stream_;
+    SharedStage guard(ctx);
+    Staged st;
+    {
+        uint32_t dummy_score = 0;
+        uint8_t dummy_status = 0;
+        ze = stage(ctx, reads, stream, false, false, &dummy_score, &dummy_status, nullptr, nullptr, nullptr, &st);
+        if (ze != ZSW_OK) return ze;
+    }
+    const uint32_t n = (uint32_t)reads->n_reads;
+    *out_n_ciglets = 0;
+    if (n == 0) return ZSW_OK;
+    const bool host = reads->mem == ZSW_MEM_HOST;
+    DevBuf* ws = ctx->a_ws;
+    ZSW_HIP(ctx, ws[WS_SCORE].ensure((size_t)n * 4 + 4));
+    ZSW_HIP(ctx, ws[WS_STATUS].ensure((size_t)n + 4));
+    ZSW_HIP(ctx, ws[WS_TIER].ensure((size_t)n + 4));
+    ZSW_HIP(ctx, ws[WS_REND].ensure((size_t)n * 4 + 4));
+    // pass 1: score, first row of the read holding it (sw_simd_align's `best` and `r_end`, striped.rs:449-598)
+    ScoreOut so;
+    so.score = ws[WS_SCORE].as<uint32_t>();
+    so.status = ws[WS_STATUS].as<uint8_t>();
+    so.tier = ws[WS_TIER].as<uint8_t>();
+    so.ref_end = ws[WS_REND].as<uint32_t>();
+    so.query_end = nullptr;
+    so.fb_list = nullptr;
+    so.fb_count = nullptr;
+    ze = shared_ends_device(ctx, st, rule, so, stream);
+    if (ze != ZSW_OK) return ze;
+    // pass 2 per tier (each tier of the cascade has its own lane count, hence its own striping of the shared sequence)
+    const int S = ctx->h_sc.S;
+    const uint32_t plen = (uint32_t)ctx->pseq_len;
+    const uint32_t MAXC = 32;
+    const uint32_t W = std::max<uint32_t>(st.max_len, 1);
+    ZSW_HIP(ctx, ws[WS_ALN].ensure((size_t)n * sizeof(zsw_alignment)));
+    ZSW_HIP(ctx, ws[WS_CIGSTART].ensure((size_t)n * 8));
+    ZSW_HIP(ctx, ws[WS_CIGRAW].ensure((size_t)n * 4));
+    ZSW_HIP(ctx, ws[WS_FBLIST].ensure((size_t)n * 4 + 4));
+    ZSW_HIP(ctx, ws[WS_FBCOUNT].ensure(8));
+    ZSW_HIP(ctx, ws[WS_CIG].ensure((size_t)n * MAXC * 4));
+    ZSW_HIP(ctx, ws[WS_ITEMS].ensure((size_t)n * 4 + 4));
+    ZSW_HIP(ctx, ctx->sh_ws[SH_LIST].ensure(16));
+    ZSW_HIP(ctx, hipMemsetAsync(ws[WS_FBCOUNT].p, 0, 4, stream));
+    ctx->timer.begin(stream);
+    struct Tier {
+        uint8_t code;
+        int N;
+    };
+    const Tier tiers[3] = {{8, lanes_w8}, {16, lanes_w16}, {32, lanes_w32}};
+    auto run_tier = [&](int N, const uint32_t* d_items, uint32_t count, uint32_t maxc, int by_item, DevBuf& ringbuf, DevBuf& cigbuf) -> zsw_error {
+        if (!count) return ZSW_OK;
+        uint32_t grid = std::min<uint32_t>((count + (64 / (uint32_t)N) - 1) / (64 / (uint32_t)N), 4096u);
+        while (grid > 1 && align_shared_ring_bytes(N, plen, W, grid, S) > (size_t(3) << 30)) grid /= 2;
+        if (align_shared_ring_bytes(N, plen, W, grid, S) > (size_t(6) << 30)) return fail(ctx, ZSW_ERR_UNSUPPORTED, "shared profile too long for the flag ring");
+        ZSW_HIP(ctx, ringbuf.ensure(align_shared_ring_bytes(N, plen, W, grid, S) + 64));
+        if (by_item) ZSW_HIP(ctx, cigbuf.ensure((uint64_t)count * maxc * 4 + 64));
+        BatchDev b = st.b;
+        b.items = d_items;
+        b.n_items = count;
+        hipError_t he = align_pass2_shared(N, ctx->d_pseq.as<uint8_t>(), plen, b, ctx->d_sc.as<ScoringDev>(), S, so.score, so.ref_end, so.status, W, maxc,
+                                           ringbuf.as<uint8_t>(), grid, cigbuf.as<uint32_t>(), 0, by_item, ws[WS_CIGSTART].as<uint64_t>(),
+                                           ws[WS_CIGRAW].as<uint32_t>(), ws[WS_ALN].as<zsw_alignment>(), ws[WS_FBLIST].as<uint32_t>(),
+                                           ws[WS_FBCOUNT].as<uint32_t>(), invert, stream);
+        if (he != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "shared align pass 2", he);
+        return ZSW_OK;
+    };
+    bool seen[65] = {false};
+    for (const Tier& t : tiers) {
+        if (rule.n_tiers == 1 ? t.code != rule.tier_code[0] : false) continue;
+        bool in_rule = false;
+        for (int k = 0; k < rule.n_tiers; ++k) in_rule = in_rule || rule.tier_code[k] == t.code;
+        if (!in_rule) continue;
+        (void)seen;
+        uint32_t* d_list = ws[WS_ITEMS].as<uint32_t>();
+        uint32_t* d_count = ctx->sh_ws[SH_LIST].as<uint32_t>();
+        ZSW_HIP(ctx, hipMemsetAsync(d_count, 0, 4, stream));
+        hipLaunchKernelGGL(iota_some_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, so.status, so.tier, t.code, d_list, d_count);
+        uint32_t count = 0;
+        ZSW_HIP(ctx, hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, stream));
+        ZSW_HIP(ctx, hipStreamSynchronize(stream));
+        ze = run_tier(t.N, d_list, count, MAXC, 0, ws[WS_RING], ws[WS_CIG]);
+        if (ze != ZSW_OK) return ze;
+        ZSW_HIP(ctx, hipStreamSynchronize(stream));  // the item list is reused by the next tier
+    }
+    ctx->timer.end(stream);
+    // reads whose CIGAR needs more than 32 ciglets: rerun with room for any CIGAR (the window already holds every row)
+    uint32_t n_fb = 0;
+    ZSW_HIP(ctx, hipMemcpyAsync(&n_fb, ws[WS_FBCOUNT].p, 4, hipMemcpyDeviceToHost, stream));
+    ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    if (n_fb) {
+        std::vector<uint32_t> fb(n_fb);
+        std::vector<uint8_t> h_tier(n);
+        ZSW_HIP(ctx, hipMemcpy(fb.data(), ws[WS_FBLIST].p, (size_t)n_fb * 4, hipMemcpyDeviceToHost));
+        ZSW_HIP(ctx, hipMemcpy(h_tier.data(), so.tier, n, hipMemcpyDeviceToHost));
+        std::map<int, std::vector<uint32_t>> by_n;
+        for (uint32_t id : fb) by_n[h_tier[id] == 8 ? lanes_w8 : h_tier[id] == 16 ? lanes_w16 : lanes_w32].push_back(id);
+        ZSW_HIP(ctx, hipMemsetAsync(ws[WS_FBCOUNT].p, 0, 4, stream));
+        const uint32_t maxc_full = plen + W + 4;
+        for (auto& g : by_n) {
+            ZSW_HIP(ctx, ws[WS_ITEMS2].ensure(g.second.size() * 4 + 4));
+            ZSW_HIP(ctx, hipMemcpy(ws[WS_ITEMS2].p, g.second.data(), g.second.size() * 4, hipMemcpyHostToDevice));
+            ze = run_tier(g.first, ws[WS_ITEMS2].as<uint32_t>(), (uint32_t)g.second.size(), maxc_full, 1, ws[WS_RING2], ws[WS_CIG2]);
+            if (ze != ZSW_OK) return ze;
+            ZSW_HIP(ctx, hipStreamSynchronize(stream));
+        }
+        uint32_t again = 0;
+        ZSW_HIP(ctx, hipMemcpy(&again, ws[WS_FBCOUNT].p, 4, hipMemcpyDeviceToHost));
+        if (again) return fail(ctx, ZSW_ERR_HIP, "shared alignment traceback did not complete");
+    }
+    return finish_alignments(ctx, ws, n, host, so.status, so.tier, invert, out_aln, out_status, out_tier, out_inc, out_op, ciglet_cap, out_n_ciglets,
+                             stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+zsw_error zsw_set_profile_sequence(zsw_context* ctx, const uint8_t* sequence, size_t len, zsw_mem mem) {
+    DeviceGuard device_guard(ctx);
+    if (!ctx || (!sequence && len)) return ZSW_ERR_INVALID_ARGUMENT;
+    if (len == 0) return ZSW_ERR_EMPTY_SEQUENCE;  // StripedProfile::new -> Err(ProfileError::EmptySequence) (profile.rs:32-44)
+    if (len > 0x7fffffffull) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "profile sequence too long");
+    ZSW_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->pseq_set) ZSW_HIP(ctx, hipDeviceSynchronize());  // queued kernels may still read the previous sequence
+    ZSW_HIP(ctx, ctx->d_pseq.ensure(len + 16));
+    ZSW_HIP(ctx, hipMemcpy(ctx->d_pseq.p, sequence, len, mem == ZSW_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
+    ctx->pseq_len = len;
+    ctx->pseq_set = true;
+    return ZSW_OK;
+}
+
+zsw_error zsw_score_shared_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, uint32_t* out_score,
+                                 uint8_t* out_status, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!valid_lanes(lanes)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "lanes must be a power of two in 2..64");
+    ResultRule rule;
+    if (!rule_direct(int_type, ctx->bias, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "bad int_type");
+    return run_score_shared(ctx, reads, rule, out_score, out_status, nullptr, stream);
+}
+
+zsw_error zsw_score_shared_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, uint32_t* out_score,
+                                      uint8_t* out_status, uint8_t* out_tier, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (preset_bits != 128 && preset_bits != 256 && preset_bits != 512) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "preset_bits");
+    ResultRule rule;
+    if (!rule_cascade(from_width, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "from_width");
+    return run_score_shared(ctx, reads, rule, out_score, out_status, out_tier, stream);
+}
+
+zsw_error zsw_score_ends_shared_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, uint32_t* out_score,
+                                      uint32_t* out_ref_end, uint32_t* out_query_end, uint8_t* out_status, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!valid_lanes(lanes)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "lanes must be a power of two in 2..64");
+    ResultRule rule;
+    if (!rule_direct(int_type, ctx->bias, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "bad int_type");
+    return run_ends_shared(ctx, reads, rule, out_score, out_ref_end, out_query_end, out_status, stream);
+}
+
+zsw_error zsw_score_ranges_shared_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, uint32_t* out_score,
+                                        uint32_t* out_ref_start, uint32_t* out_ref_end, uint32_t* out_query_start, uint32_t* out_query_end,
+                                        uint8_t* out_status, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!valid_lanes(lanes)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "lanes must be a power of two in 2..64");
+    ResultRule rule;
+    if (!rule_direct(int_type, ctx->bias, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "bad int_type");
+    return run_ranges_shared(ctx, reads, rule, out_score, out_ref_start, out_ref_end, out_query_start, out_query_end, out_status, nullptr, stream);
+}
+
+zsw_error zsw_score_ranges_shared_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, uint32_t* out_score,
+                                             uint32_t* out_ref_start, uint32_t* out_ref_end, uint32_t* out_query_start, uint32_t* out_query_end,
+                                             uint8_t* out_status, uint8_t* out_tier, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (preset_bits != 128 && preset_bits != 256 && preset_bits != 512) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "preset_bits");
+    ResultRule rule;
+    if (!rule_cascade(from_width, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "from_width");
+    return run_ranges_shared(ctx, reads, rule, out_score, out_ref_start, out_ref_end, out_query_start, out_query_end, out_status, out_tier, stream);
+}
+
+zsw_error zsw_align_shared_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, int invert, zsw_alignment* out_aln,
+                                 uint8_t* out_status, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!valid_lanes(lanes)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "lanes must be a power of two in 2..64");
+    ResultRule rule;
+    if (!rule_direct(int_type, ctx->bias, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "bad int_type");
+    return run_align_shared(ctx, reads, rule, lanes, lanes, lanes, invert, out_aln, out_status, nullptr, out_inc, out_op, ciglet_cap, out_n_ciglets,
+                            stream);
+}
+
+zsw_error zsw_align_shared_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, int invert, zsw_alignment* out_aln,
+                                      uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap,
+                                      uint64_t* out_n_ciglets, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (preset_bits != 128 && preset_bits != 256 && preset_bits != 512) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "preset_bits");
+    ResultRule rule;
+    if (!rule_cascade(from_width, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "from_width");
+    return run_align_shared(ctx, reads, rule, preset_bits / 8, preset_bits / 16, preset_bits / 32, invert, out_aln, out_status, out_tier, out_inc,
+                            out_op, ciglet_cap, out_n_ciglets, stream);
+}
+
+}  // extern "C"
