@@ -101,3 +101,18 @@ def test_header_is_c_and_links_from_c(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert f"{len(header_symbols())} entry points, sizeof(zsw_alignment) = 40" in out.stdout
+
+
+def test_the_library_exports_the_c_abi_and_nothing_else():
+    """nm -D: every defined dynamic symbol is a zsw_* entry point of the header (linker version script zsw_exports.map); no C++
+    internals (_ZN3zsw...) leak out of the library."""
+    import subprocess
+
+    from zoe_amd import _lib, build
+
+    out = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    names = [line.split()[-1] for line in out.splitlines() if line.strip()]
+    exported = sorted(n for n in names if not n.startswith(("__", "_init", "_fini", "_edata", "_end")))
+    assert exported, "no exported symbols"
+    assert all(n.startswith("zsw_") for n in exported), [n for n in exported if not n.startswith("zsw_")][:5]
+    assert set(exported) == set(_lib.SYMBOLS)

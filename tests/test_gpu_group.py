@@ -112,6 +112,64 @@ def test_group_alignments_equal_one_context(za, fixed, n, three_pass):
         assert got.key(i) == one.key(i), i
 
 
+@pytest.mark.parametrize("fixed", [True, False])
+def test_eight_contexts_on_one_gpu_equal_one_context(za, fixed):
+    """The shard arithmetic of a whole node (G = 8: [i*n/8, (i+1)*n/8), eight worker threads that live with the group) through the
+    host path, on device 0: scores, tiers and alignments of a batch whose size is not a multiple of 8 equal one context's; two
+    calls in a row reuse the workers."""
+    import torch
+
+    n = 40_003
+    ref, bases, off, L = _reference_and_reads(n, fixed)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    g = za.SwGroup([0] * 8)
+    try:
+        assert len(g) == 8
+        g.configure(dna, -10, -1, ref)
+        s, st, t = g.sw_score_from_host(bases, n, fixed_len=L, offsets=off)
+        s2, st2, t2 = g.sw_score_from_host(bases, n, fixed_len=L, offsets=off)
+        aln = g.sw_align_from_host(bases, 2001, fixed_len=L, offsets=None if off is None else off[:2002])
+    finally:
+        g.close()
+    assert np.array_equal(s, s2) and np.array_equal(st, st2) and np.array_equal(t, t2)
+    if fixed:
+        rb = za.ReadBatch.from_fixed(torch.from_numpy(bases).cuda(), 150)
+        rb_a = za.ReadBatch.from_fixed(torch.from_numpy(bases[: 2001 * 150]).cuda(), 150)
+    else:
+        o64 = torch.from_numpy(off.astype(np.int64)).cuda()
+        rb = za.ReadBatch(torch.from_numpy(bases).cuda(), n, offsets=o64)
+        rb_a = za.ReadBatch(torch.from_numpy(bases).cuda(), 2001, offsets=o64[:2002].contiguous())
+    one = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1).sw_score_from_i8(ref)
+    assert np.array_equal(st, one.status.cpu().numpy())
+    some = st == 0
+    assert np.array_equal(s[some], one.score.cpu().numpy().view(np.uint32)[some])
+    assert np.array_equal(t[some], one.tier.cpu().numpy()[some])
+    one_a = za.LocalProfilesBatch.new_with_w256(rb_a, dna, -10, -1).sw_align_from_i8(za.SeqSrc.Reference(ref))
+    assert np.array_equal(aln.status, one_a.status)
+    for i in range(0, 2001, 7):
+        assert aln.key(i) == one_a.key(i), i
+
+
+def test_the_device_entry_point_rejects_duplicate_devices(za):
+    """RCCL wants one rank per GPU: two contexts on device 0 are fine for the host path and ZSW_ERR_INVALID_ARGUMENT here (before
+    ncclCommInitAll is reached)."""
+    import torch
+
+    from zoe_amd import _lib, synth
+
+    ref = synth.reference_host(2000)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    g = za.SwGroup([0, 0])
+    try:
+        g.configure(dna, -10, -1, ref)
+        rb = za.ReadBatch.from_fixed(torch.from_numpy(synth.reads_host(ref, 1, 64, 150).reshape(-1)).cuda(), 150)
+        with pytest.raises(_lib.ZswError) as ei:
+            g.sw_score_from_device([rb, rb])
+        assert ei.value.code == -1 and "distinct devices" in str(ei.value)
+    finally:
+        g.close()
+
+
 def test_device_shards_and_the_rccl_gather_at_world_size_one(za, oracle):
     """Device-memory form: the context writes its slice of the device's result arrays and the grouped RCCL broadcast completes
     them (world size 1 here: the collective is issued and must leave the results intact); checked against the oracle."""

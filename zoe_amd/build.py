@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzoe_sw_hip.so")
 SOURCES = ["zsw_capi.hip", "zsw_capi_shared.hip", "zsw_shared.hip", "zsw_score.hip", "zsw_align.hip", "zsw_align_pk8.hip", "zsw_align_pk16.hip", "zsw_align_pk32.hip", "zsw_align_pk64.hip", "zsw_group.hip", "zsw_threepass.hip", "zsw_filter.hip", "zsw_score_wide.hip", "zsw_score_w32.hip", "zsw_score_prune.hip", "zsw_score_seed.hip", "zsw_score_seed_m0.hip", "zsw_score_seed_m1.hip", "zsw_score_seed_m2.hip", "zsw_multi.hip"]
-HEADERS = ["zsw_internal.hpp", "zsw_align_dev.hpp", "zsw_align_pk.hpp", "zsw_align_pk_kernel.hpp", "zsw_score_v1.hpp", "zsw_score_v2.hpp", "zsw_score_prune.hpp", "zsw_seed.hpp", "zsw_context.hpp", "zsw_shared.hpp", "zsw_score_seed.hpp", "zsw_score_seed_kernel.hpp", "zsw_align.hpp", "zsw_timer.hpp", "zsw_synth.h", os.path.join("..", "..", "include", "zoe_sw.h")]
+HEADERS = ["zsw_internal.hpp", "zsw_align_dev.hpp", "zsw_align_pk.hpp", "zsw_align_pk_kernel.hpp", "zsw_score_v1.hpp", "zsw_score_v2.hpp", "zsw_score_prune.hpp", "zsw_seed.hpp", "zsw_context.hpp", "zsw_shared.hpp", "zsw_score_seed.hpp", "zsw_score_seed_kernel.hpp", "zsw_align.hpp", "zsw_timer.hpp", "zsw_synth.h", "zsw_exports.map", os.path.join("..", "..", "include", "zoe_sw.h")]
 ARCH = "gfx950"
 # per-file code generation flags. Measured and rejected for zsw_align_pk*.hip: -mllvm -amdgpu-sched-strategy=max-ilp
 # (s_nop between dependent packed instructions 206 -> 92 in the <16,10> kernel, but 190 VGPRs = two waves per SIMD: 46 instead of 41 ms)
@@ -61,7 +61,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             sys.stderr.write(out)
     if failed:
         raise RuntimeError("hipcc compilation failed")
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    # only the zsw_* entry points of include/zoe_sw.h are exported (the C++ internals stay local to the library)
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, "-Wl,--version-script=" + os.path.join(CSRC, "zsw_exports.map")] + objs
     subprocess.run(cmd, check=True)
     return LIB
 

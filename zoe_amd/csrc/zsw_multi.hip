@@ -5,7 +5,8 @@
 // Alignments are independent, so the group shards the reads into contiguous index ranges [i*n/G, (i+1)*n/G), one per context,
 // and drives every context from its own host thread; the reference and the scoring tables are replicated. There is no exchange
 // during the computation. Results in host memory land in place (no collective at all); results in device memory are completed
-// on every device by one RCCL all-gather over xGMI (grouped broadcasts, so the shards may differ by one read).
+// on every device by RCCL over xGMI: one in-place ncclAllGather per array when the shards are equal, grouped broadcasts when
+// they differ by a read. One worker thread per context lives as long as the group.
 //
 // This file uses only the public C ABI (include/zoe_sw.h) and the HIP runtime; librccl is opened at the first device-memory
 // call, so that hosts without it can still use everything else (the call then fails loudly with ZSW_ERR_UNSUPPORTED).
@@ -14,6 +15,9 @@
 #include <rccl/rccl.h>
 #include <stdio.h>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -27,6 +31,7 @@ struct Rccl {
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -49,6 +54,7 @@ struct Rccl {
         ZSW_SYM(CommInitAll, "ncclCommInitAll")
         ZSW_SYM(CommDestroy, "ncclCommDestroy")
         ZSW_SYM(Broadcast, "ncclBroadcast")
+        ZSW_SYM(AllGather, "ncclAllGather")
         ZSW_SYM(GroupStart, "ncclGroupStart")
         ZSW_SYM(GroupEnd, "ncclGroupEnd")
         ZSW_SYM(GetErrorString, "ncclGetErrorString")
@@ -59,11 +65,69 @@ struct Rccl {
 
 }  // namespace
 
+namespace {
+
+// One worker per context, alive as long as the group: a call hands every worker its shard's task and waits for all of them.
+struct Workers {
+    std::mutex m;
+    std::condition_variable wake, done;
+    std::vector<std::thread> threads;
+    std::vector<std::function<void()>> task;  // task[i] != nullptr: worker i has work
+    int pending = 0;
+    bool quit = false;
+
+    void start(int n) {
+        task.assign((size_t)n, nullptr);
+        for (int i = 0; i < n; ++i)
+            threads.emplace_back([this, i] {
+                for (;;) {
+                    std::function<void()> fn;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        wake.wait(lk, [&] { return quit || task[(size_t)i] != nullptr; });
+                        if (quit) return;
+                        fn = std::move(task[(size_t)i]);
+                        task[(size_t)i] = nullptr;
+                    }
+                    fn();
+                    {
+                        std::lock_guard<std::mutex> lk(m);
+                        --pending;
+                    }
+                    done.notify_all();
+                }
+            });
+    }
+    // runs fn(i) on worker i for every i, returns when all are finished (one caller at a time, as for a context)
+    void run(const std::function<void(int)>& fn) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            pending = (int)task.size();
+            for (size_t i = 0; i < task.size(); ++i) task[i] = [&fn, i] { fn((int)i); };
+        }
+        wake.notify_all();
+        std::unique_lock<std::mutex> lk(m);
+        done.wait(lk, [&] { return pending == 0; });
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        wake.notify_all();
+        for (auto& t : threads) t.join();
+        threads.clear();
+    }
+};
+
+}  // namespace
+
 struct zsw_group {
     std::vector<int> devices;
     std::vector<zsw_context*> ctx;
     std::vector<ncclComm_t> comms;  // created with the first device-memory call
     Rccl rccl;
+    Workers workers;                // started by zsw_group_create when the group has more than one context
     std::string err;
 };
 
@@ -100,10 +164,7 @@ zsw_error for_each_context(zsw_group* g, Fn fn) {
     if (G == 1) {
         rc[0] = fn(0);
     } else {
-        std::vector<std::thread> th;
-        th.reserve((size_t)G);
-        for (int i = 0; i < G; ++i) th.emplace_back([&, i] { rc[(size_t)i] = fn(i); });
-        for (auto& t : th) t.join();
+        g->workers.run([&](int i) { rc[(size_t)i] = fn(i); });
     }
     for (int i = 0; i < G; ++i)
         if (rc[(size_t)i] != ZSW_OK) {
@@ -135,12 +196,14 @@ zsw_error zsw_group_create(const int* device_ids, int n_devices, zsw_group** out
         g->devices.push_back(device_ids[i]);
         g->ctx.push_back(c);
     }
+    if (n_devices > 1) g->workers.start(n_devices);
     *out = g;
     return ZSW_OK;
 }
 
 void zsw_group_destroy(zsw_group* g) {
     if (!g) return;
+    g->workers.stop();
     if (g->rccl.CommDestroy)
         for (ncclComm_t c : g->comms) (void)g->rccl.CommDestroy(c);
     for (zsw_context* p : g->ctx) zsw_destroy(p);
@@ -319,6 +382,12 @@ zsw_error zsw_group_score_batch_from_device(zsw_group* g, const zsw_batch* shard
         first[(size_t)i + 1] = first[(size_t)i] + shards[i].n_reads;
     }
     if (g->comms.empty()) {  // one communicator per context, created once
+        // RCCL wants one rank per GPU: the host-memory entry points accept several contexts on one device, this one does not
+        for (int i = 0; i < G; ++i)
+            for (int j = i + 1; j < G; ++j)
+                if (g->devices[(size_t)i] == g->devices[(size_t)j])
+                    return gfail(g, ZSW_ERR_INVALID_ARGUMENT, "zsw_group_score_batch_from_device needs distinct devices (device " +
+                                                                  std::to_string(g->devices[(size_t)i]) + " appears twice)");
         if (!g->rccl.load(&g->err)) return ZSW_ERR_UNSUPPORTED;
         g->comms.resize((size_t)G);
         const ncclResult_t r = g->rccl.CommInitAll(g->comms.data(), G, g->devices.data());
@@ -336,21 +405,41 @@ zsw_error zsw_group_score_batch_from_device(zsw_group* g, const zsw_batch* shard
         return (hipSetDevice(g->devices[(size_t)i]) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess) ? ZSW_OK : ZSW_ERR_HIP;
     });
     if (e != ZSW_OK) return e;
-    // ... and one grouped collective completes the arrays on every device: shard r is broadcast from rank r (an all-gather whose
-    // pieces may differ in length), in place
+    // ... and one grouped collective completes the arrays on every device, in place. Equal shards: one ncclAllGather per array
+    // (rank r's piece already sits at r * count of its own arrays). Shards that differ by a read: shard r is broadcast from rank r.
+    // An error inside the bracket only ends the loop: ncclGroupEnd always runs, or the communicators would stay in an open group.
+    bool equal = true;
+    for (int i = 1; i < G; ++i) equal = equal && shards[i].n_reads == shards[0].n_reads;
+    bool device_error = false;
     ncclResult_t r = g->rccl.GroupStart();
-    for (int root = 0; root < G && r == ncclSuccess; ++root) {
-        const uint64_t cnt = shards[root].n_reads;
-        if (cnt == 0) continue;
-        for (int i = 0; i < G && r == ncclSuccess; ++i) {
-            if (hipSetDevice(g->devices[(size_t)i]) != hipSuccess) return gfail(g, ZSW_ERR_HIP, "hipSetDevice");
-            uint32_t* ps = out_score[i] + first[(size_t)root];
-            uint8_t* pt = out_status[i] + first[(size_t)root];
-            r = g->rccl.Broadcast(ps, ps, cnt, ncclUint32, root, g->comms[(size_t)i], nullptr);
-            if (r == ncclSuccess) r = g->rccl.Broadcast(pt, pt, cnt, ncclUint8, root, g->comms[(size_t)i], nullptr);
+    if (equal && shards[0].n_reads > 0) {
+        const uint64_t cnt = shards[0].n_reads;
+        for (int i = 0; i < G && r == ncclSuccess && !device_error; ++i) {
+            if (hipSetDevice(g->devices[(size_t)i]) != hipSuccess) {
+                device_error = true;
+                break;
+            }
+            r = g->rccl.AllGather(out_score[i] + (uint64_t)i * cnt, out_score[i], cnt, ncclUint32, g->comms[(size_t)i], nullptr);
+            if (r == ncclSuccess) r = g->rccl.AllGather(out_status[i] + (uint64_t)i * cnt, out_status[i], cnt, ncclUint8, g->comms[(size_t)i], nullptr);
+        }
+    } else {
+        for (int root = 0; root < G && r == ncclSuccess && !device_error; ++root) {
+            const uint64_t cnt = shards[root].n_reads;
+            if (cnt == 0) continue;
+            for (int i = 0; i < G && r == ncclSuccess; ++i) {
+                if (hipSetDevice(g->devices[(size_t)i]) != hipSuccess) {
+                    device_error = true;
+                    break;
+                }
+                uint32_t* ps = out_score[i] + first[(size_t)root];
+                uint8_t* pt = out_status[i] + first[(size_t)root];
+                r = g->rccl.Broadcast(ps, ps, cnt, ncclUint32, root, g->comms[(size_t)i], nullptr);
+                if (r == ncclSuccess) r = g->rccl.Broadcast(pt, pt, cnt, ncclUint8, root, g->comms[(size_t)i], nullptr);
+            }
         }
     }
     const ncclResult_t r2 = g->rccl.GroupEnd();
+    if (device_error) return gfail(g, ZSW_ERR_HIP, "hipSetDevice inside the RCCL gather");
     if (r != ncclSuccess || r2 != ncclSuccess)
         return gfail(g, ZSW_ERR_HIP, std::string("RCCL gather: ") + g->rccl.GetErrorString(r != ncclSuccess ? r : r2));
     for (int i = 0; i < G; ++i)

@@ -262,7 +262,9 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
         }
     }
     __syncthreads();
-    const int joff = a0 - blo + (G - 1) - g;  // table entry of this lane's row at step t: joff + t
+    // table entry of this lane's row at step t: joff + t. Lane groups past the batch (validA false: the tail of the last block)
+    // keep a0 = 0 while the block's table starts at blo: they read from entry 0 on, inside the table
+    const int joff = validA ? a0 - blo + (G - 1) - g : 0;
 
     // the boundary streams of the two reads
     const uint2* bA = a.bnd + (size_t)(ridA >> 1) * (size_t)a.row_stride;
@@ -421,6 +423,10 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
         const int colr = CP + (g + 1) * C;
         v3A = max(v3A, (int)(Fout & 0xffffu) - dA + maxw * max(0, (int)lenA - colr - 1));
         v3B = max(v3B, (int)(Fout >> 16) - dB + maxw * max(0, (int)lenB - colr - 1));
+        if (g > 0) {  // the diagonal from the left neighbour's last column, one row up, into the first cell below this lane's rows
+            v3A = max(v3A, (int)(Hin_prev & 0xffffu) - dA + maxw * max(0, (int)lenA - (CP + g * C)));
+            v3B = max(v3B, (int)(Hin_prev >> 16) - dB + maxw * max(0, (int)lenB - (CP + g * C)));
+        }
     }
     // V2: crossings in rows outside the window, block by block
     int v2A = 0, v2B = 0;
