@@ -36,10 +36,16 @@ struct SeedArgs {
     uint32_t* fail_count;
 };
 
+// One thread per read. STAGED (contiguous fixed-length reads of at most SEED_STAGE_LEN bases): the block's reads arrive in LDS
+// by 16-byte loads first — 150 single-byte loads per thread, each touching 64 different cache lines per wavefront, were most of
+// this kernel's time.
+constexpr uint32_t SEED_STAGE_LEN = 160;
+
+template <bool STAGED>
 __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a) {
     __shared__ uint16_t cell_lut[256];  // read byte -> seed_cell (potential, 2-bit code) of its residue
+    __shared__ __attribute__((aligned(16))) uint8_t sbytes[STAGED ? 256 * SEED_STAGE_LEN + 16 : 16];
     cell_lut[threadIdx.x] = (uint16_t)seed_cell(a.sp, (int)a.sc->index_map[threadIdx.x]);
-    __syncthreads();
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const bool valid = k < a.n;
     uint32_t id = 0, len = 0;
@@ -49,12 +55,30 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a) {
         off = a.b.offsets ? a.b.offsets[id] : (uint64_t)id * a.b.fixed_len;
         len = a.b.offsets ? (uint32_t)(a.b.offsets[id + 1] - off) : a.b.fixed_len;
     }
+    if (STAGED) {  // bytes [block_first * L, min(n, block_first + 256) * L) of the batch, 16 at a time, the tail byte by byte
+        const uint32_t L = a.b.fixed_len;
+        const uint64_t b0 = (uint64_t)(a.first + blockIdx.x * 256u) * L;
+        const uint32_t cnt = min(256u, a.n - blockIdx.x * 256u) * L;
+        const uint8_t* src = a.b.bases + b0;
+        const uint32_t head = (uint32_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u)) & 15u);  // bytes before the first aligned 16
+        // LDS offset = global offset + shift, so that aligned global loads land on aligned LDS stores
+        const uint32_t shift = (16u - head) & 15u;
+        for (uint32_t i = threadIdx.x; i < min(head, cnt); i += 256) sbytes[shift + i] = src[i];
+        const uint32_t n16 = cnt > head ? (cnt - head) / 16 : 0;
+        for (uint32_t i = threadIdx.x; i < n16; i += 256)
+            *reinterpret_cast<uint4*>(&sbytes[shift + head + 16 * i]) = *reinterpret_cast<const uint4*>(src + head + 16 * i);
+        for (uint32_t i = head + 16 * n16 + threadIdx.x; i < cnt; i += 256) sbytes[shift + i] = src[i];
+        __syncthreads();
+        off = (uint64_t)shift + (uint64_t)threadIdx.x * L;  // this thread's read inside sbytes
+    } else {
+        __syncthreads();
+    }
     SeedRead sr;
     sr.ok = 0;
     sr.t_all = sr.d_fa = sr.d_bl = 0;
     sr.bl_mask = 0;
     if (valid && len >= SEED_MIN_LEN && len < SEED_KEY_BIAS) {
-        const uint8_t* bases = a.b.bases + off;
+        const uint8_t* bases = STAGED ? sbytes + off : a.b.bases + off;
         const uint2* table = a.table;
         sr = seed_read(
             a.sp, (int)len, [&](int c) { return (uint32_t)cell_lut[bases[c]]; },
@@ -144,7 +168,10 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIn
     s.ref_len = a2.ref_len;
     s.fail_list = fail_list;
     s.fail_count = fail_count;
-    hipLaunchKernelGGL(seed_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, s);
+    if (!s.b.offsets && !s.b.items && s.b.fixed_len <= SEED_STAGE_LEN)
+        hipLaunchKernelGGL(seed_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, stream, s);
+    else
+        hipLaunchKernelGGL(seed_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, stream, s);
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t*)keys, keys_out, (const uint32_t*)ids, order, (int)n, 0,
                                                       key_bits, stream);
     if (e != hipSuccess) return e;
