@@ -18,7 +18,7 @@ namespace zsw {
 // ~64 registers on top, so the widest strips run at two waves per SIMD (which still fills the 4-cycle issue slots: r03 PMC,
 // seed_window_kernel<4,38,2> at 3.99 cycles per instruction with two) instead of spilling at three.
 constexpr int seed_min_waves(int C, int MODE) {
-    const int need = MODE == 2 ? 4 * C + 96 : 3 * C + 64;
+    const int need = MODE == 2 ? 4 * C + 96 : 3 * C + 54;
     return need <= 80 ? 6 : need <= 96 ? 5 : need <= 128 ? 4 : need <= 168 ? 3 : 2;
 }
 
