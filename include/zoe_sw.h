@@ -328,7 +328,10 @@ typedef enum zsw_debug_flag {
     ZSW_DEBUG_PRUNE_STRIP = 512,
     /* align: the second pass starts warmup_rows before the first kept row for every read (round 2), not at the row the seeded
      * first pass certifies (zsw_seed.hpp: seed_safe_start) */
-    ZSW_DEBUG_ALIGN_LONG_WARMUP = 1024
+    ZSW_DEBUG_ALIGN_LONG_WARMUP = 1024,
+    /* score: the seeded pass computes whole rows around the anchor (seed_window_kernel) for score-only calls too, instead of the
+     * band of diagonals of seed_band_kernel (zsw_score_band.hip) */
+    ZSW_DEBUG_SEED_NO_BAND = 2048
 } zsw_debug_flag;
 zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags);
 

@@ -73,3 +73,17 @@ def test_late_start_certificate_model(tmp_path, seed):
     out = subprocess.run([_build(tmp_path, "seed_warmup"), "400", str(seed)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "seed_warmup OK" in out.stdout
+
+
+@pytest.mark.parametrize("seed", [20261004, 7, 41])
+def test_banded_pass_bounds_model(tmp_path, seed):
+    """The banded form of the seeded pass for score-only calls (zoe_amd/csrc/zsw_score_band.hip; bounds: zsw_seed.hpp,
+    seed_band_upper / seed_band_lower / seed_gap_up / seed_gap_down), against a layered Gotoh DP that classes every path with a
+    cell outside the band by how it first got there — a fresh start above / below the band, an exit through a strip's right edge,
+    an exit through a strip's last row — and checks each class's best path against that class's own bound, for every read
+    (passing or not), so that a weak bound cannot hide behind a larger one; a passing read has the true score (and, with the
+    strict checks, the true first row and column). Exact copies, errors, chimeras, long deletions / insertions, overhanging and
+    random reads; free gap extension; strips of 5-30 columns; band widths of a few diagonals."""
+    out = subprocess.run([_build(tmp_path, "seed_band"), "250", str(seed)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "seed_band OK" in out.stdout

@@ -28,14 +28,17 @@ def za():
     return zoe_amd
 
 
-@pytest.fixture(params=["seeded", "strip"])
+@pytest.fixture(params=["seeded", "window", "strip"])
 def pruned(za, request):
-    """The context with a pruned pass switched on for batches of every size: the seeded pass, or the strip + window pass."""
+    """The context with a pruned pass switched on for batches of every size: the seeded pass (score-only calls: the banded
+    kernel, zsw_score_band.hip), the seeded pass with whole rows for score-only calls too (seed_window_kernel), or round 2's
+    strip + window pass."""
     from zoe_amd import _lib
 
     ctx = za.SwContext.get(0)
     ctx.kind = request.param
-    ctx.debug_set(_lib.DEBUG_SCORE_PRUNE_ANY_SIZE | (_lib.DEBUG_PRUNE_STRIP if request.param == "strip" else 0))
+    extra = {"seeded": 0, "window": _lib.DEBUG_SEED_NO_BAND, "strip": _lib.DEBUG_PRUNE_STRIP}[request.param]
+    ctx.debug_set(_lib.DEBUG_SCORE_PRUNE_ANY_SIZE | extra)
     yield ctx
     ctx.debug_set(0)
 

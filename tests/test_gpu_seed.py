@@ -167,8 +167,64 @@ def test_long_reads_take_the_wide_window_configurations(za, oracle):
 
     ref = synth.reference_host(30000)
     dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
-    for L in (500, 608, 1216, 2400):
-        reads = synth.reads_host(ref, L, 1100, L)
-        back = _oracle_check(za, oracle, reads, dna, -10, -1, ref)
-        if L <= 608:  # sixteen sampled k-mers prove at most 16 x lambda = 112: longer reads lose more than that to their own errors
-            assert back < 600, (L, back)
+    from zoe_amd import _lib
+
+    ctx = za.SwContext.get(0)
+    try:
+        for flags in (0, _lib.DEBUG_SEED_NO_BAND):  # score-only calls: the banded kernel, then whole rows
+            ctx.debug_set(flags)
+            for L in (500, 608, 1216, 2400):
+                reads = synth.reads_host(ref, L, 1100, L)
+                back = _oracle_check(za, oracle, reads, dna, -10, -1, ref)
+                if L <= 608:  # sixteen sampled k-mers prove at most 16 x lambda = 112: longer reads lose more than that to their own errors
+                    assert back < 600, (L, back, flags)
+    finally:
+        ctx.debug_set(0)
+
+
+def test_banded_pass_pairs_lengths_and_edges(za, oracle):
+    """The banded kernel walks two reads per lane (16-bit halves) strip by strip: pairs whose anchors lie too far apart to share a
+    band (sparse batch on a long reference), pairs of different lengths (ragged batch), an odd read count, reads hanging over both
+    ends of the reference (anchor diagonals < 0 and > ref_len - len), free gap extension — each against the oracle, and the two
+    seeded kernels must hand back similar numbers of reads."""
+    import torch
+    from zoe_amd import _lib, synth
+
+    ctx = za.SwContext.get(0)
+    rng = np.random.default_rng(stable_seed("band-edges"))
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    try:
+        # sparse: 1,501 reads of 150 over 30 kb (neighbouring anchors ~20 apart, many pairs beyond the 32-diagonal slack)
+        ref = synth.reference_host(30000)
+        reads = synth.reads_host(ref, 9, 1501, 150)
+        ctx.debug_set(_lib.DEBUG_SCORE_PRUNE_ANY_SIZE)
+        back_band = _oracle_check(za, oracle, reads, dna, -10, -1, ref)
+        ctx.debug_set(_lib.DEBUG_SCORE_PRUNE_ANY_SIZE | _lib.DEBUG_SEED_NO_BAND)
+        back_window = _oracle_check(za, oracle, reads, dna, -10, -1, ref)
+        assert back_window < 150 and back_band < 900, (back_band, back_window)
+        # overhanging reads: copies of reference[-40..110) and reference[R-110..R+40), the overhang random
+        ref2 = synth.reference_host(2000)
+        r2 = np.frombuffer(bytes(ref2), dtype=np.uint8)
+        over = np.empty((2049, 150), dtype=np.uint8)
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        for i in range(over.shape[0]):
+            h = int(rng.integers(1, 60))
+            junk = acgt[rng.integers(0, 4, h)]
+            over[i] = np.concatenate([junk, r2[: 150 - h]]) if i % 2 else np.concatenate([r2[len(r2) - (150 - h):], junk])
+        for scheme in ((2, -5, -10, -1), (3, -2, -4, 0), (1, -1, -2, -1)):
+            m = za.WeightMatrix.new_dna_matrix(scheme[0], scheme[1], b"N")
+            ctx.debug_set(_lib.DEBUG_SCORE_PRUNE_ANY_SIZE)
+            _oracle_check(za, oracle, over, m, scheme[2], scheme[3], ref2)
+        # ragged: lengths 24-400 side by side in a lane
+        n = 5001
+        bases, off = synth.reads_ragged_host(ref2, 11, n, 24, 400)
+        sc = oracle.Scoring(dna.signed_weights(), dna.mapping.index_map, -10, -1)
+        ws, wst, wt = oracle.batch_score_w256(8, sc, bases, ref2, offsets=off, threads=8)
+        rb = za.ReadBatch(torch.from_numpy(bases).cuda(), n, offsets=torch.from_numpy(off.astype(np.int64)).cuda())
+        got = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1).sw_score_from_i8(ref2)
+        assert np.array_equal(got.status.cpu().numpy(), wst)
+        assert np.array_equal(got.score.cpu().numpy().view(np.uint32), ws)
+        assert np.array_equal(got.tier.cpu().numpy(), wt)
+        assert ctx.prune_rescored() < n // 4
+    finally:
+        ctx.debug_set(0)

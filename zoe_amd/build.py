@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzoe_sw_hip.so")
-SOURCES = ["zsw_capi.hip", "zsw_capi_shared.hip", "zsw_shared.hip", "zsw_score.hip", "zsw_align.hip", "zsw_align_pk8.hip", "zsw_align_pk16.hip", "zsw_align_pk32.hip", "zsw_align_pk64.hip", "zsw_group.hip", "zsw_threepass.hip", "zsw_filter.hip", "zsw_score_wide.hip", "zsw_score_w32.hip", "zsw_score_prune.hip", "zsw_score_seed.hip", "zsw_score_seed_m0.hip", "zsw_score_seed_m1.hip", "zsw_score_seed_m2.hip", "zsw_multi.hip"]
+SOURCES = ["zsw_capi.hip", "zsw_capi_shared.hip", "zsw_shared.hip", "zsw_score.hip", "zsw_align.hip", "zsw_align_pk8.hip", "zsw_align_pk16.hip", "zsw_align_pk32.hip", "zsw_align_pk64.hip", "zsw_group.hip", "zsw_threepass.hip", "zsw_filter.hip", "zsw_score_wide.hip", "zsw_score_w32.hip", "zsw_score_prune.hip", "zsw_score_seed.hip", "zsw_score_seed_m0.hip", "zsw_score_seed_m1.hip", "zsw_score_seed_m2.hip", "zsw_score_band.hip", "zsw_multi.hip"]
 HEADERS = ["zsw_internal.hpp", "zsw_align_dev.hpp", "zsw_align_pk.hpp", "zsw_align_pk_kernel.hpp", "zsw_score_v1.hpp", "zsw_score_v2.hpp", "zsw_score_prune.hpp", "zsw_seed.hpp", "zsw_context.hpp", "zsw_shared.hpp", "zsw_score_seed.hpp", "zsw_score_seed_kernel.hpp", "zsw_align.hpp", "zsw_timer.hpp", "zsw_synth.h", "zsw_exports.map", os.path.join("..", "..", "include", "zoe_sw.h")]
 ARCH = "gfx950"
 # per-file code generation flags. Measured and rejected for zsw_align_pk*.hip: -mllvm -amdgpu-sched-strategy=max-ilp

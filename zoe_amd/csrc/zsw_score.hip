@@ -530,7 +530,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         if (!use_v2 || !ws.seed || !ws.seed_work || !ws.prune_fail_list || !(ws.debug & ZSW_DEBUG_SCORE_PRUNE) || (ws.debug & ZSW_DEBUG_PRUNE_STRIP))
             return hipErrorNotSupported;
         if (bb.n_items < SEED_MIN_READS && !(ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) return hipErrorNotSupported;
-        if (g == 32 || work_off + seed_workspace_bytes(bb.n_items) > ws.seed_bytes) return hipErrorNotSupported;
+        if (g == 32 || work_off + seed_workspace_bytes(bb.n_items, longest) > ws.seed_bytes) return hipErrorNotSupported;
         ScoreArgsV2 ap = a2;
         if (!build_tables_v2(h_sc, g, &ap) || !seed_applicable(*ws.seed, longest, ref_len, ap.limit)) return hipErrorNotSupported;
         if (!ws.seed_gtab) return hipErrorNotSupported;
@@ -543,8 +543,8 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         pe = hipMemsetAsync(counter, 0, 4, stream);
         if (pe != hipSuccess) return pe;
         ap.b = bb;
-        pe = launch_score_seeded(ap, g, c, *ws.seed, ws.seed_work + work_off, seed_workspace_bytes(bb.n_items), ws.seed_gtab,
-                                 ws.prune_fail_list + list_off, counter, mode, stream, ws.window_timer);
+        pe = launch_score_seeded(ap, g, c, longest, *ws.seed, ws.seed_work + work_off, seed_workspace_bytes(bb.n_items, longest), ws.seed_gtab,
+                                 ws.prune_fail_list + list_off, counter, mode, !(ws.debug & ZSW_DEBUG_SEED_NO_BAND), stream, ws.window_timer);
         if (pe != hipSuccess) return pe;
         ap.b.items = ws.prune_fail_list + list_off;
         ap.n_items_dev = counter;
@@ -656,7 +656,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
                 stream = main_stream;
                 if (e == hipSuccess) ++used;
                 if (e == hipSuccess) {
-                    work_off += seed_workspace_bytes(counts[k]);
+                    work_off += seed_workspace_bytes(counts[k], caps.cap[k]);
                     counts[k] = 0;
                 } else if (e != hipErrorNotSupported) {
                     return e;

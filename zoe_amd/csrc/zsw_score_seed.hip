@@ -30,6 +30,10 @@ struct SeedArgs {
     uint32_t* ids;
     uint32_t* info;
     uint32_t* masks;
+    uint32_t* band_masks;  // banded pass: fa_mask | fb_mask << 16, d_fb, and the read as 4-bit residue codes (cs dwords per item)
+    uint8_t* band_dfb;
+    uint32_t* codes;
+    uint32_t cs;
     uint32_t key_bias, fail_key;
     uint32_t ref_len;
     uint32_t* fail_list;
@@ -43,9 +47,13 @@ constexpr uint32_t SEED_STAGE_LEN = 160;
 
 template <bool STAGED>
 __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a) {
-    __shared__ uint16_t cell_lut[256];  // read byte -> seed_cell (potential, 2-bit code) of its residue
+    __shared__ uint16_t cell_lut[256];  // read byte -> seed_cell (potential, 2-bit code) of its residue | residue index << 12
     __shared__ __attribute__((aligned(16))) uint8_t sbytes[STAGED ? 256 * SEED_STAGE_LEN + 16 : 16];
-    cell_lut[threadIdx.x] = (uint16_t)seed_cell(a.sp, (int)a.sc->index_map[threadIdx.x]);
+    {  // bits 0-7 potential, 8-9 code (bits 8-11 = 0xf: not a good residue), 12-15 residue index (S <= 7)
+        const int res = (int)a.sc->index_map[threadIdx.x];
+        const uint32_t cellv = seed_cell(a.sp, res);
+        cell_lut[threadIdx.x] = (uint16_t)((cellv & 0xffu) | (((cellv >> 8) == 0xffu ? 0xfu : ((cellv >> 8) & 3u)) << 8) | ((uint32_t)(res & 15) << 12));
+    }
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const bool valid = k < a.n;
     uint32_t id = 0, len = 0;
@@ -80,8 +88,22 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a) {
     if (valid && len >= SEED_MIN_LEN && len < SEED_KEY_BIAS) {
         const uint8_t* bases = STAGED ? sbytes + off : a.b.bases + off;
         const uint2* table = a.table;
+        // seed_read asks for every column exactly once, in order: the cell functor also packs the residue codes for the banded pass
+        uint32_t* code_out = a.codes ? a.codes + (size_t)k * a.cs : nullptr;
+        uint32_t acc = 0;
         sr = seed_read(
-            a.sp, (int)len, [&](int c) { return (uint32_t)cell_lut[bases[c]]; },
+            a.sp, (int)len,
+            [&](int c) {
+                const uint32_t v = cell_lut[bases[c]];
+                if (code_out) {
+                    acc |= (v >> 12) << (4 * (c & 7));
+                    if ((c & 7) == 7) {
+                        code_out[c >> 3] = acc;
+                        acc = 0;
+                    }
+                }
+                return (v & 0xffu) | (((v >> 8) & 0xfu) == 0xfu ? 0xff00u : (v & 0x300u));
+            },
             [&](uint32_t code, uint32_t* f1, uint32_t* l1) {
                 const uint2 e = table[code];
                 *f1 = e.x;
@@ -94,6 +116,24 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a) {
         a.ids[k] = k;
         a.info[k] = (uint32_t)sr.t_all | ((uint32_t)sr.d_fa << 16) | ((uint32_t)sr.d_bl << 24);
         a.masks[k] = sr.bl_mask;
+        if (a.codes) {
+            a.band_masks[k] = sr.fa_mask | (sr.fb_mask << 16);
+            a.band_dfb[k] = (uint8_t)sr.d_fb;
+            // the last, partial dword of the codes and the rest of the row: padding (reads the seed did not sweep are all padding)
+            uint32_t* code_row = a.codes + (size_t)k * a.cs;
+            const bool swept = len >= SEED_MIN_LEN && len < SEED_KEY_BIAS;
+            const uint32_t full = swept ? len >> 3 : 0;
+            if (full < a.cs) {
+                uint32_t tail = 0xffffffffu;
+                if (swept && (len & 7u)) {
+                    const uint8_t* bases = STAGED ? sbytes + off : a.b.bases + off;
+                    tail = 0;
+                    for (uint32_t c = full * 8; c < full * 8 + 8; ++c) tail |= (c < len ? (uint32_t)(cell_lut[bases[c]] >> 12) : 15u) << (4 * (c & 7));
+                }
+                code_row[full] = tail;
+                for (uint32_t d = full + 1; d < a.cs; ++d) code_row[d] = 0xffffffffu;
+            }
+        }
     }
     // reads without an anchor are scored over all their cells: one atomic per wavefront
     const unsigned long long m = __ballot(fail);
@@ -126,7 +166,18 @@ size_t sort_temp_bytes(uint32_t n) {
 
 }  // namespace
 
-size_t seed_workspace_bytes(uint32_t n) { return 6 * round256((size_t)n * 4 + 8) + round256(sort_temp_bytes(n)) + 256; }
+uint32_t seed_codes_stride(uint32_t max_len) { return (max_len + 7) / 8 + 1; }
+
+// keys, sorted keys, ids, order, info, masks, band masks (u32 per item), d_fb (u8), packed residue codes, sort temp, band buffer
+size_t seed_workspace_bytes(uint32_t n, uint32_t max_len) {
+    SeedParams p{};
+    p.M1 = SEED_M1;
+    p.M1_per8 = SEED_M1_PER8;
+    p.Wd = SEED_WD;
+    p.Wd_per16 = SEED_WD_PER16;
+    return 7 * round256((size_t)n * 4 + 8) + round256((size_t)n + 8) + round256((size_t)n * seed_codes_stride(max_len) * 4 + 8) +
+           round256(sort_temp_bytes(n)) + round256(seed_band_buffer_bytes(p, n, max_len)) + 256;
+}
 
 bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, uint32_t limit) {
     if (!ix.valid || !ix.usable || !ix.d_table || ref_len == 0 || ref_len >= (1u << 24)) return false;
@@ -134,11 +185,14 @@ bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, ui
     return (uint64_t)ix.params.maxw * max_len + 8 < limit;  // no score can leave the packed range
 }
 
-hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIndex& ix, uint8_t* work, size_t work_bytes, uint2* gtab,
-                               uint32_t* fail_list, uint32_t* fail_count, int mode, hipStream_t stream, KernelTimer* window_timer) {
+hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max_len, const SeedIndex& ix, uint8_t* work, size_t work_bytes,
+                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, bool band, hipStream_t stream,
+                               KernelTimer* window_timer) {
     const uint32_t n = a2.b.n_items;
     if (n == 0) return hipSuccess;
-    if (!work || !gtab || work_bytes < seed_workspace_bytes(n)) return hipErrorNotSupported;
+    if (!work || !gtab || work_bytes < seed_workspace_bytes(n, max_len)) return hipErrorNotSupported;
+    // score-only calls take the banded kernel (zsw_score_band.hip) when a strip's rows fit one drift period
+    band = band && mode == 0 && seed_band_applicable(ix.params, max_len, a2.K);
     const size_t per = round256((size_t)n * 4 + 8);
     uint32_t* keys = reinterpret_cast<uint32_t*>(work);
     uint32_t* keys_out = reinterpret_cast<uint32_t*>(work + per);
@@ -146,7 +200,16 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIn
     uint32_t* order = reinterpret_cast<uint32_t*>(work + 3 * per);
     uint32_t* info = reinterpret_cast<uint32_t*>(work + 4 * per);
     uint32_t* masks = reinterpret_cast<uint32_t*>(work + 5 * per);
-    void* temp = work + 6 * per;
+    uint32_t* band_masks = reinterpret_cast<uint32_t*>(work + 6 * per);
+    uint8_t* p8 = work + 7 * per;
+    uint8_t* band_dfb = p8;
+    p8 += round256((size_t)n + 8);
+    const uint32_t cs = seed_codes_stride(max_len);
+    uint32_t* codes = reinterpret_cast<uint32_t*>(p8);
+    p8 += round256((size_t)n * cs * 4 + 8);
+    void* temp = p8;
+    p8 += round256(sort_temp_bytes(n));
+    uint2* band_buf = reinterpret_cast<uint2*>(p8);
     size_t temp_bytes = sort_temp_bytes(n);
     int key_bits = 1;
     while ((1ull << key_bits) < (uint64_t)a2.ref_len + 2ull * SEED_KEY_BIAS + 2 && key_bits < 32) ++key_bits;
@@ -163,6 +226,10 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIn
     s.ids = ids;
     s.info = info;
     s.masks = masks;
+    s.band_masks = band_masks;
+    s.band_dfb = band_dfb;
+    s.codes = band ? codes : nullptr;
+    s.cs = cs;
     s.key_bias = SEED_KEY_BIAS;
     s.fail_key = fail_key;
     s.ref_len = a2.ref_len;
@@ -176,6 +243,36 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIn
                                                       key_bits, stream);
     if (e != hipSuccess) return e;
 
+    if (band) {
+        SeedBandArgs b;
+        b.b = a2.b;
+        b.ref_len = a2.ref_len;
+        b.ge2 = a2.ge2;
+        b.gd2 = a2.gd2;
+        b.floor0 = a2.floor0;
+        b.rule = a2.rule;
+        b.out = a2.out;
+        b.sp = ix.params;
+        b.n = n;
+        b.order = order;
+        b.keys = keys;
+        b.info = info;
+        b.band_masks = band_masks;
+        b.band_dfb = band_dfb;
+        b.codes = codes;
+        b.cs = cs;
+        b.gtab = gtab;
+        b.bnd = band_buf;
+        b.nb = seed_band_rows(ix.params, max_len);
+        b.key_bias = SEED_KEY_BIAS;
+        b.fail_key = fail_key;
+        b.fail_list = fail_list;
+        b.fail_count = fail_count;
+        if (window_timer) window_timer->begin(stream);
+        e = launch_seed_band(b, stream);
+        if (window_timer) window_timer->end(stream);
+        return e;
+    }
     SeedWindowArgs w;
     w.b = a2.b;
     w.ref = a2.ref;
@@ -231,6 +328,9 @@ hipError_t seed_index_update(SeedIndex* ix, const ScoringDev& sc, const uint8_t*
     p.M1_per8 = SEED_M1_PER8;
     p.M2 = SEED_M2;
     p.Dn = SEED_DN;
+    p.Dm = SEED_DM;
+    p.Wd = SEED_WD;
+    p.Wd_per16 = SEED_WD_PER16;
     p.tol = SEED_TOL;
     const size_t entries = size_t(1) << (2 * K);
     std::vector<uint32_t> table(2 * entries, 0u);

@@ -10,7 +10,12 @@ constexpr int SEED_M1 = 24;   // window rows above the first row of the anchor d
 constexpr int SEED_M1_PER8 = 1;  // gap_extend is the price of a path that comes down to the anchor from above the window)
 constexpr int SEED_M2 = 16;   // and below its last row (the read's own deletions)
 constexpr int SEED_DN = 4;    // diagonals left of the anchor that count as near (the read's own insertions)
-constexpr int SEED_TOL = 8;   // anchor vote tolerance
+constexpr int SEED_TOL = 8;    // anchor vote tolerance
+constexpr int SEED_DM = 4;     // banded pass: diagonals right of the anchor that count as near (the read's own deletions)
+constexpr int SEED_WD = 9;     // banded pass: diagonals kept below the anchor, SEED_WD + len * SEED_WD_PER16 / 16 (18 for 150 bases;
+constexpr int SEED_WD_PER16 = 1;  // coming back from beyond them takes insertions: the gap and the inserted columns' potential)
+constexpr int SEED_BAND_SLACK = 32;           // banded pass: two reads share a lane if their anchors are at most this far apart
+constexpr uint32_t SEED_BAND_MAX_GRID = 1024;  // banded pass: persistent blocks (each lane owns a boundary buffer in HBM)
 constexpr uint32_t SEED_KEY_BIAS = 1u << 16;  // sort key = anchor diagonal + bias (reads of up to 65,535 bases)
 constexpr uint32_t SEED_MAX_LEN = 2432;       // the widest strip configuration
 constexpr uint32_t SEED_MIN_LEN = 24;
@@ -48,18 +53,47 @@ struct SeedWindowArgs {
     uint32_t* fail_count;
 };
 
+// banded pass (zsw_score_band.hip): one read pair per lane, strips of query columns
+struct SeedBandArgs {
+    BatchDev b;
+    uint32_t ref_len;
+    uint32_t ge2, gd2, floor0;
+    ResultRule rule;
+    ScoreOut out;
+    SeedParams sp;
+    uint32_t n;
+    const uint32_t* order;
+    const uint32_t* keys;
+    const uint32_t* info;        // t_all | d_fa << 16 | d_bl << 24
+    const uint32_t* band_masks;  // fa_mask | fb_mask << 16
+    const uint8_t* band_dfb;     // d_fb
+    const uint32_t* codes;       // [item][cs]: the read as 4-bit residue codes, 15 = padding
+    uint32_t cs;                 // dwords per read in `codes`
+    const uint2* gtab;
+    uint2* bnd;                  // [block][nb][BLOCK]: the strip boundary of each lane (true scores: H of the last column, outgoing F)
+    uint32_t nb;
+    uint32_t key_bias, fail_key;
+    uint32_t* fail_list;
+    uint32_t* fail_count;
+};
+uint32_t seed_band_rows(const SeedParams& p, uint32_t max_len);
+size_t seed_band_buffer_bytes(const SeedParams& p, uint32_t n, uint32_t max_len);
+bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase_rows);
+hipError_t launch_seed_band(const SeedBandArgs& a, hipStream_t stream);
+
 struct ScoreArgsV2;
 
 // bytes of workspace for a range of n items
-size_t seed_workspace_bytes(uint32_t n);
+size_t seed_workspace_bytes(uint32_t n, uint32_t max_len);
 // can reads of up to max_len bases be seeded with this index, given the packed kernels' score limit?
 bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, uint32_t limit);
 // Seeds, sorts and runs the window kernel (strip configuration G x C of a2's tables) over the items of a2.b; reads without an
 // anchor and reads whose bounds fail are appended to fail_list (count at fail_count, not reset here).
 // gtab: (ref_len + 2 * SEED_GTAB_PAD) uint2, filled by seed_build_gtab (once per call of launch_score, from a2's tables).
 hipError_t seed_build_gtab(const ScoreArgsV2& a2, uint2* gtab, hipStream_t stream);
-hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, const SeedIndex& ix, uint8_t* work, size_t work_bytes, uint2* gtab,
-                               uint32_t* fail_list, uint32_t* fail_count, int mode, hipStream_t stream, KernelTimer* window_timer);
+hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max_len, const SeedIndex& ix, uint8_t* work, size_t work_bytes,
+                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, bool band, hipStream_t stream,
+                               KernelTimer* window_timer);
 // (Re)builds the index for a reference given as residue indices on the host.
 hipError_t seed_index_update(SeedIndex* ix, const ScoringDev& sc, const uint8_t* h_ref, size_t ref_len);
 void seed_index_release(SeedIndex* ix);

@@ -51,6 +51,8 @@ struct SeedParams {
     int M1, M1_per8;  // window rows above the first row of the anchor diagonal: M1 + len * M1_per8 / 8
     int M2;           // and below its last row
     int Dn;           // diagonals left of the anchor that still count as "near" (the read's own insertions)
+    int Dm;           // and right of it (the read's own deletions) — banded pass
+    int Wd, Wd_per16; // banded pass: diagonals kept below the anchor, Wd + len * Wd_per16 / 16 (above it: the rows of seed_rows_above)
     int tol;          // anchor vote: k-mers within this many diagonals support each other
     uint8_t code[32]; // residue index -> 2-bit code; 0xff: not a good residue
     uint8_t wp[32];   // residue index of the READ -> potential of a column holding it
@@ -152,6 +154,9 @@ ZSW_SEED_HD int seed_exit_bound(int v, int x, int m, int c0, int stride, int len
 // window rows kept above the first row of a read's anchor diagonal: what a path pays to come down to the anchor from above the
 // window (gap_open + (rows - Dn) * gap_extend) should exceed what a read of this length loses to its own errors
 ZSW_SEED_HD int seed_rows_above(const SeedParams& p, int len) { return p.M1 + len * p.M1_per8 / 8; }
+// banded pass: diagonals kept below the anchor diagonal. Leaving the band downwards and coming back costs a deletion and an
+// insertion of about this many positions; that, too, should exceed what a read of this length loses to its own errors
+ZSW_SEED_HD int seed_rows_below(const SeedParams& p, int len) { return p.Wd + len * p.Wd_per16 / 16; }
 
 struct SeedBounds {
     int above, below;  // -1: no such path exists (the window touches that end of the reference)
@@ -182,6 +187,10 @@ struct SeedRead {
     int d_fa;   // t_all - (bound of the paths that stay left of diagonal dt - Dn), capped at 255
     int d_bl;   // t_all - (bound of the paths below row dt + len + M2), capped at 255
     uint32_t bl_mask;  // bit j: sampled k-mer j is usable and does not occur at or below row dt + len + M2 (the exit bound's set)
+    // banded pass (seed_band_kernel): the same by diagonals — fa: no occurrence on a diagonal < dt - Dn (d_fa above), fb: none on a
+    // diagonal > dt + Dm
+    int d_fb;          // t_all - (bound of the paths that stay right of diagonal dt + Dm), capped at 255
+    uint32_t fa_mask, fb_mask;
 };
 
 // cell(c): what the seed kernel needs of query column c: potential Wp in bits 0-7, 2-bit code in bits 8-15 (0xff: the residue is
@@ -197,6 +206,8 @@ ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetCell cell, Looku
     out.d_fa = 0;
     out.d_bl = 0;
     out.bl_mask = 0;
+    out.d_fb = 0;
+    out.fa_mask = out.fb_mask = 0;
     int m, stride, c0;
     seed_layout(len, p.K, p.spacer, &m, &stride, &c0);
     // one sweep over the columns, k-mer by k-mer (the loops over the k-mers have a fixed trip count: their arrays stay in registers)
@@ -238,12 +249,15 @@ ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetCell cell, Looku
     int dt = 0;
     const int support = seed_vote(m, has, dlo, dhi, p.tol, &dt);
     if (support < (m >= 3 ? 2 : 1)) return out;
-    bool fa[SEED_MAX_KMERS], bl[SEED_MAX_KMERS];
+    bool fa[SEED_MAX_KMERS], bl[SEED_MAX_KMERS], fb[SEED_MAX_KMERS];
 #pragma unroll
     for (int i = 0; i < SEED_MAX_KMERS; ++i) {
         fa[i] = i < m && usable[i] && (!has[i] || dlo[i] >= dt - p.Dn);
         bl[i] = i < m && usable[i] && (!has[i] || last[i] < dt + len + p.M2);
+        fb[i] = i < m && usable[i] && (!has[i] || dhi[i] <= dt + p.Dm);
         out.bl_mask |= bl[i] ? 1u << i : 0u;
+        out.fa_mask |= fa[i] ? 1u << i : 0u;
+        out.fb_mask |= fb[i] ? 1u << i : 0u;
     }
     const int lam = seed_lambda(p, stride);
     const int u_fa = seed_span_bound(m, pot_lo, pot_hi, pot, fa, lam);
@@ -252,7 +266,84 @@ ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetCell cell, Looku
     out.dt = dt;
     out.d_fa = pot - u_fa > 255 ? 255 : pot - u_fa;
     out.d_bl = pot - u_bl > 255 ? 255 : pot - u_bl;
+    const int u_fb = seed_span_bound(m, pot_lo, pot_hi, pot, fb, lam);
+    out.d_fb = pot - u_fb > 255 ? 255 : pot - u_fb;
     return out;
+}
+
+// ---- banded pass (seed_band_kernel): the computed cells are a band of diagonals around the anchor, strip by strip ----------
+// Strip k holds query columns [kC, (k+1)C) and the reference rows [dt + kC - Wu, dt + (k+1)C + Wd). Every cell above the band
+// ("upper": right of it in a row) lies on a diagonal <= dt - Wu - 1, every cell below it ("lower") on a diagonal >= dt + Wd + 1.
+// A path with a cell outside the band either starts out there or leaves the band from a computed cell; from its first outside
+// cell on:
+//   upper  it never reaches diagonal dt - Dn again — then every k-mer it traverses exactly sits at an occurrence left of that
+//          diagonal, and the k-mers of fa_mask cost lambda each — or it does, by deleting at least Wu + 1 - Dn reference rows:
+//          seed_gap_up;
+//   lower  it never gets back to diagonal dt + Dm — k-mers of fb_mask cost lambda — or it does, by inserting at least
+//          Wd + 1 - Dm query columns, which cost the gap AND the potential of those columns (at least maxw each, less the read's
+//          total deficit maxw * len - t_all): seed_gap_down.
+// So: a fresh start outside scores at most t_all - min(d_fa, gap_up) resp. t_all - min(d_fb, gap_down); an exit from a computed
+// cell with value v in column x at most v + max(suffix bound of the mask (seed_exit_bound), maxw * (len - 1 - x) - gap)
+// (seed_band_upper / seed_band_lower, which also count how far outside the band's edge the exit cell's successor lies).
+ZSW_SEED_HD int seed_gap_up(const SeedParams& p, int wu) {
+    const int need = wu + 1 - p.Dn;
+    return need >= 1 ? p.go + (need - 1) * p.ge : 0;
+}
+ZSW_SEED_HD int seed_gap_down(const SeedParams& p, int wd, int len, int t_all) {
+    const int need = wd + 1 - p.Dm;
+    if (need < 1) return 0;
+    const int lost = p.maxw * need - (p.maxw * len - t_all);
+    return p.go + (need - 1) * p.ge + (lost > 0 ? lost : 0);
+}
+// An exit cell that lies e diagonals further out than the band's edge needs e more gap positions to come back, except for the
+// first one (the diagonal step out of a cell one diagonal inside the edge lands on the edge's neighbour all the same): the
+// kernel keeps, next to the plain maximum of the exit values, the maximum of [value - gap_extend * max(e - 1, 0)], and the lower
+// exits, whose way back also loses the inserted columns' potential, add maxw for e >= 1 only (instead of maxw * e).
+// seed_gap_down(wd + e') >= seed_gap_down(wd) + (ge + maxw) * e' - seed_gap_down_slack: the potential lost to insertions is
+// counted from the read's total deficit on only.
+ZSW_SEED_HD int seed_gap_down_slack(const SeedParams& p, int wd, int len, int t_all) {
+    const int need = wd + 1 - p.Dm;
+    const int d = (p.maxw * len - t_all) - p.maxw * need;
+    return d > 0 ? d : 0;
+}
+// Upper exits of a strip whose last column is xl (right edge, rows above the next strip's first row; e = rows above the last of
+// them): uk = max v, ug = max [v - ge * max(e - 1, 0)] (floored at 0) over the exit cells' values v = max(H, outgoing F).
+template <typename Q>
+ZSW_SEED_HD int seed_band_upper(const SeedParams& p, int uk, int ug, int xl, int len, int wu, int m, int c0, int stride, const Q* q_fa) {
+    if (xl >= len - 1) return -1;  // no column left: the path ends here, the band's own maximum covers it
+    // The outgoing F is an insertion run already open: it swallows the next columns at ins_col each, and running into a k-mer that
+    // starts fewer than `spacer` columns away costs it less than lambda (seed_analyze chose the spacer so that a run across a whole
+    // spacer and into the k-mer pays lambda). Such a k-mer counts as plain potential: i = the first one at least `spacer` columns on.
+    int i = 0;
+    if (m > 0 && xl + p.spacer >= c0) {
+        i = (xl + p.spacer - c0) / stride + 1;
+        if (i > m) i = m;
+    }
+    const int ci = i < m ? c0 + i * stride : len;
+    const int via_kmers = uk + p.maxw * (ci - 1 - xl) + (int)q_fa[i];
+    const int via_gap = (wu + 1 - p.Dn >= 1 ? ug : uk) + p.maxw * (len - 1 - xl) - seed_gap_up(p, wu);
+    return via_gap > via_kmers ? via_gap : via_kmers;
+}
+// Lower exits of a strip of C columns ending in column xl (last row; e = C - 1 - c for the strip's column c): with
+// he(c) = max(H, E of the next row) of the exit cell, mk = max [he(c) + maxw * e], mg = max [he(c) - ge * max(e - 1, 0) +
+// (e >= 1 ? maxw : 0)] (the first term floored at 0). Columns at or beyond the read's end only raise the two maxima.
+template <typename Q>
+ZSW_SEED_HD int seed_band_lower(const SeedParams& p, int mk, int mg, int xl, int len, int wd, int t_all, int m, int c0, int stride, const Q* q_fb) {
+    if (xl >= len - 1) {  // the read's last strip: nothing beyond column len - 1 (he(c) + maxw * (len - 1 - c) <= mk - maxw * (xl - (len - 1)))
+        const int v = mk - p.maxw * (xl - (len - 1));
+        return v > 0 ? v : 0;
+    }
+    int i = 0;
+    if (m > 0 && xl >= c0) {
+        i = (xl - c0) / stride + 1;
+        if (i > m) i = m;
+    }
+    const int ci = i < m ? c0 + i * stride : len;
+    int via_kmers = p.maxw * (ci - 1 - xl) + (int)q_fb[i];
+    via_kmers = mk + (via_kmers > 0 ? via_kmers : 0);
+    const int need = wd + 1 - p.Dm;
+    const int via_gap = (need >= 1 ? mg + seed_gap_down_slack(p, wd, len, t_all) : mk) + p.maxw * (len - 1 - xl) - seed_gap_down(p, wd, len, t_all);
+    return via_gap > via_kmers ? via_gap : via_kmers;
 }
 
 // Certificate for the late start of the alignment's second pass (sw_simd_align's flags, striped.rs:449-598, recomputed for the
