@@ -9,7 +9,8 @@ One process per GPU.  A "step" is one pass of the hot path (`read.into_local_pro
 for every read, i.e. zsw_score_batch_from) over the rank's batch of synthetic reads, already resident in HBM,
 followed — for N > 1 — by the RCCL all-gather of the per-read scores and statuses (the only exchange the path
 has; one collective per step, zoe_amd/dist.py).  `value` is the library's default path: the seeded exact pass
-(zsw_score_seed.hip: k-mer anchors, the rows around them, bound checks, the full pass for the reads handed back —
+(zsw_score_seed.hip, zsw_score_band.hip: k-mer anchors, a band of diagonals around them, bound checks, the full pass for the
+reads handed back —
 bit-identical to computing every cell, which the run verifies on ALL reads and reports beside it).
 Workloads (BASELINE.json):
   N = 1  configs[1]: 10 M reads on the GPU.
@@ -36,12 +37,14 @@ sys.path.insert(0, ROOT)
 READ_LEN = 150
 REF_LEN = 2000
 ALGO_BYTES_PER_READ = READ_LEN + 4  # read bytes in + u32 score out
-# seed_window_kernel<4,38,0> on the 10 M-read headline batch, from committed rocprofv3 --pmc passes (separate runs; FETCH_SIZE with
-# the gfx950 x2 correction for wide streaming reads is NOT applied to this kernel's scattered 150-byte read gathers: the raw
-# counter is reported). CONSTANTS from that profile, not measurements of this run (the bench line says so).
-PMC_PROFILE = "profiles/r03_seed_summary.txt"
-WINDOW_HBM_BYTES_PER_READ = 417.9  # FETCH_SIZE 323.6 + WRITE_SIZE 94.3 B per read (scattered 150-byte read gathers, 4-byte result scatters)
-WINDOW_VALU_PER_READ = 2047        # SQ_INSTS_VALU of the window kernel per read (2.047e10 per 10 M-read launch)
+# seed_band_kernel<32,3> on the 10 M-read headline batch, from committed rocprofv3 --pmc passes (separate runs; the gfx950 x2
+# correction for wide streaming reads is NOT applied to FETCH_SIZE: the kernel's loads are 8-byte strip-boundary rows and 4-byte
+# code words, the raw counter is reported). CONSTANTS from that profile, not measurements of this run (the bench line says so).
+# Nearly all of it is the strip boundary (H and outgoing F of a strip's last column, 8 bytes per row and read pair, written once
+# and read once by the same lane: ~96 MB in flight, beyond the 32 MB of L2).
+PMC_PROFILE = "profiles/r03_band_summary.txt"
+WINDOW_HBM_BYTES_PER_READ = 2354.1  # FETCH_SIZE 1168.1 + WRITE_SIZE 1186.0 B per read
+WINDOW_VALU_PER_READ = 979          # SQ_INSTS_VALU of the banded kernel per read (9.793e9 per 10 M-read launch)
 VALU_PEAK_SOURCE = "profiles/r01_valu_issue_rates_ubench.txt"  # this repo's micro-benchmark (tools/ubench.hip), not a figure of the guide
 TOTAL_READS_MULTI_GPU = 500_000_000  # BASELINE.json configs[3]
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
@@ -474,7 +477,7 @@ def main():
         pass_s = kern_s / max(launches, 1)             # the whole first pass: seed + sort + window + full pass over the handed-back reads
         seeded = win_launches > 0
         kern = win_s / win_launches if seeded else pass_s  # the dominant kernel alone
-        kernel_name = "zsw::seed_window_kernel<4,38,0>" if seeded else "zsw::score_kernel_v2<4,38,0>"
+        kernel_name = "zsw::seed_band_kernel<32,3>" if seeded else "zsw::score_kernel_v2<4,38,0>"
         achieved = ALGO_BYTES_PER_READ * n_local / kern / 1e9 if kern > 0 else 0.0
         traffic = WINDOW_HBM_BYTES_PER_READ * n_local if (seeded and WINDOW_HBM_BYTES_PER_READ) else None
         out = {
@@ -501,7 +504,7 @@ def main():
                                 if world > 1 else "single GPU"),
             },
             "path": {
-                "default": "seeded exact pass (zsw_score_seed.hip): k-mer anchors -> rows around the anchor -> bound checks -> full pass for the reads handed back; "
+                "default": "seeded exact pass (zsw_score_seed.hip, zsw_score_band.hip): k-mer anchors -> a band of diagonals around the anchor -> bound checks -> full pass for the reads handed back; "
                            "bit-identical to computing every cell" if seeded else "full pass (every cell)",
                 "handed_back_fraction": handed_back / max(n_local, 1),
                 "first_pass_ms": pass_s * 1e3,
@@ -522,7 +525,7 @@ def main():
                 "kernel_ms": kern * 1e3,
                 "kernel_ms_source": "HIP events recorded around the kernel on its stream, inside this run",
                 "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
-                "note": "HBM is not the binding roof: packed-i16 VALU issue is (valu_roofline); the seeded pass raises the rate by computing fewer cells",
+                "note": "HBM is not the binding roof: packed-i16 VALU issue is (valu_roofline); the seeded pass raises the rate by computing fewer cells; traffic is the strip boundary of the banded kernel",
             },
             "parity_checked_reads": args.verify if verified else 0,
         }
