@@ -331,7 +331,9 @@ typedef enum zsw_debug_flag {
     ZSW_DEBUG_ALIGN_LONG_WARMUP = 1024,
     /* score: the seeded pass computes whole rows around the anchor (seed_window_kernel) for score-only calls too, instead of the
      * band of diagonals of seed_band_kernel (zsw_score_band.hip) */
-    ZSW_DEBUG_SEED_NO_BAND = 2048
+    ZSW_DEBUG_SEED_NO_BAND = 2048,
+    /* score: the banded kernel walks every read in the full band at once (no narrow first band for short reads) */
+    ZSW_DEBUG_SEED_WIDE_BAND = 4096
 } zsw_debug_flag;
 zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags);
 

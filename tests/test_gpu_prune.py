@@ -28,16 +28,16 @@ def za():
     return zoe_amd
 
 
-@pytest.fixture(params=["seeded", "window", "strip"])
+@pytest.fixture(params=["seeded", "wide", "window", "strip"])
 def pruned(za, request):
     """The context with a pruned pass switched on for batches of every size: the seeded pass (score-only calls: the banded
-    kernel, zsw_score_band.hip), the seeded pass with whole rows for score-only calls too (seed_window_kernel), or round 2's
-    strip + window pass."""
+    kernel, zsw_score_band.hip — a narrow band first, the full band for the reads that fail in it), the same with the full band
+    at once, the seeded pass with whole rows for score-only calls too (seed_window_kernel), or round 2's strip + window pass."""
     from zoe_amd import _lib
 
     ctx = za.SwContext.get(0)
     ctx.kind = request.param
-    extra = {"seeded": 0, "window": _lib.DEBUG_SEED_NO_BAND, "strip": _lib.DEBUG_PRUNE_STRIP}[request.param]
+    extra = {"seeded": 0, "wide": _lib.DEBUG_SEED_WIDE_BAND, "window": _lib.DEBUG_SEED_NO_BAND, "strip": _lib.DEBUG_PRUNE_STRIP}[request.param]
     ctx.debug_set(_lib.DEBUG_SCORE_PRUNE_ANY_SIZE | extra)
     yield ctx
     ctx.debug_set(0)

@@ -199,6 +199,8 @@ def test_banded_pass_pairs_lengths_and_edges(za, oracle):
         reads = synth.reads_host(ref, 9, 1501, 150)
         ctx.debug_set(_lib.DEBUG_SCORE_PRUNE_ANY_SIZE)
         back_band = _oracle_check(za, oracle, reads, dna, -10, -1, ref)
+        ctx.debug_set(_lib.DEBUG_SCORE_PRUNE_ANY_SIZE | _lib.DEBUG_SEED_WIDE_BAND)
+        _oracle_check(za, oracle, reads, dna, -10, -1, ref)  # the full band at once
         ctx.debug_set(_lib.DEBUG_SCORE_PRUNE_ANY_SIZE | _lib.DEBUG_SEED_NO_BAND)
         back_window = _oracle_check(za, oracle, reads, dna, -10, -1, ref)
         assert back_window < 150 and back_band < 900, (back_band, back_window)

@@ -544,7 +544,9 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         if (pe != hipSuccess) return pe;
         ap.b = bb;
         pe = launch_score_seeded(ap, g, c, longest, *ws.seed, ws.seed_work + work_off, seed_workspace_bytes(bb.n_items, longest), ws.seed_gtab,
-                                 ws.prune_fail_list + list_off, counter, mode, !(ws.debug & ZSW_DEBUG_SEED_NO_BAND), stream, ws.window_timer);
+                                 ws.prune_fail_list + list_off, counter, mode, !(ws.debug & ZSW_DEBUG_SEED_NO_BAND),
+                                 (ws.debug & ZSW_DEBUG_SEED_WIDE_BAND) ? 0xffffffffu : (ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE) ? 0u : SEED_NARROW_MIN_READS, stream,
+                                 ws.window_timer);
         if (pe != hipSuccess) return pe;
         ap.b.items = ws.prune_fail_list + list_off;
         ap.n_items_dev = counter;

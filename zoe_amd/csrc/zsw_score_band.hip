@@ -36,7 +36,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
     }
     __syncthreads();
     const int R = (int)a.ref_len;
-    const uint32_t n_pairs = (a.n + 1) / 2;
+    const uint32_t n_items = a.n_dev ? min(*a.n_dev, a.n) : a.n;
+    const uint32_t n_pairs = (n_items + 1) / 2;
     const uint32_t ge2 = a.ge2, gd2 = a.gd2;
     const uint32_t ge1 = ge2 & 0xffffu;
     const int maxw = a.sp.maxw;
@@ -48,15 +49,16 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
         const uint32_t ridA = a.order[itemA];
         const uint32_t keyA = a.keys[ridA];
         if (keyA == a.fail_key) break;  // sorted: every later pair of this lane is without an anchor too (the seed kernel listed them)
-        uint32_t ridB = itemB < a.n ? a.order[itemB] : ridA;
-        uint32_t keyB = itemB < a.n ? a.keys[ridB] : a.fail_key;
+        uint32_t ridB = itemB < n_items ? a.order[itemB] : ridA;
+        uint32_t keyB = itemB < n_items ? a.keys[ridB] : a.fail_key;
         bool validB = keyB != a.fail_key;
         const int dtA = (int)keyA - (int)a.key_bias;
         int dtB = validB ? (int)keyB - (int)a.key_bias : dtA;
         const uint32_t idA = a.b.items ? a.b.items[ridA] : ridA;
         uint32_t idB = validB ? (a.b.items ? a.b.items[ridB] : ridB) : idA;
-        if (validB && dtB - dtA > SEED_BAND_SLACK) {  // anchors too far apart to share a band: B takes the full pass
-            a.fail_list[atomicAdd(a.fail_count, 1u)] = idB;
+        if (validB && dtB - dtA > SEED_BAND_SLACK) {  // anchors too far apart to share a band: B waits for the next tier / takes the full pass
+            if (a.retry) a.retry[itemB] = 1;
+            else a.fail_list[atomicAdd(a.fail_count, 1u)] = idB;
             validB = false;
             dtB = dtA;
         }
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
         const uint32_t lenB = validB ? (a.b.offsets ? (uint32_t)(a.b.offsets[idB + 1] - a.b.offsets[idB]) : a.b.fixed_len) : 0u;
         const int lenmax = (int)max(lenA, lenB);
         const int n_strips = (lenmax + C - 1) / C;
-        const int wu = seed_rows_above(a.sp, lenmax), wd = seed_rows_below(a.sp, lenmax);
+        const int wu = a.wu0 + lenmax * a.wu_per16 / 16, wd = a.wd0 + lenmax * a.wd_per32 / 32;
         const int dtmin = min(dtA, dtB), dtmax = max(dtA, dtB);
         // what the seed kernel left: potentials, k-mer bounds, masks; the suffix bounds of the two masks per read
         const uint32_t infoA = a.info[ridA], infoB = a.info[ridB];
@@ -212,7 +214,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
             const uint32_t id = h ? idB : idA;
             const int S = h ? SB : SA, bound = h ? bndB : bndA;
             if ((h ? lenB : lenA) == 0 || bound > S) {
-                a.fail_list[atomicAdd(a.fail_count, 1u)] = id;
+                if (a.retry) a.retry[h ? itemB : itemA] = 1;
+                else a.fail_list[atomicAdd(a.fail_count, 1u)] = id;
             } else {
                 uint32_t score;
                 uint8_t status, tier;

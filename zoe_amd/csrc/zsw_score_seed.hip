@@ -157,11 +157,14 @@ __global__ void seed_gtab_kernel(const uint8_t* ref, uint32_t ref_len, const Sco
 
 size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// temporary storage of the radix sort and of the selection of the reads the full band walks again (the larger of the two)
 size_t sort_temp_bytes(uint32_t n) {
-    size_t bytes = 0;
+    size_t bytes = 0, sel = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
                                              (uint32_t*)nullptr, (int)n, 0, 32, (hipStream_t)0);
-    return bytes;
+    (void)hipcub::DeviceSelect::Flagged(nullptr, sel, (const uint32_t*)nullptr, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                        (int)n, (hipStream_t)0);
+    return std::max(bytes, sel);
 }
 
 }  // namespace
@@ -186,7 +189,7 @@ bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, ui
 }
 
 hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max_len, const SeedIndex& ix, uint8_t* work, size_t work_bytes,
-                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, bool band, hipStream_t stream,
+                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, bool band, uint32_t narrow_min_reads, hipStream_t stream,
                                KernelTimer* window_timer) {
     const uint32_t n = a2.b.n_items;
     if (n == 0) return hipSuccess;
@@ -268,7 +271,34 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
         b.fail_key = fail_key;
         b.fail_list = fail_list;
         b.fail_count = fail_count;
+        b.wu0 = ix.params.M1;
+        b.wu_per16 = 2 * ix.params.M1_per8;
+        b.wd0 = ix.params.Wd;
+        b.wd_per32 = 2 * ix.params.Wd_per16;
+        b.n_dev = nullptr;
+        b.retry = nullptr;
         if (window_timer) window_timer->begin(stream);
+        if (max_len <= SEED_NARROW_MAX_LEN && n >= narrow_min_reads) {
+            // two tiers: every read in a narrow band; the reads whose bounds fail there, still in anchor order, in the full band.
+            // The sort's input values and output keys are free by now: flags and the second tier's order.
+            uint8_t* retry = reinterpret_cast<uint8_t*>(ids);
+            uint32_t* order2 = keys_out;
+            uint32_t* n2 = reinterpret_cast<uint32_t*>(work + 3 * per + (size_t)n * 4);  // the 8 spare bytes behind `order`
+            e = hipMemsetAsync(retry, 0, n, stream);
+            if (e != hipSuccess) return e;
+            SeedBandArgs b1 = b;
+            b1.wu0 = SEED_NARROW_WU;
+            b1.wu_per16 = SEED_NARROW_WU_PER16;
+            b1.wd0 = SEED_NARROW_WD;
+            b1.wd_per32 = SEED_NARROW_WD_PER32;
+            b1.retry = retry;
+            e = launch_seed_band(b1, stream);
+            if (e != hipSuccess) return e;
+            e = hipcub::DeviceSelect::Flagged(temp, temp_bytes, (const uint32_t*)order, (const uint8_t*)retry, order2, n2, (int)n, stream);
+            if (e != hipSuccess) return e;
+            b.order = order2;
+            b.n_dev = n2;
+        }
         e = launch_seed_band(b, stream);
         if (window_timer) window_timer->end(stream);
         return e;

@@ -14,6 +14,12 @@ constexpr int SEED_TOL = 8;    // anchor vote tolerance
 constexpr int SEED_DM = 4;     // banded pass: diagonals right of the anchor that count as near (the read's own deletions)
 constexpr int SEED_WD = 9;     // banded pass: diagonals kept below the anchor, SEED_WD + len * SEED_WD_PER16 / 16 (18 for 150 bases;
 constexpr int SEED_WD_PER16 = 1;  // coming back from beyond them takes insertions: the gap and the inserted columns' potential)
+// A narrow first band for short reads (two tiers): most reads lose little to their own errors and prove their score inside
+// 12 + len/16 diagonals above and 6 + len/32 below the anchor; the reads that cannot are walked again in the full band
+// (SEED_M1 + len/8, SEED_WD + len/16), and only what fails there is scored over all its cells.
+constexpr int SEED_NARROW_WU = 12, SEED_NARROW_WU_PER16 = 1, SEED_NARROW_WD = 6, SEED_NARROW_WD_PER32 = 1;
+constexpr uint32_t SEED_NARROW_MAX_LEN = 192;  // beyond: a read's errors outgrow what a narrower band can prove
+constexpr uint32_t SEED_NARROW_MIN_READS = 200000;  // below: two more launches cost more than the narrower band saves (length classes of a ragged batch)
 constexpr int SEED_BAND_SLACK = 32;           // banded pass: two reads share a lane if their anchors are at most this far apart
 constexpr uint32_t SEED_BAND_MAX_GRID = 1024;  // banded pass: persistent blocks (each lane owns a boundary buffer in HBM)
 constexpr uint32_t SEED_KEY_BIAS = 1u << 16;  // sort key = anchor diagonal + bias (reads of up to 65,535 bases)
@@ -72,6 +78,9 @@ struct SeedBandArgs {
     const uint2* gtab;
     uint2* bnd;                  // [block][nb][BLOCK]: the strip boundary of each lane (true scores: H of the last column, outgoing F)
     uint32_t nb;
+    int wu0, wu_per16, wd0, wd_per32;  // this launch's band: wu0 + len * wu_per16 / 16 diagonals above the anchor, wd0 + len * wd_per32 / 32 below
+    const uint32_t* n_dev;             // non-null: the number of items in `order` (a device-side count, at most n)
+    uint8_t* retry;                    // non-null (first tier): a read whose bounds fail sets retry[its position in `order`] instead of joining the list
     uint32_t key_bias, fail_key;
     uint32_t* fail_list;
     uint32_t* fail_count;
@@ -87,12 +96,13 @@ struct ScoreArgsV2;
 size_t seed_workspace_bytes(uint32_t n, uint32_t max_len);
 // can reads of up to max_len bases be seeded with this index, given the packed kernels' score limit?
 bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, uint32_t limit);
+// narrow_min_reads: score-only calls of at least this many short reads walk a narrow band first (SEED_NARROW_*).
 // Seeds, sorts and runs the window kernel (strip configuration G x C of a2's tables) over the items of a2.b; reads without an
 // anchor and reads whose bounds fail are appended to fail_list (count at fail_count, not reset here).
 // gtab: (ref_len + 2 * SEED_GTAB_PAD) uint2, filled by seed_build_gtab (once per call of launch_score, from a2's tables).
 hipError_t seed_build_gtab(const ScoreArgsV2& a2, uint2* gtab, hipStream_t stream);
 hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max_len, const SeedIndex& ix, uint8_t* work, size_t work_bytes,
-                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, bool band, hipStream_t stream,
+                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, bool band, uint32_t narrow_min_reads, hipStream_t stream,
                                KernelTimer* window_timer);
 // (Re)builds the index for a reference given as residue indices on the host.
 hipError_t seed_index_update(SeedIndex* ix, const ScoringDev& sc, const uint8_t* h_ref, size_t ref_len);
