@@ -37,14 +37,15 @@ sys.path.insert(0, ROOT)
 READ_LEN = 150
 REF_LEN = 2000
 ALGO_BYTES_PER_READ = READ_LEN + 4  # read bytes in + u32 score out
-# seed_band_kernel<32,3> on the 10 M-read headline batch, from committed rocprofv3 --pmc passes (separate runs; the gfx950 x2
-# correction for wide streaming reads is NOT applied to FETCH_SIZE: the kernel's loads are 8-byte strip-boundary rows and 4-byte
-# code words, the raw counter is reported). CONSTANTS from that profile, not measurements of this run (the bench line says so).
-# Nearly all of it is the strip boundary (H and outgoing F of a strip's last column, 8 bytes per row and read pair, written once
-# and read once by the same lane: ~96 MB in flight, beyond the 32 MB of L2).
+# seed_band_kernel<32,3> on the 10 M-read headline batch — TWO launches per step: the narrow band over every read, then the full
+# band over the ~11 % of reads whose bounds fail in it (a hipCUB selection in between) — from committed rocprofv3 --pmc passes
+# (separate runs; the gfx950 x2 correction for wide streaming reads is NOT applied to FETCH_SIZE: the kernel's loads are 8-byte
+# strip-boundary rows and 4-byte code words, the raw counter is reported). CONSTANTS from that profile, not measurements of this
+# run (the bench line says so). Nearly all of the traffic is the strip boundary (H and outgoing F of a strip's last column,
+# 8 bytes per row and read pair, written once and read once by the same lane: ~70 MB in flight, beyond the 32 MB of L2).
 PMC_PROFILE = "profiles/r03_band_summary.txt"
-WINDOW_HBM_BYTES_PER_READ = 2354.1  # FETCH_SIZE 1168.1 + WRITE_SIZE 1186.0 B per read
-WINDOW_VALU_PER_READ = 979          # SQ_INSTS_VALU of the banded kernel per read (9.793e9 per 10 M-read launch)
+WINDOW_HBM_BYTES_PER_READ = 1932.5  # FETCH_SIZE 934.2 + 131.1, WRITE_SIZE 734.0 + 133.2 B per read of the batch (narrow + full band launch)
+WINDOW_VALU_PER_READ = 789          # SQ_INSTS_VALU per read of the batch: 684 (narrow band, 6.841e9 per launch) + 105 (full band over the rest)
 VALU_PEAK_SOURCE = "profiles/r01_valu_issue_rates_ubench.txt"  # this repo's micro-benchmark (tools/ubench.hip), not a figure of the guide
 TOTAL_READS_MULTI_GPU = 500_000_000  # BASELINE.json configs[3]
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
@@ -165,9 +166,14 @@ def file_tag(rel: str) -> str:
 
 WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4  # wave64 VALU instructions/s: 1,024 SIMDs, one per 4 cycles at 2.4 GHz (VALU_PEAK_SOURCE)
 # VALU wave-instructions per read of the pass-2 / score kernels, from committed rocprofv3 --pmc SQ_INSTS_VALU passes
-# (constants from those profiles, not measured in the bench run): see profiles/r02_align_pk_pmc.txt
-ALIGN_PK_VALU_PER_READ = 21_279
-ALIGN_PK_PROFILE = "profiles/r02_align_pk_pmc.txt"
+# (constants from those profiles, not measured in the bench run): tools/pmc_entry.py, one entry point per run, every kernel of
+# the call summed (profiles/r03_secondary_valu.txt; per-phase budget of the packed alignment kernel: profiles/r02_align_pk_pmc.txt)
+SECONDARY_VALU_PROFILE = "profiles/r03_secondary_valu.txt"
+ALIGN_PK_VALU_PER_READ = 15_462   # align_kernel_pk<16,10> 14,789 + <32,5> 673 (pass 2 alone: what pass2_kernel_ms times)
+ALIGN_PK_PROFILE = SECONDARY_VALU_PROFILE
+RANGES_VALU_PER_READ = 5_808      # window kernel 2,372 + reverse pass 2,830 + handed-back reads 525 + seed kernel 66
+THREEPASS_VALU_PER_READ = 6_024   # the same + threepass_kernel 212
+MIXED_VALU_PER_READ = 16_114      # 75-400 bp vs 30 kb: 13,800 of them are the full pass over the 3 % of reads handed back
 
 
 def rooflines(algo_bytes: float, kernel_s: float, valu_instr: float = None, source: str = None):
@@ -268,7 +274,7 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     entry = {"reads_per_s_end_to_end_incl_d2h": n_full / dt, "pass2_kernel_ms": ks * 1e3, "pass2_kernel_ms_per_1M_reads": ks * 1e3 / (n_full / 1e6),
              "ciglets": n_cig, "aligned_reads": n_some,
              "call": "into_local_profile(..).sw_align_from_i8(SeqSrc::Reference(ref)) (CIGAR of the i16x16 / i8x32 tier), 10 M reads (BASELINE.json configs[2] at full size)",
-             "kernel": "zsw::align_kernel_pk<16,10> (+ <32,5> for the reads that answer at i8x32); pass 1 = the seeded exact pass (seed_window_kernel<4,38,1>)"}
+             "kernel": "zsw::align_kernel_pk<16,10> (+ <32,5> for the reads that answer at i8x32); pass 1 = the seeded exact pass (seed_window_kernel<4,38,1>: 2,092 more VALU instructions per read)"}
     # algorithmic bytes: read in, record out (score, 4 coordinates, 2 lengths, count, offset = 40 B), 5 B per ciglet
     entry.update(rooflines(n_full * (READ_LEN + 4.0) + n_some * 40.0 + n_cig * 5.0, ks, ALIGN_PK_VALU_PER_READ * n_full, ALIGN_PK_PROFILE))
     ap, dtp, ksp = with_full_first_pass(lambda: prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref2k)))
@@ -285,7 +291,8 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     a3, dt, ks = timed(lambda: prof.sw_align_from_i8_3pass(zoe_amd.SeqSrc.Reference(ref2k)))
     entry = {"reads_per_s_end_to_end_incl_d2h": 1_000_000 / dt, "kernels_ms": ks * 1e3, "ciglets": int(len(a3.inc)),
              "call": "into_local_profile(..).sw_align_from_i8_3pass(SeqSrc::Reference(ref)) (three_pass.rs: ranges, then no-gaps / banded / scalar in the box)"}
-    entry.update(rooflines(1e6 * (READ_LEN + 4.0) + float((a3.status == 0).sum()) * 40.0 + len(a3.inc) * 5.0, ks))
+    entry.update(rooflines(1e6 * (READ_LEN + 4.0) + float((a3.status == 0).sum()) * 40.0 + len(a3.inc) * 5.0, ks, THREEPASS_VALU_PER_READ * 1e6,
+                           SECONDARY_VALU_PROFILE))
     ap, dtp, ksp = with_full_first_pass(lambda: prof.sw_align_from_i8_3pass(zoe_amd.SeqSrc.Reference(ref2k)))
     entry["with_full_first_pass"] = {"reads_per_s_end_to_end_incl_d2h": 1_000_000 / dtp, "kernels_ms": ksp * 1e3,
                                        "identical": bool(np.array_equal(ap.status, a3.status) and np.array_equal(ap.records, a3.records)
@@ -296,7 +303,7 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     sp = zoe_amd.StripedProfileBatch(rb, matrix, -10, -1, T="i16", N=16, device=ctx.device)
     rg, dt, ks = timed(lambda: sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k)))
     entry = {"reads_per_s": 1_000_000 / dt, "kernels_ms": ks * 1e3, "call": "StripedProfile::<i16,16,5>::sw_score_ranges(SeqSrc::Reference(ref))"}
-    entry.update(rooflines(1e6 * (READ_LEN + 4.0 + 16.0), max(ks, 1e-9) if ks > 0 else dt))
+    entry.update(rooflines(1e6 * (READ_LEN + 4.0 + 16.0), max(ks, 1e-9) if ks > 0 else dt, RANGES_VALU_PER_READ * 1e6, SECONDARY_VALU_PROFILE))
     rp_, dtp, ksp = with_full_first_pass(lambda: sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k)))
     entry["with_full_first_pass"] = {"reads_per_s": 1_000_000 / dtp, "kernels_ms": ksp * 1e3,
                                        "identical": all(bool(torch.equal(getattr(rp_, f), getattr(rg, f)))
@@ -322,7 +329,7 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     cells = total_bases * 30000
     entry = {"reads_per_s": 1_000_000 / dt, "kernel_ms": ks * 1e3,
              "call": "sw_score_from_i8, reads bucketed by strip configuration on the device, seeded exact pass per length class"}
-    entry.update(rooflines(total_bases + 1e6 * (8.0 + 4.0), dt))
+    entry.update(rooflines(total_bases + 1e6 * (8.0 + 4.0), dt, MIXED_VALU_PER_READ * 1e6, SECONDARY_VALU_PROFILE))
     entry["gcups"] = "equivalent: the cells of the full matrices per second (the seeded pass computes about one in ninety of them)"
     entry["gcups_equivalent"] = cells / dt / 1e9
     del entry["gcups"]
@@ -477,7 +484,7 @@ def main():
         pass_s = kern_s / max(launches, 1)             # the whole first pass: seed + sort + window + full pass over the handed-back reads
         seeded = win_launches > 0
         kern = win_s / win_launches if seeded else pass_s  # the dominant kernel alone
-        kernel_name = "zsw::seed_band_kernel<32,3>" if seeded else "zsw::score_kernel_v2<4,38,0>"
+        kernel_name = "zsw::seed_band_kernel<32,3> (two launches per step: narrow band over every read + full band over the reads that fail in it)" if seeded else "zsw::score_kernel_v2<4,38,0>"
         achieved = ALGO_BYTES_PER_READ * n_local / kern / 1e9 if kern > 0 else 0.0
         traffic = WINDOW_HBM_BYTES_PER_READ * n_local if (seeded and WINDOW_HBM_BYTES_PER_READ) else None
         out = {
@@ -523,7 +530,7 @@ def main():
                                   if traffic else None,
                 "kernel": kernel_name,
                 "kernel_ms": kern * 1e3,
-                "kernel_ms_source": "HIP events recorded around the kernel on its stream, inside this run",
+                "kernel_ms_source": "HIP events recorded around the kernel launches (both tiers and the selection between them) on their stream, inside this run",
                 "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
                 "note": "HBM is not the binding roof: packed-i16 VALU issue is (valu_roofline); the seeded pass raises the rate by computing fewer cells; traffic is the strip boundary of the banded kernel",
             },

@@ -20,8 +20,9 @@ for r in keep:
     out.append(f"{r['Name'][:96]:96s} calls={r['Calls']} avg_ms={float(r['AverageNs'])/1e6:.3f} min_ms={float(r['MinNs'])/1e6:.3f} max_ms={float(r['MaxNs'])/1e6:.3f} share={float(r['TotalDurationNs'])/total:.3f}")
     dur[r["Name"]] = float(r["AverageNs"]) / 1e9
 names = [r["Name"] for r in keep]
+trace = collections.defaultdict(list)
 for f in glob.glob(f"{src}/stats/*/*kernel_trace.csv"):
-    d = collections.defaultdict(list)
+    d = trace
     for r in csv.DictReader(open(f)):
         if r["Kernel_Name"] in names:
             d[r["Kernel_Name"]].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6)
@@ -50,14 +51,24 @@ for k in sorted(vals):
         if small:
             line += f"   small {sum(small)/len(small):.4g} (x{len(small)})"
         out.append(line)
-    v = {c: max(x) for c, x in vals[k].items()}
-    t = dur.get(k)
-    if t and "SQ_INSTS_VALU" in v and "score_kernel_v2" not in k:
-        clk = v.get("GRBM_GUI_ACTIVE", 0) / 8 / t if v.get("GRBM_GUI_ACTIVE") else 2.4e9
-        out.append(f"    -> avg {t*1e3:.3f} ms; cycles per wave64 VALU instruction = 1024 SIMDs x t x clk({clk/1e9:.2f} GHz) / SQ_INSTS_VALU = {1024*t*clk/v['SQ_INSTS_VALU']:.2f} (issue roof 4.0); VALU wave-instructions per read = {v['SQ_INSTS_VALU']/n_reads:.0f}")
-    if "WRITE_SIZE" in v:
-        out.append(f"    -> WRITE_SIZE x 1 KiB = {v['WRITE_SIZE']*1024/1e9:.3f} GB per launch = {v['WRITE_SIZE']*1024/n_reads:.1f} B per read")
-    if "FETCH_SIZE" in v:
-        out.append(f"    -> FETCH_SIZE x 1 KiB = {v['FETCH_SIZE']*1024/1e9:.3f} GB per launch = {v['FETCH_SIZE']*1024/n_reads:.1f} B per read (x2 for wide streaming reads on gfx950, MI355X_MICROARCH.md)")
+    # derived figures per class of launches (durations from the kernel trace, split the same way)
+    ds = trace.get(k, [])
+    for name, pick in (("large", lambda x, m: x > 0.3 * m), ("small", lambda x, m: x <= 0.3 * m)):
+        v = {}
+        for c, xs in vals[k].items():
+            sel = [x for x in xs if pick(x, max(xs))]
+            if sel:
+                v[c] = sum(sel) / len(sel)
+        tsel = [x for x in ds if pick(x, max(ds))] if ds else []
+        if not v or (name == "small" and not tsel):
+            continue
+        t = sum(tsel) / len(tsel) / 1e3 if tsel else None
+        if t and "SQ_INSTS_VALU" in v and "score_kernel_v2" not in k:
+            clk = v.get("GRBM_GUI_ACTIVE", 0) / 8 / t if v.get("GRBM_GUI_ACTIVE") else 2.4e9
+            out.append(f"    -> {name}: avg {t*1e3:.3f} ms; cycles per wave64 VALU instruction = 1024 SIMDs x t x clk({clk/1e9:.2f} GHz) / SQ_INSTS_VALU = {1024*t*clk/v['SQ_INSTS_VALU']:.2f} (issue roof 4.0); VALU wave-instructions per read of the batch = {v['SQ_INSTS_VALU']/n_reads:.0f}")
+        if "WRITE_SIZE" in v:
+            out.append(f"    -> {name}: WRITE_SIZE x 1 KiB = {v['WRITE_SIZE']*1024/1e9:.3f} GB per launch = {v['WRITE_SIZE']*1024/n_reads:.1f} B per read of the batch")
+        if "FETCH_SIZE" in v:
+            out.append(f"    -> {name}: FETCH_SIZE x 1 KiB = {v['FETCH_SIZE']*1024/1e9:.3f} GB per launch = {v['FETCH_SIZE']*1024/n_reads:.1f} B per read of the batch (raw counter; x2 for wide streaming reads on gfx950, MI355X_MICROARCH.md)")
 open(f"profiles/{tag}.txt", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
