@@ -230,3 +230,27 @@ def test_banded_pass_pairs_lengths_and_edges(za, oracle):
         assert ctx.prune_rescored() < n // 4
     finally:
         ctx.debug_set(0)
+
+
+def test_every_length_class_of_a_large_ragged_batch_takes_the_seeded_pass(za):
+    """6 M reads of 75-400 bases: the length classes share the banded kernel's blocks (and their boundary buffers) in proportion
+    to their reads, so the classes' workspace regions fit what the call allocated. A class that did not fit would quietly take the
+    full pass: then the 2 % random reads of that class would not show up among the handed-back reads."""
+    import torch
+    from zoe_amd import _lib, synth
+
+    ctx = za.SwContext.get(0)
+    ref = synth.reference_host(2000)
+    n = 6_000_000
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    rb = synth.reads_ragged_device(ctx, ref, 0, n, 75, 400)
+    prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
+    got = prof.sw_score_from_i8(ref)
+    back = ctx.prune_rescored()
+    assert 0.023 * n < back < 0.04 * n, back
+    ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
+    try:
+        full = prof.sw_score_from_i8(ref)
+    finally:
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
+    assert torch.equal(got.score, full.score) and torch.equal(got.status, full.status) and torch.equal(got.tier, full.tier)

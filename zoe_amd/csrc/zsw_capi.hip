@@ -151,8 +151,9 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
         if (!ctx->seed.valid) ZSW_HIP(ctx, seed_index_update(&ctx->seed, ctx->h_sc, ctx->h_ref.data(), ctx->ref_len));
         if (ctx->seed.usable) {
             // ragged batches: a region per length class (the banded pass's buffers are sized per region, by the reads in it)
+            // (ragged: the classes' sort temporaries and round-ups, and SEED_BAND_CLASS_MIN_GRID blocks of boundary buffer each)
             const size_t want = seed_workspace_bytes(n, st->max_len) + 24 * seed_workspace_bytes(0, st->max_len) +
-                                (reads->offsets ? 20 * seed_workspace_bytes(std::min<uint32_t>(n, 2048), st->max_len) : 0);
+                                (reads->offsets ? 24 * seed_workspace_bytes(std::min<uint32_t>(n, 2 * SEED_BAND_CLASS_MIN_GRID * 256), st->max_len, SEED_BAND_CLASS_MIN_GRID) : 0);
             if (ctx->d_seed_work.ensure(want) == hipSuccess && ctx->d_seed_gtab.ensure((ctx->ref_len + 2 * SEED_GTAB_PAD) * 8) == hipSuccess &&
                 ctx->d_prune_list.ensure((size_t)n * 4 + 4) == hipSuccess &&
                 ctx->d_prune_count.ensure(64 * 4) == hipSuccess) {

@@ -526,11 +526,12 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     // score_kernel_v2 over the reads it hands back (device-side list; `counter` = its count, zeroed here). The workspace region
     // [work_off, work_off + seed_workspace_bytes(n_items)) and fail_list + list_off belong to this call alone.
     bool gtab_built = false;
-    auto seed_items = [&](const BatchDev& bb, int g, int c, uint32_t longest, size_t work_off, uint32_t list_off, uint32_t* counter) -> hipError_t {
+    auto seed_items = [&](const BatchDev& bb, int g, int c, uint32_t longest, size_t work_off, uint32_t list_off, uint32_t* counter,
+                          uint32_t band_grid_cap) -> hipError_t {
         if (!use_v2 || !ws.seed || !ws.seed_work || !ws.prune_fail_list || !(ws.debug & ZSW_DEBUG_SCORE_PRUNE) || (ws.debug & ZSW_DEBUG_PRUNE_STRIP))
             return hipErrorNotSupported;
         if (bb.n_items < SEED_MIN_READS && !(ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) return hipErrorNotSupported;
-        if (g == 32 || work_off + seed_workspace_bytes(bb.n_items, longest) > ws.seed_bytes) return hipErrorNotSupported;
+        if (g == 32 || work_off + seed_workspace_bytes(bb.n_items, longest, band_grid_cap) > ws.seed_bytes) return hipErrorNotSupported;
         ScoreArgsV2 ap = a2;
         if (!build_tables_v2(h_sc, g, &ap) || !seed_applicable(*ws.seed, longest, ref_len, ap.limit)) return hipErrorNotSupported;
         if (!ws.seed_gtab) return hipErrorNotSupported;
@@ -543,9 +544,9 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         pe = hipMemsetAsync(counter, 0, 4, stream);
         if (pe != hipSuccess) return pe;
         ap.b = bb;
-        pe = launch_score_seeded(ap, g, c, longest, *ws.seed, ws.seed_work + work_off, seed_workspace_bytes(bb.n_items, longest), ws.seed_gtab,
+        pe = launch_score_seeded(ap, g, c, longest, *ws.seed, ws.seed_work + work_off, seed_workspace_bytes(bb.n_items, longest, band_grid_cap), ws.seed_gtab,
                                  ws.prune_fail_list + list_off, counter, mode, !(ws.debug & ZSW_DEBUG_SEED_NO_BAND),
-                                 (ws.debug & ZSW_DEBUG_SEED_WIDE_BAND) ? 0xffffffffu : (ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE) ? 0u : SEED_NARROW_MIN_READS, stream,
+                                 (ws.debug & ZSW_DEBUG_SEED_WIDE_BAND) ? 0xffffffffu : (ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE) ? 0u : SEED_NARROW_MIN_READS, band_grid_cap, stream,
                                  ws.window_timer);
         if (pe != hipSuccess) return pe;
         ap.b.items = ws.prune_fail_list + list_off;
@@ -647,6 +648,8 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         // 15 ms per class against a 30 kb reference — so these launches must overlap.
         {
             size_t work_off = 0;
+            uint32_t n_seedable = 0;  // the banded kernel's blocks are shared among the classes in proportion to their reads
+            for (int k = 0; k < NCLS; ++k) n_seedable += counts[k];
             for (int k = NCLS - 1; k >= 0; --k) {
                 if (!counts[k]) continue;
                 BatchDev bk = b;
@@ -654,11 +657,12 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
                 bk.n_items = counts[k];
                 const Cfg& cf = kCfgs[kBucketCfg[k]];
                 stream = fork ? side->s[used % SideStreams::N] : main_stream;
-                e = seed_items(bk, cf.G, cf.C, caps.cap[k], work_off, starts[k], ws.prune_fail_count + 2 + k);
+                const uint32_t grid_cap = seed_band_class_cap(counts[k], n_seedable);
+                e = seed_items(bk, cf.G, cf.C, caps.cap[k], work_off, starts[k], ws.prune_fail_count + 2 + k, grid_cap);
                 stream = main_stream;
                 if (e == hipSuccess) ++used;
                 if (e == hipSuccess) {
-                    work_off += seed_workspace_bytes(counts[k], caps.cap[k]);
+                    work_off += seed_workspace_bytes(counts[k], caps.cap[k], grid_cap);
                     counts[k] = 0;
                 } else if (e != hipErrorNotSupported) {
                     return e;
@@ -748,7 +752,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         e = hipErrorNotSupported;
         {
             int Gs = 0, Cs = 0;
-            if (score_config_for(max_len, &Gs, &Cs)) e = seed_items(b, Gs, Cs, max_len, 0, 0, ws.prune_fail_count);
+            if (score_config_for(max_len, &Gs, &Cs)) e = seed_items(b, Gs, Cs, max_len, 0, 0, ws.prune_fail_count, SEED_BAND_MAX_GRID);
         }
         const int cls = prune_class_for(max_len);
         if (e == hipErrorNotSupported && cls >= 0) e = prune_items(b, cls, b.n_items);

@@ -232,13 +232,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
 
 uint32_t seed_band_rows(const SeedParams& p, uint32_t max_len) { return (uint32_t)seed_rows_above(p, (int)max_len) + (uint32_t)seed_rows_below(p, (int)max_len) + SEED_BAND_SLACK + 4; }
 
-uint32_t seed_band_grid(uint32_t n) {
+uint32_t seed_band_grid(uint32_t n, uint32_t grid_cap) {
     const uint32_t pairs = (n + 1) / 2;
-    return std::max<uint32_t>(1, std::min<uint32_t>((pairs + BLOCK - 1) / BLOCK, SEED_BAND_MAX_GRID));
+    return std::max<uint32_t>(1, std::min<uint32_t>((pairs + BLOCK - 1) / BLOCK, std::min(grid_cap, SEED_BAND_MAX_GRID)));
 }
 
-size_t seed_band_buffer_bytes(const SeedParams& p, uint32_t n, uint32_t max_len) {
-    return n ? (size_t)seed_band_grid(n) * BLOCK * (size_t)seed_band_rows(p, max_len) * sizeof(uint2) : 0;
+size_t seed_band_buffer_bytes(const SeedParams& p, uint32_t n, uint32_t max_len, uint32_t grid_cap) {
+    return n ? (size_t)seed_band_grid(n, grid_cap) * BLOCK * (size_t)seed_band_rows(p, max_len) * sizeof(uint2) : 0;
 }
 
 bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase_rows) {
@@ -247,7 +247,7 @@ bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase
 }
 
 hipError_t launch_seed_band(const SeedBandArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL((seed_band_kernel<BC, 3>), dim3(seed_band_grid(a.n)), dim3(BLOCK), 0, stream, a);
+    hipLaunchKernelGGL((seed_band_kernel<BC, 3>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -172,14 +172,14 @@ size_t sort_temp_bytes(uint32_t n) {
 uint32_t seed_codes_stride(uint32_t max_len) { return (max_len + 7) / 8 + 1; }
 
 // keys, sorted keys, ids, order, info, masks, band masks (u32 per item), d_fb (u8), packed residue codes, sort temp, band buffer
-size_t seed_workspace_bytes(uint32_t n, uint32_t max_len) {
+size_t seed_workspace_bytes(uint32_t n, uint32_t max_len, uint32_t band_grid_cap) {
     SeedParams p{};
     p.M1 = SEED_M1;
     p.M1_per8 = SEED_M1_PER8;
     p.Wd = SEED_WD;
     p.Wd_per16 = SEED_WD_PER16;
     return 7 * round256((size_t)n * 4 + 8) + round256((size_t)n + 8) + round256((size_t)n * seed_codes_stride(max_len) * 4 + 8) +
-           round256(sort_temp_bytes(n)) + round256(seed_band_buffer_bytes(p, n, max_len)) + 256;
+           round256(sort_temp_bytes(n)) + round256(seed_band_buffer_bytes(p, n, max_len, band_grid_cap)) + 256;
 }
 
 bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, uint32_t limit) {
@@ -189,11 +189,11 @@ bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, ui
 }
 
 hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max_len, const SeedIndex& ix, uint8_t* work, size_t work_bytes,
-                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, bool band, uint32_t narrow_min_reads, hipStream_t stream,
+                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, bool band, uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream,
                                KernelTimer* window_timer) {
     const uint32_t n = a2.b.n_items;
     if (n == 0) return hipSuccess;
-    if (!work || !gtab || work_bytes < seed_workspace_bytes(n, max_len)) return hipErrorNotSupported;
+    if (!work || !gtab || work_bytes < seed_workspace_bytes(n, max_len, band_grid_cap)) return hipErrorNotSupported;
     // score-only calls take the banded kernel (zsw_score_band.hip) when a strip's rows fit one drift period
     band = band && mode == 0 && seed_band_applicable(ix.params, max_len, a2.K);
     const size_t per = round256((size_t)n * 4 + 8);
@@ -267,6 +267,7 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
         b.gtab = gtab;
         b.bnd = band_buf;
         b.nb = seed_band_rows(ix.params, max_len);
+        b.grid = seed_band_grid(n, band_grid_cap);
         b.key_bias = SEED_KEY_BIAS;
         b.fail_key = fail_key;
         b.fail_list = fail_list;

@@ -78,6 +78,7 @@ struct SeedBandArgs {
     const uint2* gtab;
     uint2* bnd;                  // [block][nb][BLOCK]: the strip boundary of each lane (true scores: H of the last column, outgoing F)
     uint32_t nb;
+    uint32_t grid;                     // blocks to launch (each owns nb * BLOCK entries of bnd)
     int wu0, wu_per16, wd0, wd_per32;  // this launch's band: wu0 + len * wu_per16 / 16 diagonals above the anchor, wd0 + len * wd_per32 / 32 below
     const uint32_t* n_dev;             // non-null: the number of items in `order` (a device-side count, at most n)
     uint8_t* retry;                    // non-null (first tier): a read whose bounds fail sets retry[its position in `order`] instead of joining the list
@@ -86,14 +87,22 @@ struct SeedBandArgs {
     uint32_t* fail_count;
 };
 uint32_t seed_band_rows(const SeedParams& p, uint32_t max_len);
-size_t seed_band_buffer_bytes(const SeedParams& p, uint32_t n, uint32_t max_len);
+uint32_t seed_band_grid(uint32_t n, uint32_t grid_cap);
+size_t seed_band_buffer_bytes(const SeedParams& p, uint32_t n, uint32_t max_len, uint32_t grid_cap);
 bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase_rows);
 hipError_t launch_seed_band(const SeedBandArgs& a, hipStream_t stream);
 
 struct ScoreArgsV2;
 
 // bytes of workspace for a range of n items
-size_t seed_workspace_bytes(uint32_t n, uint32_t max_len);
+// band_grid_cap: most blocks the banded kernel may launch for this range (each owns a boundary buffer). A ragged batch shares
+// SEED_BAND_MAX_GRID among its length classes in proportion to their reads (seed_band_class_cap), so that the classes' regions
+// together stay within seed_workspace_bytes(n_reads, max_len) + SEED_BAND_CLASS_SLACK regions of an empty range.
+constexpr uint32_t SEED_BAND_CLASS_MIN_GRID = 64;
+inline uint32_t seed_band_class_cap(uint32_t n_class, uint32_t n_total) {
+    return SEED_BAND_CLASS_MIN_GRID + (uint32_t)((uint64_t)SEED_BAND_MAX_GRID * n_class / (n_total ? n_total : 1));
+}
+size_t seed_workspace_bytes(uint32_t n, uint32_t max_len, uint32_t band_grid_cap = SEED_BAND_MAX_GRID);
 // can reads of up to max_len bases be seeded with this index, given the packed kernels' score limit?
 bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, uint32_t limit);
 // narrow_min_reads: score-only calls of at least this many short reads walk a narrow band first (SEED_NARROW_*).
@@ -102,7 +111,7 @@ bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, ui
 // gtab: (ref_len + 2 * SEED_GTAB_PAD) uint2, filled by seed_build_gtab (once per call of launch_score, from a2's tables).
 hipError_t seed_build_gtab(const ScoreArgsV2& a2, uint2* gtab, hipStream_t stream);
 hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max_len, const SeedIndex& ix, uint8_t* work, size_t work_bytes,
-                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, bool band, uint32_t narrow_min_reads, hipStream_t stream,
+                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, bool band, uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream,
                                KernelTimer* window_timer);
 // (Re)builds the index for a reference given as residue indices on the host.
 hipError_t seed_index_update(SeedIndex* ix, const ScoringDev& sc, const uint8_t* h_ref, size_t ref_len);
