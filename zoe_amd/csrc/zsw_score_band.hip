@@ -25,7 +25,7 @@ __device__ __forceinline__ uint32_t pk_subu_sat(uint32_t a, uint32_t b) {
 
 constexpr int BC = 32;  // columns per strip (a multiple of 8: a strip's residue codes are whole dwords of the packed reads)
 
-template <int C, int MINW>
+template <int C, int MINW, int MODE>
 __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) {
     __shared__ uint16_t sel_lut[16];
     __shared__ uint16_t sq[BLOCK * 4 * (SEED_MAX_KMERS + 1)];  // per lane: seed_suffix_q of (read A, B) x (fa, fb), private slices
@@ -95,6 +95,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
         const uint32_t* codeA = a.codes + (size_t)ridA * a.cs;
         const uint32_t* codeB = a.codes + (size_t)ridB * a.cs;
         uint32_t best = 0;          // true scores
+        // ends (MODE 1, 2): first row holding the maximum, then the first column of that row (striped.rs:296-321). A strip walks its
+        // rows in order; strips overlap in rows, so each strip keeps its own (maximum, first row, H row of that row) and the strips
+        // merge by (higher maximum, then earlier row; the same row in two strips: the earlier strip holds the earlier column).
+        int bestA = 0, bestB = 0, rowA = 0x7fffffff, rowB = 0x7fffffff, colA = 0x7fffffff, colB = 0x7fffffff;
         int bndA = -1, bndB = -1;   // the exit bounds so far
         int prev_bot = 0;
 #pragma unroll 1
@@ -130,6 +134,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
             // exits through the right edge in the rows above the next strip: largest H / outgoing F of the last column, plain and
             // less gap_extend per diagonal beyond the first outside the band's edge (seed_band_upper)
             uint32_t uk = 0, ug = 0;
+            uint32_t sbest = 0, snapD = 0;  // this strip's maximum (true scores) and, MODE 2, the H row and drift of each read's latest rise
+            int srA = 0x7fffffff, srB = 0x7fffffff;
+            uint32_t snap[MODE == 2 ? C : 1];
+            if (MODE == 2) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) snap[MODE == 2 ? c : 0] = 0;
+            }
             const int e_top = (dtmin + (k + 1) * C - wu) - 1 - top;  // the first row's distance from the last row above the next strip
             uint32_t dec = min(ge1 * (uint32_t)max(e_top - 1, 0), 0xffffu) * 0x00010001u;
 #pragma unroll 1
@@ -168,7 +179,21 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                     }
                 }
                 dec = pk_subu_sat(dec, ge2);
-                best = pk_maxu(best, pk_subu(rmax, Dr));
+                const uint32_t tmax = pk_subu(rmax, Dr);
+                if (MODE != 0) {
+                    const uint32_t nsb = pk_maxu(sbest, tmax);
+                    const uint32_t ch = nsb ^ sbest;
+                    if (ch & 0xffffu) srA = r;
+                    if (ch >> 16) srB = r;
+                    if (MODE == 2) {
+                        const uint32_t m = ((ch & 0xffffu) ? 0xffffu : 0u) | ((ch >> 16) ? 0xffff0000u : 0u);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) snap[MODE == 2 ? c : 0] = (H[c] & m) | (snap[MODE == 2 ? c : 0] & ~m);
+                        snapD = (Dr & m) | (snapD & ~m);
+                    }
+                    sbest = nsb;
+                }
+                best = pk_maxu(best, tmax);
                 w = wn;
                 bl = bln;
             }
@@ -196,6 +221,31 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                 if (k * C < (int)lenB)
                     bndB = max(bndB, seed_band_lower(a.sp, (int)(mk >> 16), (int)(mg >> 16), xl, (int)lenB, wd, tallB, mB, c0B, strB, q + 3 * (SEED_MAX_KMERS + 1)));
             }
+            if (MODE != 0) {  // merge the strip's maximum into the read's
+                const int sA = (int)(sbest & 0xffffu), sB = (int)(sbest >> 16);
+                const bool upA = sA > bestA || (sA == bestA && sA > 0 && srA < rowA);
+                const bool upB = sB > bestB || (sB == bestB && sB > 0 && srB < rowB);
+                if (upA) {
+                    bestA = sA;
+                    rowA = srA;
+                }
+                if (upB) {
+                    bestB = sB;
+                    rowB = srB;
+                }
+                if (MODE == 2 && (upA || upB)) {
+                    int cA = 0x7fffffff, cB = 0x7fffffff;
+                    const int sdA = (int)(snapD & 0xffffu), sdB = (int)(snapD >> 16);
+#pragma unroll
+                    for (int c = C - 1; c >= 0; --c) {
+                        const uint32_t sv = snap[MODE == 2 ? c : 0];
+                        if ((int)(sv & 0xffffu) - sdA == sA) cA = k * C + c;
+                        if ((int)(sv >> 16) - sdB == sB) cB = k * C + c;
+                    }
+                    if (upA) colA = cA;
+                    if (upB) colB = cB;
+                }
+            }
             prev_bot = bot;
         }
         // fresh starts outside the band
@@ -213,7 +263,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
             if (h == 1 && !validB) break;
             const uint32_t id = h ? idB : idA;
             const int S = h ? SB : SA, bound = h ? bndB : bndA;
-            if ((h ? lenB : lenA) == 0 || bound > S) {
+            // score only: a path outside the band matters if it can score MORE than S; with ends also if it can score S (it could
+            // end in an earlier row or column)
+            const bool redo = MODE == 0 ? bound > S : bound >= S;
+            if ((h ? lenB : lenA) == 0 || redo) {
                 if (a.retry) a.retry[h ? itemB : itemA] = 1;
                 else a.fail_list[atomicAdd(a.fail_count, 1u)] = id;
             } else {
@@ -223,6 +276,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                 a.out.score[id] = score;
                 a.out.status[id] = status;
                 if (a.out.tier) a.out.tier[id] = tier;
+                const bool some = status == ZSW_STATUS_SOME;
+                if (MODE != 0 && a.out.ref_end) a.out.ref_end[id] = some ? (uint32_t)(h ? rowB : rowA) + 1 : 0;
+                if (MODE == 2 && a.out.query_end) a.out.query_end[id] = some ? (uint32_t)(h ? colB : colA) + 1 : 0;
+                if (MODE != 0 && a.out.safe_row)  // sw_simd_align's second pass may start this late (or 0xffffffff: no certificate)
+                    a.out.safe_row[id] = (uint32_t)seed_safe_start(a.sp, h ? tallB : tallA, h ? dfaB : dfaA, h ? dtB : dtA, S);
             }
         }
     }
@@ -246,8 +304,11 @@ bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase
     return (uint32_t)BC + seed_band_rows(p, max_len) + 2 <= rebase_rows;
 }
 
-hipError_t launch_seed_band(const SeedBandArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL((seed_band_kernel<BC, 3>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+hipError_t launch_seed_band(const SeedBandArgs& a, int mode, hipStream_t stream) {
+    // MODE 2 keeps a snapshot of the H row (32 more registers): two waves per SIMD
+    if (mode == 0) hipLaunchKernelGGL((seed_band_kernel<BC, 3, 0>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+    else if (mode == 1) hipLaunchKernelGGL((seed_band_kernel<BC, 3, 1>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((seed_band_kernel<BC, 2, 2>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
     return hipGetLastError();
 }
 

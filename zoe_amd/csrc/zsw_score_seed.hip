@@ -194,8 +194,8 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
     const uint32_t n = a2.b.n_items;
     if (n == 0) return hipSuccess;
     if (!work || !gtab || work_bytes < seed_workspace_bytes(n, max_len, band_grid_cap)) return hipErrorNotSupported;
-    // score-only calls take the banded kernel (zsw_score_band.hip) when a strip's rows fit one drift period
-    band = band && mode == 0 && seed_band_applicable(ix.params, max_len, a2.K);
+    // the banded kernel (zsw_score_band.hip) when a strip's rows fit one drift period
+    band = band && seed_band_applicable(ix.params, max_len, a2.K);
     const size_t per = round256((size_t)n * 4 + 8);
     uint32_t* keys = reinterpret_cast<uint32_t*>(work);
     uint32_t* keys_out = reinterpret_cast<uint32_t*>(work + per);
@@ -293,14 +293,14 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
             b1.wd0 = SEED_NARROW_WD;
             b1.wd_per32 = SEED_NARROW_WD_PER32;
             b1.retry = retry;
-            e = launch_seed_band(b1, stream);
+            e = launch_seed_band(b1, mode, stream);
             if (e != hipSuccess) return e;
             e = hipcub::DeviceSelect::Flagged(temp, temp_bytes, (const uint32_t*)order, (const uint8_t*)retry, order2, n2, (int)n, stream);
             if (e != hipSuccess) return e;
             b.order = order2;
             b.n_dev = n2;
         }
-        e = launch_seed_band(b, stream);
+        e = launch_seed_band(b, mode, stream);
         if (window_timer) window_timer->end(stream);
         return e;
     }

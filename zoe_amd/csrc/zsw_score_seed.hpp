@@ -90,7 +90,7 @@ uint32_t seed_band_rows(const SeedParams& p, uint32_t max_len);
 uint32_t seed_band_grid(uint32_t n, uint32_t grid_cap);
 size_t seed_band_buffer_bytes(const SeedParams& p, uint32_t n, uint32_t max_len, uint32_t grid_cap);
 bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase_rows);
-hipError_t launch_seed_band(const SeedBandArgs& a, hipStream_t stream);
+hipError_t launch_seed_band(const SeedBandArgs& a, int mode, hipStream_t stream);
 
 struct ScoreArgsV2;
 
