@@ -169,11 +169,11 @@ WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4  # wave64 VALU instructions/s: 1,024 SIMDs
 # (constants from those profiles, not measured in the bench run): tools/pmc_entry.py, one entry point per run, every kernel of
 # the call summed (profiles/r03_secondary_valu.txt; per-phase budget of the packed alignment kernel: profiles/r02_align_pk_pmc.txt)
 SECONDARY_VALU_PROFILE = "profiles/r03_secondary_valu.txt"
-ALIGN_PK_VALU_PER_READ = 15_462   # align_kernel_pk<16,10> 14,789 + <32,5> 673 (pass 2 alone: what pass2_kernel_ms times)
+ALIGN_PK_VALU_PER_READ = 15_464   # align_kernel_pk<16,10> 14,789 + <32,5> 675 (pass 2 alone: what pass2_kernel_ms times)
 ALIGN_PK_PROFILE = SECONDARY_VALU_PROFILE
-RANGES_VALU_PER_READ = 5_808      # window kernel 2,372 + reverse pass 2,830 + handed-back reads 525 + seed kernel 66
-THREEPASS_VALU_PER_READ = 6_024   # the same + threepass_kernel 212
-MIXED_VALU_PER_READ = 16_114      # 75-400 bp vs 30 kb: 13,800 of them are the full pass over the 3 % of reads handed back
+RANGES_VALU_PER_READ = 4_393      # banded kernel (MODE 2, two launches) 939 + reverse pass 2,830 + handed-back reads 528 + seed kernel 81
+THREEPASS_VALU_PER_READ = 4_609   # the same + threepass_kernel 213
+MIXED_VALU_PER_READ = 16_107      # 75-400 bp vs 30 kb: 13,800 of them are the full pass over the 3 % of reads handed back
 
 
 def rooflines(algo_bytes: float, kernel_s: float, valu_instr: float = None, source: str = None):
@@ -274,7 +274,7 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     entry = {"reads_per_s_end_to_end_incl_d2h": n_full / dt, "pass2_kernel_ms": ks * 1e3, "pass2_kernel_ms_per_1M_reads": ks * 1e3 / (n_full / 1e6),
              "ciglets": n_cig, "aligned_reads": n_some,
              "call": "into_local_profile(..).sw_align_from_i8(SeqSrc::Reference(ref)) (CIGAR of the i16x16 / i8x32 tier), 10 M reads (BASELINE.json configs[2] at full size)",
-             "kernel": "zsw::align_kernel_pk<16,10> (+ <32,5> for the reads that answer at i8x32); pass 1 = the seeded exact pass (seed_window_kernel<4,38,1>: 2,092 more VALU instructions per read)"}
+             "kernel": "zsw::align_kernel_pk<16,10> (+ <32,5> for the reads that answer at i8x32); pass 1 = the seeded exact pass (seed_band_kernel<32,3,1>: 823 more VALU instructions per read)"}
     # algorithmic bytes: read in, record out (score, 4 coordinates, 2 lengths, count, offset = 40 B), 5 B per ciglet
     entry.update(rooflines(n_full * (READ_LEN + 4.0) + n_some * 40.0 + n_cig * 5.0, ks, ALIGN_PK_VALU_PER_READ * n_full, ALIGN_PK_PROFILE))
     ap, dtp, ksp = with_full_first_pass(lambda: prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref2k)))
