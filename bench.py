@@ -173,14 +173,23 @@ ALIGN_PK_VALU_PER_READ = 15_464   # align_kernel_pk<16,10> 14,789 + <32,5> 675 (
 ALIGN_PK_PROFILE = SECONDARY_VALU_PROFILE
 RANGES_VALU_PER_READ = 4_393      # banded kernel (MODE 2, two launches) 939 + reverse pass 2,830 + handed-back reads 528 + seed kernel 81
 THREEPASS_VALU_PER_READ = 4_609   # the same + threepass_kernel 213
-MIXED_VALU_PER_READ = 16_107      # 75-400 bp vs 30 kb: 13,800 of them are the full pass over the 3 % of reads handed back
+# FETCH_SIZE + WRITE_SIZE per read of the same calls (separate --pmc passes, raw counters), same file
+RANGES_HBM_PER_READ = 1_046 + 1_546
+THREEPASS_HBM_PER_READ = 13_591 + 18_706   # the third pass's DP rows and traceback cells in global memory
+MIXED_HBM_PER_READ = 2_700 + 3_745
+ALIGN_HBM_PER_READ = 11_512 + 33_470       # the flag ring of pass 2 (30 kB per read) and its read-back by the traceback
+MIXED_VALU_PER_READ = 16_114      # 75-400 bp vs 30 kb: 13,800 of them are the full pass over the 3 % of reads handed back
 
 
-def rooflines(algo_bytes: float, kernel_s: float, valu_instr: float = None, source: str = None):
-    """The two roofs of a secondary entry: algorithmic bytes over the kernels' time against HBM, and (where a committed PMC
-    pass gives the instruction count) issued VALU wave-instructions against the 4-cycle issue rate."""
+def rooflines(algo_bytes: float, kernel_s: float, valu_instr: float = None, source: str = None, traffic_bytes: float = None):
+    """The two roofs of a secondary entry: algorithmic bytes over the kernels' time against HBM (`traffic`: the FETCH_SIZE +
+    WRITE_SIZE counters of a committed PMC pass of the same call, over the same time), and (where a committed PMC pass gives
+    the instruction count) issued VALU wave-instructions against the 4-cycle issue rate."""
     out = {"roofline": {"bound": "hbm", "achieved": algo_bytes / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": algo_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": algo_bytes / kernel_s / 1e9 / HBM_PEAK_GBS,
+                        "traffic": traffic_bytes / kernel_s / 1e9 if traffic_bytes else None,
+                        "traffic_bytes_per_launch": traffic_bytes, "traffic_measured_in_this_run": False if traffic_bytes else None,
+                        "traffic_source": file_tag(source) if (traffic_bytes and source) else None,
                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_s * 1e3}}
     if valu_instr:
         out["valu_roofline"] = {"bound": "valu", "achieved": valu_instr / kernel_s / 1e9, "peak": WAVE_INSTR_PEAK / 1e9,
@@ -276,7 +285,8 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
              "call": "into_local_profile(..).sw_align_from_i8(SeqSrc::Reference(ref)) (CIGAR of the i16x16 / i8x32 tier), 10 M reads (BASELINE.json configs[2] at full size)",
              "kernel": "zsw::align_kernel_pk<16,10> (+ <32,5> for the reads that answer at i8x32); pass 1 = the seeded exact pass (seed_band_kernel<32,3,1>: 823 more VALU instructions per read)"}
     # algorithmic bytes: read in, record out (score, 4 coordinates, 2 lengths, count, offset = 40 B), 5 B per ciglet
-    entry.update(rooflines(n_full * (READ_LEN + 4.0) + n_some * 40.0 + n_cig * 5.0, ks, ALIGN_PK_VALU_PER_READ * n_full, ALIGN_PK_PROFILE))
+    entry.update(rooflines(n_full * (READ_LEN + 4.0) + n_some * 40.0 + n_cig * 5.0, ks, ALIGN_PK_VALU_PER_READ * n_full, ALIGN_PK_PROFILE,
+                           ALIGN_HBM_PER_READ * n_full))
     ap, dtp, ksp = with_full_first_pass(lambda: prof.sw_align_from_i8(zoe_amd.SeqSrc.Reference(ref2k)))
     entry["with_full_first_pass"] = {"reads_per_s_end_to_end_incl_d2h": n_full / dtp, "pass2_kernel_ms": ksp * 1e3,
                                        "identical": bool(np.array_equal(ap.status, a.status) and np.array_equal(ap.records, a.records)
@@ -292,7 +302,7 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     entry = {"reads_per_s_end_to_end_incl_d2h": 1_000_000 / dt, "kernels_ms": ks * 1e3, "ciglets": int(len(a3.inc)),
              "call": "into_local_profile(..).sw_align_from_i8_3pass(SeqSrc::Reference(ref)) (three_pass.rs: ranges, then no-gaps / banded / scalar in the box)"}
     entry.update(rooflines(1e6 * (READ_LEN + 4.0) + float((a3.status == 0).sum()) * 40.0 + len(a3.inc) * 5.0, ks, THREEPASS_VALU_PER_READ * 1e6,
-                           SECONDARY_VALU_PROFILE))
+                           SECONDARY_VALU_PROFILE, THREEPASS_HBM_PER_READ * 1e6))
     ap, dtp, ksp = with_full_first_pass(lambda: prof.sw_align_from_i8_3pass(zoe_amd.SeqSrc.Reference(ref2k)))
     entry["with_full_first_pass"] = {"reads_per_s_end_to_end_incl_d2h": 1_000_000 / dtp, "kernels_ms": ksp * 1e3,
                                        "identical": bool(np.array_equal(ap.status, a3.status) and np.array_equal(ap.records, a3.records)
@@ -303,7 +313,7 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     sp = zoe_amd.StripedProfileBatch(rb, matrix, -10, -1, T="i16", N=16, device=ctx.device)
     rg, dt, ks = timed(lambda: sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k)))
     entry = {"reads_per_s": 1_000_000 / dt, "kernels_ms": ks * 1e3, "call": "StripedProfile::<i16,16,5>::sw_score_ranges(SeqSrc::Reference(ref))"}
-    entry.update(rooflines(1e6 * (READ_LEN + 4.0 + 16.0), max(ks, 1e-9) if ks > 0 else dt, RANGES_VALU_PER_READ * 1e6, SECONDARY_VALU_PROFILE))
+    entry.update(rooflines(1e6 * (READ_LEN + 4.0 + 16.0), max(ks, 1e-9) if ks > 0 else dt, RANGES_VALU_PER_READ * 1e6, SECONDARY_VALU_PROFILE, RANGES_HBM_PER_READ * 1e6))
     rp_, dtp, ksp = with_full_first_pass(lambda: sp.sw_score_ranges(zoe_amd.SeqSrc.Reference(ref2k)))
     entry["with_full_first_pass"] = {"reads_per_s": 1_000_000 / dtp, "kernels_ms": ksp * 1e3,
                                        "identical": all(bool(torch.equal(getattr(rp_, f), getattr(rg, f)))
@@ -329,7 +339,7 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     cells = total_bases * 30000
     entry = {"reads_per_s": 1_000_000 / dt, "kernel_ms": ks * 1e3,
              "call": "sw_score_from_i8, reads bucketed by strip configuration on the device, seeded exact pass per length class"}
-    entry.update(rooflines(total_bases + 1e6 * (8.0 + 4.0), dt, MIXED_VALU_PER_READ * 1e6, SECONDARY_VALU_PROFILE))
+    entry.update(rooflines(total_bases + 1e6 * (8.0 + 4.0), dt, MIXED_VALU_PER_READ * 1e6, SECONDARY_VALU_PROFILE, MIXED_HBM_PER_READ * 1e6))
     entry["gcups"] = "equivalent: the cells of the full matrices per second (the seeded pass computes about one in ninety of them)"
     entry["gcups_equivalent"] = cells / dt / 1e9
     del entry["gcups"]
