@@ -166,10 +166,15 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                 a.fb_list[k] = id;
                 continue;
             }
-            uint8_t* slot = a.scratch + (uint64_t)tid * a.slot_bytes;
-            int32_t* h_row = reinterpret_cast<int32_t*>(slot);
-            int32_t* e_row = h_row + qlen;
-            uint8_t* bt = slot + ((8ull * qlen + 15) & ~15ull);
+            // The 64 slots of a block are interleaved word by word (word i of lane l at word i * 64 + l of the block's region): the
+            // lanes walk their rows and flag bytes in step, so a wavefront's accesses to "its i-th word" fall into four cache lines
+            // instead of sixty-four.
+            uint32_t* const region = reinterpret_cast<uint32_t*>(a.scratch + (uint64_t)blockIdx.x * 64 * a.slot_bytes) + threadIdx.x;
+            const uint32_t e_off = qlen;                                          // words: H row, then E row, then the flag bytes
+            const uint64_t bt_off = (((8ull * qlen + 15) & ~15ull) >> 2);
+            auto h_row = [&](uint32_t c) -> int32_t& { return reinterpret_cast<int32_t*>(region)[(uint64_t)c * 64]; };
+            auto e_row = [&](uint32_t c) -> int32_t& { return reinterpret_cast<int32_t*>(region)[(uint64_t)(e_off + c) * 64]; };
+            auto bt = [&](uint64_t k) -> uint8_t& { return reinterpret_cast<uint8_t*>(region + (bt_off + (k >> 2)) * 64)[k & 3]; };
             const uint8_t* refb = a.ref + rs;
             const uint8_t* qb = query + qs;
             int r_fin = 0, c_fin = 0, r_end = 0, c_end = 0;
@@ -184,21 +189,21 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                     break;
                 }
                 for (uint32_t c = 0; c < qlen; ++c) {
-                    h_row[c] = 0;
-                    e_row[c] = go;
+                    h_row(c) = 0;
+                    e_row(c) = go;
                 }
-                for (uint64_t k = 0; k < (uint64_t)rlen * full; ++k) bt[k] = 0;
+                for (uint64_t k = 0; k < ((uint64_t)rlen * full + 3) / 4; ++k) region[(bt_off + k) * 64] = 0;  // the flag bytes, a word at a time
                 int32_t best = 0, h_store = 0;
                 for (uint32_t r = 0; r < rlen; ++r) {
                     int32_t f = go, h = h_store;
                     const uint32_t start_col = r > band ? r - band : 0;
                     const uint32_t end_col = min(r + band + 1, qlen);
                     if (start_col >= end_col) break;
-                    if (start_col + band == r) h_store = max(max(h + wt(refb[r], qb[start_col]), e_row[start_col]), 0);
+                    if (start_col + band == r) h_store = max(max(h + wt(refb[r], qb[start_col]), e_row(start_col)), 0);
                     for (uint32_t c = start_col; c < end_col; ++c) {
                         uint8_t cell = 0;
                         h += wt(refb[r], qb[c]);
-                        int32_t e = e_row[c];
+                        int32_t e = e_row(c);
                         h = max(max(max(h, e), f), 0);
                         if (h > best) {
                             best = h;
@@ -208,8 +213,8 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                         if (e == h) cell |= BT_UP;
                         if (f == h) cell |= BT_LEFT;
                         if (h == 0) cell = BT_STOP;
-                        const int32_t next_diag = h_row[c];
-                        h_row[c] = h;
+                        const int32_t next_diag = h_row(c);
+                        h_row(c) = h;
                         h += go;
                         e = max(e + ge, h);
                         f = max(f + ge, h);
@@ -218,8 +223,8 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                             if (f > h) cell |= BT_LEFT_EXT;
                         }
                         h = next_diag;
-                        e_row[c] = e;
-                        bt[(uint64_t)r * full + (c - start_col)] = cell;
+                        e_row(c) = e;
+                        bt((uint64_t)r * full + (c - start_col)) = cell;
                     }
                 }
                 if (best > 0 && (uint32_t)best == score) {
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                             *ok = false;
                             return BT_STOP;
                         }
-                        return bt[cur];
+                        return bt(cur);
                     };
                     CigWriter trial = w;
                     if (tp_traceback(cell, r_end, c_end, qlen, qs, query_len, trial, &r_fin, &c_fin)) {
@@ -254,8 +259,8 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
             if (!have) {
                 // sw_scalar_align on the box (scalar.rs:173-271)
                 for (uint32_t c = 0; c < qlen; ++c) {
-                    h_row[c] = 0;
-                    e_row[c] = go;
+                    h_row(c) = 0;
+                    e_row(c) = go;
                 }
                 int32_t best = 0;
                 for (uint32_t r = 0; r < rlen; ++r) {
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                     for (uint32_t c = 0; c < qlen; ++c) {
                         uint8_t cell = 0;
                         h += wt(refb[r], qb[c]);
-                        int32_t e = e_row[c];
+                        int32_t e = e_row(c);
                         h = max(max(max(h, e), f), 0);
                         if (h > best) {
                             best = h;
@@ -273,8 +278,8 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                         if (e == h) cell |= BT_UP;
                         if (f == h) cell |= BT_LEFT;
                         if (h == 0) cell = BT_STOP;
-                        const int32_t next_diag = h_row[c];
-                        h_row[c] = h;
+                        const int32_t next_diag = h_row(c);
+                        h_row(c) = h;
                         h += go;
                         e = max(e + ge, h);
                         f = max(f + ge, h);
@@ -283,11 +288,11 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                             if (f > h) cell |= BT_LEFT_EXT;
                         }
                         h = next_diag;
-                        e_row[c] = e;
-                        bt[(uint64_t)r * qlen + c] = cell;
+                        e_row(c) = e;
+                        bt((uint64_t)r * qlen + c) = cell;
                     }
                 }
-                auto cell = [&](int rr, int cc, bool* ok) -> uint32_t { return bt[(uint64_t)rr * qlen + (uint32_t)cc]; };
+                auto cell = [&](int rr, int cc, bool* ok) -> uint32_t { return bt((uint64_t)rr * qlen + (uint32_t)cc); };
                 tp_traceback(cell, r_end, c_end, qlen, qs, query_len, w, &r_fin, &c_fin);
             }
             out.ref_start = (uint32_t)r_fin + rs;
