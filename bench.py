@@ -172,10 +172,10 @@ SECONDARY_VALU_PROFILE = "profiles/r03_secondary_valu.txt"
 ALIGN_PK_VALU_PER_READ = 15_464   # align_kernel_pk<16,10> 14,789 + <32,5> 675 (pass 2 alone: what pass2_kernel_ms times)
 ALIGN_PK_PROFILE = SECONDARY_VALU_PROFILE
 RANGES_VALU_PER_READ = 4_393      # banded kernel (MODE 2, two launches) 939 + reverse pass 2,830 + handed-back reads 528 + seed kernel 81
-THREEPASS_VALU_PER_READ = 4_609   # the same + threepass_kernel 213
+THREEPASS_VALU_PER_READ = 4_648   # the same + threepass_kernel 252
 # FETCH_SIZE + WRITE_SIZE per read of the same calls (separate --pmc passes, raw counters), same file
 RANGES_HBM_PER_READ = 1_046 + 1_546
-THREEPASS_HBM_PER_READ = 13_591 + 18_706   # the third pass's DP rows and traceback cells in global memory
+THREEPASS_HBM_PER_READ = 2_244 + 4_722     # the third pass's DP rows and traceback cells in global memory (13.6 + 18.7 kB before the slots were interleaved)
 MIXED_HBM_PER_READ = 2_700 + 3_745
 ALIGN_HBM_PER_READ = 11_512 + 33_470       # the flag ring of pass 2 (30 kB per read) and its read-back by the traceback
 MIXED_VALU_PER_READ = 16_114      # 75-400 bp vs 30 kb: 13,800 of them are the full pass over the 3 % of reads handed back
