@@ -1,13 +1,16 @@
-// zsw_score_band.hip — the banded form of the seeded exact pass for score-only calls (MODE 0). seed_window_kernel computes
-// every query column for all ~len + 60 rows around the anchor; the alignment itself occupies a band of a few diagonals. Here a
-// lane owns one read pair (16-bit halves, as everywhere) and walks it strip by strip: strip k = query columns [kC, (k+1)C) in
-// registers (score_kernel_v2's packed column loop) against the reference rows [dt + kC - Wu, dt + (k+1)C + Wd) only, the strip's
-// last column (H, outgoing F, true scores) handed to the next strip through a per-lane buffer in global memory (8 bytes per row,
-// written and re-read once: L2). No lane talks to another. What lies outside the band is covered by the bounds of zsw_seed.hpp
-// ("banded pass": fresh starts above / below the band, exits through a strip's right edge above the next strip's first row,
-// exits through a strip's last row); host model against a two-layer Gotoh DP: tests/models/seed_band.cpp. A read whose bounds
-// fail joins the same worklist as in the window kernel and is scored over all its cells.
-// 150 bp: 5 strips x ~96 rows x 32 columns per pair in one lane instead of 4 lanes x 211 steps x 38 columns.
+// zsw_score_band.hip — the banded form of the seeded exact pass (sw_simd_score / sw_simd_score_ends, striped.rs:65-142, 153-336:
+// MODE 0 score only, 1 with the reference end, 2 with both ends). seed_window_kernel computes every query column for all
+// ~len + 60 rows around the anchor; the alignment itself occupies a band of a few diagonals. Here a lane owns one read pair
+// (16-bit halves, as everywhere) and walks it strip by strip: strip k = query columns [kC, (k+1)C) in registers (score_kernel_v2's
+// packed column loop) against the reference rows [dt + kC - Wu, dt + (k+1)C + Wd) only, the strip's last column (H, outgoing F,
+// true scores) handed to the next strip through a per-lane buffer in global memory (8 bytes per row, written and re-read once).
+// No lane talks to another. What lies outside the band is covered by the bounds of zsw_seed.hpp ("banded pass": fresh starts
+// above / below the band, exits through a strip's right edge above the next strip's first row, exits through a strip's last
+// row); host model against a layered Gotoh DP, one layer per class of paths: tests/models/seed_band.cpp. The launch's band
+// (SeedBandArgs::wu0 ...) is either the full one or, for short reads, a narrow first tier whose failures are flagged in place
+// (`retry`), selected in anchor order and walked again in the full band (launch_score_seeded, zsw_score_seed.hip); a read whose
+// bounds fail in the last tier joins the same worklist as in the window kernel and is scored over all its cells.
+// 150 bp: 5 strips x 63 (narrow) or 92 (full) rows x 32 columns per pair in one lane instead of 4 lanes x 211 steps x 38 columns.
 #include <algorithm>
 
 #include "zsw_score_seed.hpp"
