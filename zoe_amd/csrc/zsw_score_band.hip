@@ -47,11 +47,24 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
     uint16_t* q = sq + (size_t)tid * 4 * (SEED_MAX_KMERS + 1);
     uint2* bnd = a.bnd + (size_t)blockIdx.x * (size_t)a.nb * BLOCK + tid;  // row j of this lane: bnd[j * BLOCK]
 
-    for (uint32_t pair = blockIdx.x * BLOCK + tid; pair < n_pairs; pair += gridDim.x * BLOCK) {
+    // Work queue: a wavefront takes the next 64 pairs of the anchor order (one atomic per wavefront), so that no lane waits for
+    // a neighbour with one pair more. Every wavefront leaves at the first chunk past the last pair, or at the first chunk that
+    // holds nothing but reads without an anchor (sorted: they are the tail of the order, and the seed kernel listed them).
+    for (;;) {
+        uint32_t base = 0;
+        if ((tid & 63) == 0) base = atomicAdd(a.next_pair, 64u);
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if (base >= n_pairs) break;
+        const uint32_t pair = base + (uint32_t)(tid & 63);
         const uint32_t itemA = 2 * pair, itemB = itemA + 1;
-        const uint32_t ridA = a.order[itemA];
-        const uint32_t keyA = a.keys[ridA];
-        if (keyA == a.fail_key) break;  // sorted: every later pair of this lane is without an anchor too (the seed kernel listed them)
+        uint32_t ridA = 0, keyA = a.fail_key;
+        if (pair < n_pairs) {
+            ridA = a.order[itemA];
+            keyA = a.keys[ridA];
+        }
+        const bool active = keyA != a.fail_key;
+        if (__ballot(active) == 0) break;
+        if (active) {
         uint32_t ridB = itemB < n_items ? a.order[itemB] : ridA;
         uint32_t keyB = itemB < n_items ? a.keys[ridB] : a.fail_key;
         bool validB = keyB != a.fail_key;
@@ -286,6 +299,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                     a.out.safe_row[id] = (uint32_t)seed_safe_start(a.sp, h ? tallB : tallA, h ? dfaB : dfaA, h ? dtB : dtA, S);
             }
         }
+        }  // active
     }
 }
 

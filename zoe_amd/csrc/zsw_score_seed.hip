@@ -278,6 +278,14 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
         b.wd_per32 = 2 * ix.params.Wd_per16;
         b.n_dev = nullptr;
         b.retry = nullptr;
+        // work-queue counters of the (up to) two launches: the spare words behind `order` and `keys`
+        uint32_t* queue1 = reinterpret_cast<uint32_t*>(work + 3 * per + (size_t)n * 4) + 1;
+        uint32_t* queue2 = reinterpret_cast<uint32_t*>(work + (size_t)n * 4);
+        e = hipMemsetAsync(queue1, 0, 4, stream);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(queue2, 0, 4, stream);
+        if (e != hipSuccess) return e;
+        b.next_pair = queue2;
         if (window_timer) window_timer->begin(stream);
         if (max_len <= SEED_NARROW_MAX_LEN && n >= narrow_min_reads) {
             // two tiers: every read in a narrow band; the reads whose bounds fail there, still in anchor order, in the full band.
@@ -293,6 +301,7 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
             b1.wd0 = SEED_NARROW_WD;
             b1.wd_per32 = SEED_NARROW_WD_PER32;
             b1.retry = retry;
+            b1.next_pair = queue1;
             e = launch_seed_band(b1, mode, stream);
             if (e != hipSuccess) return e;
             e = hipcub::DeviceSelect::Flagged(temp, temp_bytes, (const uint32_t*)order, (const uint8_t*)retry, order2, n2, (int)n, stream);

@@ -81,6 +81,7 @@ struct SeedBandArgs {
     uint32_t grid;                     // blocks to launch (each owns nb * BLOCK entries of bnd)
     int wu0, wu_per16, wd0, wd_per32;  // this launch's band: wu0 + len * wu_per16 / 16 diagonals above the anchor, wd0 + len * wd_per32 / 32 below
     const uint32_t* n_dev;             // non-null: the number of items in `order` (a device-side count, at most n)
+    uint32_t* next_pair;               // work queue: the next pair to hand out (zeroed before the launch)
     uint8_t* retry;                    // non-null (first tier): a read whose bounds fail sets retry[its position in `order`] instead of joining the list
     uint32_t key_bias, fail_key;
     uint32_t* fail_list;
