@@ -44,7 +44,7 @@ ALGO_BYTES_PER_READ = READ_LEN + 4  # read bytes in + u32 score out (SURVEY.md Â
 # run (the bench line says so). Nearly all of the traffic is the strip boundary (H and outgoing F of a strip's last column,
 # 8 bytes per row and read pair, written once and read once by the same lane: ~70 MB in flight, beyond the 32 MB of L2).
 PMC_PROFILE = "profiles/r03_band_summary.txt"
-WINDOW_HBM_BYTES_PER_READ = 1932.5  # FETCH_SIZE 934.2 + 131.1, WRITE_SIZE 734.0 + 133.2 B per read of the batch (narrow + full band launch)
+WINDOW_HBM_BYTES_PER_READ = 1946.7  # FETCH_SIZE 948.6 + 131.9, WRITE_SIZE 733.4 + 132.8 B per read of the batch (narrow + full band launch)
 WINDOW_VALU_PER_READ = 789          # SQ_INSTS_VALU per read of the batch: 684 (narrow band, 6.841e9 per launch) + 105 (full band over the rest)
 VALU_PEAK_SOURCE = "profiles/r01_valu_issue_rates_ubench.txt"  # this repo's micro-benchmark (tools/ubench.hip), not a figure of the guide
 TOTAL_READS_MULTI_GPU = 500_000_000  # BASELINE.json configs[3]
