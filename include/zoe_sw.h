@@ -299,11 +299,11 @@ zsw_error zsw_timing_read_window(zsw_context* ctx, double* seconds, uint64_t* la
 /* Options of a context. ZSW_OPTION_EXACT_PRUNING (value 0 / 1, default 1): the seeded exact first pass (zsw_score_seed.hip;
  * DESIGN.md 4.1e). sw_simd_score returns only the maximum of the DP matrix (striped.rs:65-142), so every entry point that starts
  * with a score pass (score, ends, ranges, alignment, 3-pass alignment) first looks a few k-mers of each read up in an index of
- * the reference, computes the rows around the diagonal they agree on, and accepts the maximum found there only if upper bounds
+ * the reference, computes a band of diagonals around the one they agree on, and accepts the maximum found there only if upper bounds
  * show that no alignment elsewhere can reach it; every other read is scored over all its cells. Same results for every input;
  * roughly an order of magnitude fewer cells on reads that resemble the reference, the cost of the full pass plus a few per
- * cent on reads that do not. 20 bytes of device workspace per read and 8 * 4^K bytes of index (K = 8 for a 2 kb reference:
- * 512 KiB; K = 10 for 30 kb: 8 MiB). Value 0 frees the workspace and computes every cell of every read.
+ * cent on reads that do not. 28 bytes + 4 bits per base of device workspace per read, up to 0.3 GB of strip-boundary buffers per
+ * call, and 8 * 4^K bytes of index (K = 8 for a 2 kb reference: 512 KiB; K = 10 for 30 kb: 8 MiB). Value 0 frees the workspace and computes every cell of every read.
  * Unknown options or values return ZSW_ERR_INVALID_ARGUMENT. */
 typedef enum zsw_option { ZSW_OPTION_EXACT_PRUNING = 1 } zsw_option;
 zsw_error zsw_set_option(zsw_context* ctx, zsw_option option, int64_t value);
@@ -329,8 +329,8 @@ typedef enum zsw_debug_flag {
     /* align: the second pass starts warmup_rows before the first kept row for every read (round 2), not at the row the seeded
      * first pass certifies (zsw_seed.hpp: seed_safe_start) */
     ZSW_DEBUG_ALIGN_LONG_WARMUP = 1024,
-    /* score: the seeded pass computes whole rows around the anchor (seed_window_kernel) for score-only calls too, instead of the
-     * band of diagonals of seed_band_kernel (zsw_score_band.hip) */
+    /* the seeded pass computes whole rows around the anchor (seed_window_kernel) instead of the band of diagonals of
+     * seed_band_kernel (zsw_score_band.hip) */
     ZSW_DEBUG_SEED_NO_BAND = 2048,
     /* score: the banded kernel walks every read in the full band at once (no narrow first band for short reads) */
     ZSW_DEBUG_SEED_WIDE_BAND = 4096

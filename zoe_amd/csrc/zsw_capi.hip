@@ -146,8 +146,8 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     const bool any_size = (flags & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE) != 0;
     if (!ctx->shared_call && (flags & ZSW_DEBUG_SCORE_PRUNE) && !(flags & ZSW_DEBUG_PRUNE_STRIP) && n > 0 && (n >= SEED_MIN_READS || any_size) && ctx->ref_len > 0 &&
         st->max_len >= SEED_MIN_LEN) {
-        // the seeded exact pass: index of the reference (first use after a change of reference or matrix), 20 bytes of workspace
-        // per read and the worklist of the reads it hands back. If the device cannot spare them the full pass runs.
+        // the seeded exact pass: index of the reference (first use after a change of reference or matrix), 28 bytes + 4 bits per base
+        // of workspace per read, the banded kernel's strip-boundary buffers and the worklist of the reads it hands back. If the device cannot spare them the full pass runs.
         if (!ctx->seed.valid) ZSW_HIP(ctx, seed_index_update(&ctx->seed, ctx->h_sc, ctx->h_ref.data(), ctx->ref_len));
         if (ctx->seed.usable) {
             // ragged batches: a region per length class (the banded pass's buffers are sized per region, by the reads in it)
