@@ -254,3 +254,40 @@ def test_every_length_class_of_a_large_ragged_batch_takes_the_seeded_pass(za):
     finally:
         ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
     assert torch.equal(got.score, full.score) and torch.equal(got.status, full.status) and torch.equal(got.tier, full.tier)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 127, 129, 513])
+def test_banded_pass_work_queue_on_tiny_batches(za, oracle, n):
+    """The banded kernel hands out pairs 64 at a time and stops at the first chunk past the end: one read, an odd count, counts
+    around one and two chunks (two reads per pair), through both tiers; scores and ranges against the full pass (and a few reads
+    against the oracle)."""
+    import torch
+    from zoe_amd import _lib, synth
+
+    ctx = za.SwContext.get(0)
+    ref = synth.reference_host(2000)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    reads = synth.reads_host(ref, 1000 + n, n, 150)
+    rb = _batch(za, reads)
+    casc = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
+    seq = za.SeqSrc.Reference(ref)
+    try:
+        ctx.debug_set(_lib.DEBUG_SCORE_PRUNE_ANY_SIZE)
+        got_s = casc.sw_score_from_i8(ref)
+        got_r = casc.sw_score_ranges_from_i8(seq)
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
+        want_s = casc.sw_score_from_i8(ref)
+        want_r = casc.sw_score_ranges_from_i8(seq)
+    finally:
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
+        ctx.debug_set(0)
+    for f in ("score", "status", "tier"):
+        assert torch.equal(getattr(got_s, f), getattr(want_s, f)), f
+    for f in ("score", "status", "ref_start", "ref_end", "query_start", "query_end"):
+        assert torch.equal(getattr(got_r, f), getattr(want_r, f)), f
+    sc = oracle.Scoring(dna.signed_weights(), dna.mapping.index_map, -10, -1)
+    for i in range(0, n, max(1, n // 8)):
+        st, s, rr, qr = oracle.score_ranges("i16", 16, sc, reads[i], ref)
+        assert int(got_r.status[i]) == st, i
+        if st == 0:
+            assert (int(got_r.score[i]), (int(got_r.ref_start[i]), int(got_r.ref_end[i])), (int(got_r.query_start[i]), int(got_r.query_end[i]))) == (s, rr, qr), i
