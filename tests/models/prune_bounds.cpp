@@ -18,6 +18,10 @@ namespace {
 
 struct Scheme {
     int match, mismatch, go, ge;  // gaps as positive magnitudes
+    // wide form (8-32 letter alphabets, prune_*_kernel<.., WIDE>): letters 'A' + k, scores from `w`, and the bounds add the
+    // columns' own potentials max(0, max_x w[x][q_c]) instead of maxw per column
+    int letters = 0;
+    std::vector<int> w;
 };
 
 int code(uint8_t b) {
@@ -43,6 +47,7 @@ struct Dp {
 };
 
 int weight(const Scheme& s, uint8_t a, uint8_t b) {
+    if (s.letters) return s.w[(size_t)(a - 'A') * s.letters + (b - 'A')];
     const int x = code(a), y = code(b);
     if (x == 4 || y == 4) return 0;  // the ignored residue
     return x == y ? s.match : s.mismatch;
@@ -82,6 +87,16 @@ struct Outcome {
 Outcome pruned(const Scheme& s, const std::vector<uint8_t>& ref, const std::vector<uint8_t>& q, Dp& d, int CP, int M2) {
     const int R = d.R, L = d.L, maxw = std::max(s.match, 0);
     Outcome o;
+    // P[c]: the most the 0-based columns c.. can add to a path (gaps add nothing)
+    std::vector<int> P(L + 2, 0);
+    for (int c = L - 1; c >= 0; --c) {
+        int pot = maxw;
+        if (s.letters) {
+            pot = 0;
+            for (int x = 0; x < s.letters; ++x) pot = std::max(pot, s.w[(size_t)x * s.letters + (q[c] - 'A')]);
+        }
+        P[c] = P[c + 1] + pot;
+    }
     // ---- strip: columns [0, CP) of every row are exact; what leaves it per row ----
     int strip = 0;
     std::vector<int> tH(R, 0), tF(R, 0);
@@ -134,14 +149,14 @@ Outcome pruned(const Scheme& s, const std::vector<uint8_t>& ref, const std::vect
     o.row = row2;
     o.col = col2;
     const int rem = std::max(0, L - CP);
-    int bound = maxw * rem;  // V1
+    int bound = P[std::min(CP, L)];  // V1
     if (rem > 0)
         for (int k = 0; k < nblk; ++k)  // V2: blocks outside the window
-            if (k < a0 / BLK || k >= b1 / BLK) bound = std::max(bound, std::max(mH[k] + maxw * rem, mF[k] + maxw * (rem - 1)));
+            if (k < a0 / BLK || k >= b1 / BLK) bound = std::max(bound, std::max(mH[k] + P[CP], mF[k] + P[CP + 1]));
     if (rows_end < R)  // V3: what can still leave the last window row (E of the next row from this row's state)
         for (int c = CP; c < L; ++c) {
             const int enext = std::max(0, std::max(Ep[c] - s.ge, Hp[c] - s.go));
-            bound = std::max(bound, std::max(Hp[c], enext) + maxw * std::max(0, L - c - 1));
+            bound = std::max(bound, std::max(Hp[c], enext) + P[c + 1]);
         }
     o.pass_score = bound <= o.S;
     o.pass_ends = bound < o.S && strip < o.S;
@@ -164,12 +179,30 @@ int main(int argc, char** argv) {
     const Scheme schemes[] = {{2, -5, 10, 1}, {1, -1, 2, 1}, {5, -4, 12, 2}, {3, -2, 4, 0}, {1, -3, 5, 2}, {2, 0, 0, 0}};
     long checked = 0, passed = 0, passed_ends = 0, plain = 0, plain_passed = 0;
     for (int it = 0; it < iters; ++it) {
-        const Scheme s = schemes[g() % 6];
+        Scheme s = schemes[g() % 6];
+        const bool wide = it % 3 == 2;
+        char alpha[33] = "ACGT";
+        if (wide) {  // a BLOSUM-shaped matrix: identities 4..11, substitutions -4..3 (some of them close to an identity), symmetric or not
+            s.letters = 8 + (int)(g() % 18);
+            s.w.assign((size_t)s.letters * s.letters, 0);
+            for (int x = 0; x < s.letters; ++x)
+                for (int y = 0; y <= x; ++y) {
+                    const int v = x == y ? 4 + (int)(g() % 8) : -4 + (int)(g() % 8);
+                    s.w[(size_t)x * s.letters + y] = v;
+                    s.w[(size_t)y * s.letters + x] = g() % 8 == 0 ? v - 1 : v;
+                }
+            if (g() % 4 == 0)  // a letter that scores nothing against anything (X)
+                for (int x = 0; x < s.letters; ++x) s.w[(size_t)x * s.letters + s.letters - 1] = s.w[(size_t)(s.letters - 1) * s.letters + x] = g() % 2 ? 0 : -1;
+            s.go = 6 + (int)(g() % 8);
+            s.ge = (int)(g() % 3);
+            for (int x = 0; x < s.letters; ++x) alpha[x] = (char)('A' + x);
+            alpha[s.letters] = 0;
+        }
         static const int kR[4] = {40, 333, 700, 1500}, kCP[4] = {8, 16, 24, 48};
         const int R = kR[g() % 4];
         const int L = 65 + (int)(g() % 120);
         const int CP = kCP[g() % 4], M2 = 16;
-        std::vector<uint8_t> ref = g() % 5 == 0 ? random_seq(g, R, "AC") : random_seq(g, R);
+        std::vector<uint8_t> ref = g() % 5 == 0 ? random_seq(g, R, "AC") : random_seq(g, R, alpha);
         if (g() % 4 == 0 && R >= 300)  // a second copy of a stretch elsewhere
             std::copy(ref.begin(), ref.begin() + R / 3, ref.begin() + R / 2);
         for (int k = 0; k < 60; ++k) {
@@ -179,7 +212,7 @@ int main(int argc, char** argv) {
             if (kind <= 2 && R > L) {  // sampled with a few edits
                 const int p = (int)(g() % (R - L));
                 q.assign(ref.begin() + p, ref.begin() + p + L);
-                for (int e = (int)(g() % 4); e > 0; --e) q[g() % L] = (uint8_t)"ACGTN"[g() % 5];
+                for (int e = (int)(g() % (wide ? 12 : 4)); e > 0; --e) q[g() % L] = wide ? (uint8_t)alpha[g() % s.letters] : (uint8_t)"ACGTN"[g() % 5];
                 is_plain = true;
             } else if (kind == 3 && R > 2 * L) {  // long deletion / chimera
                 const int p = (int)(g() % (R - 2 * L)), cut = 10 + (int)(g() % (L - 20)), gap = (int)(g() % 90);
@@ -187,18 +220,18 @@ int main(int argc, char** argv) {
                 q.insert(q.end(), ref.begin() + p + cut + gap, ref.begin() + p + cut + gap + (L - cut));
             } else if (kind == 4 && R > L) {  // junk at one end
                 const int p = (int)(g() % (R - L)), j = 1 + (int)(g() % (L - 1));
-                q = random_seq(g, L);
+                q = random_seq(g, L, alpha);
                 if (g() & 1) std::copy(ref.begin() + p + j, ref.begin() + p + L, q.begin() + j);
                 else std::copy(ref.begin() + p, ref.begin() + p + L - j, q.begin());
             } else if (kind == 5) {  // hanging over an end of the reference
                 const int kk = 1 + (int)(g() % std::min(L - 1, R));
-                q = random_seq(g, L);
+                q = random_seq(g, L, alpha);
                 if (g() & 1) std::copy(ref.end() - kk, ref.end(), q.begin());
                 else std::copy(ref.begin(), ref.begin() + kk, q.end() - kk);
             } else if (kind == 6) {
                 q = random_seq(g, L, g() & 1 ? "A" : "AC");
             } else {
-                q = random_seq(g, L);
+                q = random_seq(g, L, alpha);
             }
             Dp d;
             Truth t;

@@ -166,7 +166,10 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
             }
         }
     }
-    if (!ctx->shared_call && (flags & ZSW_DEBUG_SCORE_PRUNE) && (flags & ZSW_DEBUG_PRUNE_STRIP) && n > 0 && (n >= PR_MIN_READS || any_size) &&
+    // the column-pruned pass (strip + window): the default first pass of 8..32-letter alphabets (the seeded pass's k-mer argument
+    // needs substitutions that cost something: it serves the 5-letter tables), a cross-check for the others (ZSW_DEBUG_PRUNE_STRIP)
+    const bool wide_alphabet = ctx->h_sc.S > 7 && ctx->h_sc.S <= 32 && !(flags & ZSW_DEBUG_NO_WIDE);
+    if (!ctx->shared_call && (flags & ZSW_DEBUG_SCORE_PRUNE) && ((flags & ZSW_DEBUG_PRUNE_STRIP) || wide_alphabet) && n > 0 && (n >= PR_MIN_READS || any_size) &&
         ctx->ref_len > 0 && (reads->offsets ? st->max_len > 64 : prune_class_for(st->max_len) >= 0)) {
         const uint32_t chunk = prune_chunk_reads((uint32_t)n, (uint32_t)ctx->ref_len);
         // a reference so long that the boundary streams of a round's reads no longer fill the chip: the full pass

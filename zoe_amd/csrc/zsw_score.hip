@@ -559,15 +559,19 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
     // Column-pruned pass over the items of `bb` (reads of at most kPruneClasses[cls].max_len bases), then score_kernel_v2 over the
     // reads it hands back (device-side list and count). hipErrorNotSupported: not switched on, or the batch does not qualify.
     auto prune_items = [&](const BatchDev& bb, int cls, uint32_t n_cls) -> hipError_t {
-        if (!use_v2 || !ws.prune_work || !(ws.debug & ZSW_DEBUG_SCORE_PRUNE) || !(ws.debug & ZSW_DEBUG_PRUNE_STRIP)) return hipErrorNotSupported;
+        // 5-letter tables: behind ZSW_DEBUG_PRUNE_STRIP (the seeded pass is their default); 8..32 letter alphabets (WIDE tables): the
+        // default first pass — the seeded pass's k-mer argument does not hold for matrices whose substitutions score close to identities
+        if (!(use_v2 || wide) || !ws.prune_work || !(ws.debug & ZSW_DEBUG_SCORE_PRUNE)) return hipErrorNotSupported;
+        if (!wide && !(ws.debug & ZSW_DEBUG_PRUNE_STRIP)) return hipErrorNotSupported;
         if (bb.n_items < PR_MIN_READS && !(ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE)) return hipErrorNotSupported;
         const int last = n_cls < bb.n_items ? cls + 1 : cls;  // the range may hold the next class too (same strip width)
         ScoreArgsV2 ap = a2;
-        if (!build_tables_v2(h_sc, 1, &ap)) return hipErrorNotSupported;
+        auto tables = [&](int g, ScoreArgsV2* t) { return wide ? build_tables_wide(h_sc, g, t) : build_tables_v2(h_sc, g, t); };
+        if (!tables(1, &ap)) return hipErrorNotSupported;
         const uint32_t floor_strip = ap.floor0;
         uint32_t limit = ap.limit, floor_window[2] = {0, 0};
         for (int c = cls; c <= last; ++c) {
-            if (!build_tables_v2(h_sc, kPruneClasses[c].g, &ap)) return hipErrorNotSupported;
+            if (!tables(kPruneClasses[c].g, &ap)) return hipErrorNotSupported;
             floor_window[c - cls] = ap.floor0;
             limit = std::min(limit, ap.limit);
         }
@@ -578,13 +582,13 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         if (pe != hipSuccess) return pe;
         ap.b = bb;
         pe = launch_score_pruned(ap, cls, n_cls, floor_strip, floor_window, h_sc, ws.prune_work, ws.prune_bytes, ws.prune_chunk,
-                                 ws.prune_fail_list, ws.prune_fail_count, mode, stream);
+                                 ws.prune_fail_list, ws.prune_fail_count, mode, wide, stream);
         if (pe != hipSuccess) return pe;
-        if (!build_tables_v2(h_sc, Gr, &a2)) return hipErrorInvalidValue;
+        if (!tables(Gr, &a2)) return hipErrorInvalidValue;
         a2.b = bb;
         a2.b.items = ws.prune_fail_list;
         a2.n_items_dev = ws.prune_fail_count;
-        pe = launch_table_cfg_v2(a2, Gr, Cr, mode, stream);
+        pe = wide ? launch_table_cfg_v2_wide(a2, Gr, Cr, mode, stream) : launch_table_cfg_v2(a2, Gr, Cr, mode, stream);
         a2.n_items_dev = nullptr;
         if (pe != hipSuccess) return pe;
         hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, stream, ws.prune_fail_count, ws.prune_fail_count + 1);

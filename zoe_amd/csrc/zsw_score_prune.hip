@@ -39,6 +39,10 @@ struct PruneArgs {
     uint32_t ref_len;
     const ScoringDev* sc;
     uint32_t wtab[9][2];
+    // WIDE kernels (alphabets of 8..32 letters): the score table of score_kernel_v2<.., WIDE> and the potential of a query column
+    // by its residue, max(0, max_x w[x][q]) — what the column can add to a path at most (index WIDE_PAD: padding, 0)
+    int8_t wide[33 * 36];
+    uint8_t colpot[36];
     uint32_t ge2, gd2, floor0, K;
     ResultRule rule;
     ScoreOut out;
@@ -71,20 +75,24 @@ __device__ __forceinline__ void read_span(const BatchDev& b, uint32_t id, uint64
 // read id of entry k of the chunk (the batch may address its reads through an item list: length classes of a ragged batch)
 __device__ __forceinline__ uint32_t read_id(const PruneArgs& a, uint32_t k) { return a.b.items ? a.b.items[a.first + k] : a.first + k; }
 
-// selector of query column q of reads A and B for the v_perm lookup (zsw_score_v2.hpp (3))
+// selector of query column q of reads A and B for the v_perm lookup (zsw_score_v2.hpp (3)); WIDE: the two residues themselves
+template <bool WIDE>
 __device__ __forceinline__ uint32_t column_selector(const BatchDev& b, const uint8_t* lut, uint32_t q, uint64_t offA, uint32_t lenA,
                                                     uint64_t offB, uint32_t lenB) {
     uint32_t kA = PAD_K, kB = PAD_K;
     if (q < lenA) kA = lut[b.bases[offA + q]];
     if (q < lenB) kB = lut[b.bases[offB + q]];
+    if (WIDE) return (kA == PAD_K ? (uint32_t)WIDE_PAD : kA) | ((kB == PAD_K ? (uint32_t)WIDE_PAD : kB) << 16);
     const uint32_t sA = kA < 4 ? (2 * kA + 1) | ((8 + kA) << 8) : (kA == PAD_K ? 0x0c00u : (2 * (kA - 3)) | 0x0c00u);
     const uint32_t sB = kB < 4 ? (2 * kB + 1) | ((8 + kB) << 8) : (kB == PAD_K ? 0x0c00u : (2 * (kB - 3)) | 0x0c00u);
     return sA | (sB << 16);
 }
 
-template <int C>
+template <int C, bool WIDE>
 __global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_strip_kernel(PruneArgs a) {
-    __shared__ uint2 rp[CH];
+    __shared__ uint2 rp[WIDE ? 1 : CH];
+    __shared__ uint16_t rpw[WIDE ? CH : 1];       // WIDE: byte offset of each staged row's table row
+    __shared__ uint32_t wt32[WIDE ? 33 * 9 : 1];  // WIDE: the score table
     __shared__ uint2 swt[9];
     __shared__ uint32_t lut32[64];
     __shared__ __attribute__((aligned(16))) uint2 stage_all[BLOCK * 10];
@@ -95,14 +103,27 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_strip_kernel(Pru
     const bool validB = valid && 2 * pair + 1 < a.n;
     if (tid < 64) lut32[tid] = reinterpret_cast<const uint32_t*>(a.sc->index_map)[tid];
     if (tid < 9) swt[tid] = make_uint2(a.wtab[tid][0], a.wtab[tid][1]);
+    if (WIDE) {
+        for (int i = tid; i < 33 * 9; i += BLOCK) wt32[WIDE ? i : 0] = reinterpret_cast<const uint32_t*>(a.wide)[i];
+    }
     __syncthreads();
+    const int8_t* wt = reinterpret_cast<const int8_t*>(wt32);
+    // column score of the current row for both reads, as a packed pair of i16 (score + ge)
+    auto lookup = [&](const uint2 ww, const uint32_t sl) -> uint32_t {
+        if constexpr (WIDE) {
+            const int sa = wt[ww.x + (sl & 0xffffu)], sb = wt[ww.x + (sl >> 16)];
+            return __builtin_amdgcn_perm((uint32_t)sb, (uint32_t)sa, 0x05040100u);
+        } else {
+            return __builtin_amdgcn_perm(ww.y, ww.x, sl);
+        }
+    };
     uint64_t offA = 0, offB = 0;
     uint32_t lenA = 0, lenB = 0;
     if (valid) read_span(a.b, read_id(a, 2 * pair), &offA, &lenA);
     if (validB) read_span(a.b, read_id(a, 2 * pair + 1), &offB, &lenB);
     uint32_t sel[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) sel[c] = column_selector(a.b, lut, (uint32_t)c, offA, lenA, offB, lenB);
+    for (int c = 0; c < C; ++c) sel[c] = column_selector<WIDE>(a.b, lut, (uint32_t)c, offA, lenA, offB, lenB);
 
     const uint32_t ge2 = a.ge2, gd2 = a.gd2;
     const uint32_t ge1 = ge2 & 0xffffu;
@@ -128,14 +149,15 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_strip_kernel(Pru
         __syncthreads();
         for (int j = tid; j < CH; j += BLOCK) {
             const int row = base + j;
-            rp[j] = swt[row < R ? (int)lut[a.ref[row]] : NEUTRAL];
+            if (WIDE) rpw[WIDE ? j : 0] = (uint16_t)((row < R ? (int)lut[a.ref[row]] : WIDE_NEUTRAL) * WIDE_STRIDE);
+            else rp[WIDE ? 0 : j] = swt[row < R ? (int)lut[a.ref[row]] : NEUTRAL];
         }
         __syncthreads();
         const int tend = (R < base + CH) ? R : base + CH;
-        uint2 w = rp[0];
+        uint2 w = WIDE ? make_uint2(rpw[0], 0u) : rp[0];
 #pragma unroll 1
         for (int t = base; t < tend; ++t) {
-            const uint2 wn = rp[(t + 1 - base) & (CH - 1)];
+            const uint2 wn = WIDE ? make_uint2(rpw[WIDE ? (t + 1 - base) & (CH - 1) : 0], 0u) : rp[WIDE ? 0 : (t + 1 - base) & (CH - 1)];
             if (ge1 != 0 && t > 0 && (t & (int)(K - 1)) == 0) {  // re-base (every lane is in the same row)
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
@@ -147,13 +169,13 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_strip_kernel(Pru
             const uint32_t Dp = Dr;         // D_{r-1}: the (zero) H left of column 0 in the previous row
             Dr = pk_addu(Dr, ge2);          // D_r
             const uint32_t Dn = pk_addu(Dr, ge2);
-            uint32_t hd = pk_addu(Dp, __builtin_amdgcn_perm(w.y, w.x, sel[0]));
+            uint32_t hd = pk_addu(Dp, lookup(w, sel[0]));
             uint32_t F = Dr;
             uint32_t rmax = 0x04000400u;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 uint32_t hd_next = 0;
-                if (c + 1 < C) hd_next = pk_addu(H[c], __builtin_amdgcn_perm(w.y, w.x, sel[c + 1 < C ? c + 1 : c]));
+                if (c + 1 < C) hd_next = pk_addu(H[c], lookup(w, sel[c + 1 < C ? c + 1 : c]));
                 const uint32_t h = pk_max3(hd, E[c], F);
                 H[c] = h;
                 const uint32_t hg = h - gd2;
@@ -202,10 +224,13 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_strip_kernel(Pru
     }
 }
 
-template <int CP, int G, int C, int MODE>
+template <int CP, int G, int C, int MODE, bool WIDE>
 __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel(PruneArgs a) {
     constexpr int M2 = PR_M2 + 8 * (G / 8);  // longer reads: more room for deletions below the anchor
-    __shared__ uint2 rp[CH + 2 * G];
+    __shared__ uint2 rp[WIDE ? 1 : CH + 2 * G];
+    __shared__ uint16_t rpw[WIDE ? CH + 2 * G : 1];  // WIDE: byte offset of each staged row's table row
+    __shared__ uint32_t wt32[WIDE ? 33 * 9 : 1];     // WIDE: the score table
+    __shared__ uint8_t spot[WIDE ? 36 : 1];          // WIDE: potential of a column by its residue
     __shared__ int s_lo, s_hi;
     __shared__ uint2 swt[9];
     __shared__ uint32_t lut32[64];
@@ -224,7 +249,20 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
         s_lo = 0x7fffffff;
         s_hi = 0;
     }
+    if (WIDE) {
+        for (int i = tid; i < 33 * 9; i += BLOCK) wt32[WIDE ? i : 0] = reinterpret_cast<const uint32_t*>(a.wide)[i];
+        if (tid < 36) spot[WIDE ? tid : 0] = a.colpot[tid];
+    }
     __syncthreads();
+    const int8_t* wt = reinterpret_cast<const int8_t*>(wt32);
+    auto lookup = [&](const uint2 ww, const uint32_t sl) -> uint32_t {
+        if constexpr (WIDE) {
+            const int sa = wt[ww.x + (sl & 0xffffu)], sb = wt[ww.x + (sl >> 16)];
+            return __builtin_amdgcn_perm((uint32_t)sb, (uint32_t)sa, 0x05040100u);
+        } else {
+            return __builtin_amdgcn_perm(ww.y, ww.x, sl);
+        }
+    };
 
     uint64_t offA = 0, offB = 0;
     uint32_t lenA = 0, lenB = 0;
@@ -233,7 +271,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
     if (validB) read_span(a.b, idB, &offB, &lenB);
     uint32_t sel[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) sel[c] = column_selector(a.b, lut, (uint32_t)(CP + g * C + c), offA, lenA, offB, lenB);
+    for (int c = 0; c < C; ++c) sel[c] = column_selector<WIDE>(a.b, lut, (uint32_t)(CP + g * C + c), offA, lenA, offB, lenB);
 
     // the window: blocks of rows around the two anchors
     const int rsA = validA ? (int)(a.anchor[ridA] & 0xffffffu) : 0, rsB = validB ? (int)(a.anchor[ridB] & 0xffffffu) : rsA;
@@ -258,7 +296,8 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
     if (staged) {
         for (int j = tid; j < bhi - blo + 2 * G; j += BLOCK) {
             const int row = blo - (G - 1) + j;
-            rp[j] = swt[(row >= 0 && row < R) ? (int)lut[a.ref[row]] : NEUTRAL];
+            if (WIDE) rpw[WIDE ? j : 0] = (uint16_t)(((row >= 0 && row < R) ? (int)lut[a.ref[row]] : WIDE_NEUTRAL) * WIDE_STRIDE);
+            else rp[WIDE ? 0 : j] = swt[(row >= 0 && row < R) ? (int)lut[a.ref[row]] : NEUTRAL];
         }
     }
     __syncthreads();
@@ -297,10 +336,11 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
         ldB = bB[a0];
     }
     const int T = staged ? Tw + G - 1 : 0;
-    uint2 w = rp[staged ? joff : 0];
+    auto row_entry = [&](int j) -> uint2 { return WIDE ? make_uint2(rpw[WIDE ? j : 0], 0u) : rp[WIDE ? 0 : j]; };
+    uint2 w = row_entry(staged ? joff : 0);
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
-        const uint2 wn = rp[joff + t + 1];
+        const uint2 wn = row_entry(joff + t + 1);
         const int row = t - g;  // row of the window
         const bool rebase = ge1 != 0 && row > 0 && (row & (int)(K - 1)) == 0;
         if (__ballot(rebase) != 0) {
@@ -330,14 +370,14 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
                 ldB = bB[grow + 1];
             }
         }
-        uint32_t hd = pk_addu(Hin_prev, __builtin_amdgcn_perm(w.y, w.x, sel[0]));
+        uint32_t hd = pk_addu(Hin_prev, lookup(w, sel[0]));
         Hin_prev = Hin;
         uint32_t F = Fin;
         uint32_t rmax = 0x04000400u;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             uint32_t hd_next = 0;
-            if (c + 1 < C) hd_next = pk_addu(H[c], __builtin_amdgcn_perm(w.y, w.x, sel[c + 1 < C ? c + 1 : c]));
+            if (c + 1 < C) hd_next = pk_addu(H[c], lookup(w, sel[c + 1 < C ? c + 1 : c]));
             const uint32_t h = pk_max3(hd, E[c], F);
             H[c] = h;
             const uint32_t hg = h - gd2;
@@ -409,23 +449,69 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
     const int SA = max(bA2, stripA), SB = max(bB2, stripB);
     const int maxw = (int)a.maxw;
     const int remA = max(0, (int)lenA - CP), remB = max(0, (int)lenB - CP);
+    // What the columns from a given one on can add to a path at most: maxw per column with the v_perm tables; WIDE: the columns'
+    // own potentials by residue (padding: 0), summed from the right — inside the lane, then over the lanes to its right.
+    int rightA = 0, rightB = 0, nfA = 0, nfB = 0, PcpA = maxw * remA, PcpB = maxw * remB, Pcp1A = maxw * max(0, remA - 1), Pcp1B = maxw * max(0, remB - 1);
+    if constexpr (WIDE) {
+        int totA = 0, totB = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            totA += (int)spot[sel[c] & 0xffffu];
+            totB += (int)spot[sel[c] >> 16];
+        }
+        const int p0A = (int)spot[sel[0] & 0xffffu], p0B = (int)spot[sel[0] >> 16];
+#pragma unroll
+        for (int d = 1; d < G; ++d) {
+            const int xa = __shfl_down(totA, d, G), xb = __shfl_down(totB, d, G);
+            if (g + d < G) {
+                rightA += xa;
+                rightB += xb;
+            }
+        }
+        nfA = __shfl_down(p0A, 1, G);
+        nfB = __shfl_down(p0B, 1, G);
+        if (g + 1 >= G) nfA = nfB = 0;
+        PcpA = __shfl(totA + rightA, 0, G);
+        PcpB = __shfl(totB + rightB, 0, G);
+        Pcp1A = __shfl(totA + rightA - p0A, 0, G);
+        Pcp1B = __shfl(totB + rightB - p0B, 0, G);
+    }
     // V3: what can still leave this lane's last row (E holds the next row's E; Fout moves right into the next lane's columns)
     int v3A = 0, v3B = 0;
     if (a0 + Tw < R) {
         const int dA = (int)(Dr & 0xffffu), dB = (int)(Dr >> 16);
+        if constexpr (WIDE) {
+            int accA = rightA, accB = rightB;  // the columns right of column c
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int col = CP + g * C + c;
-            const uint32_t he = pk_maxu(H[c], pk_subu(E[c], ge2));
-            v3A = max(v3A, (int)(he & 0xffffu) - dA + maxw * max(0, (int)lenA - col - 1));
-            v3B = max(v3B, (int)(he >> 16) - dB + maxw * max(0, (int)lenB - col - 1));
-        }
-        const int colr = CP + (g + 1) * C;
-        v3A = max(v3A, (int)(Fout & 0xffffu) - dA + maxw * max(0, (int)lenA - colr - 1));
-        v3B = max(v3B, (int)(Fout >> 16) - dB + maxw * max(0, (int)lenB - colr - 1));
-        if (g > 0) {  // the diagonal from the left neighbour's last column, one row up, into the first cell below this lane's rows
-            v3A = max(v3A, (int)(Hin_prev & 0xffffu) - dA + maxw * max(0, (int)lenA - (CP + g * C)));
-            v3B = max(v3B, (int)(Hin_prev >> 16) - dB + maxw * max(0, (int)lenB - (CP + g * C)));
+            for (int c = C - 1; c >= 0; --c) {
+                const uint32_t he = pk_maxu(H[c], pk_subu(E[c], ge2));
+                v3A = max(v3A, (int)(he & 0xffffu) - dA + accA);
+                v3B = max(v3B, (int)(he >> 16) - dB + accB);
+                accA += (int)spot[sel[c] & 0xffffu];
+                accB += (int)spot[sel[c] >> 16];
+            }
+            // the outgoing F opens the next lane's first column as a gap: the columns after that one
+            v3A = max(v3A, (int)(Fout & 0xffffu) - dA + rightA - nfA);
+            v3B = max(v3B, (int)(Fout >> 16) - dB + rightB - nfB);
+            if (g > 0) {  // the diagonal from the left neighbour's last column, one row up, into the first cell below this lane's rows
+                v3A = max(v3A, (int)(Hin_prev & 0xffffu) - dA + accA);
+                v3B = max(v3B, (int)(Hin_prev >> 16) - dB + accB);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int col = CP + g * C + c;
+                const uint32_t he = pk_maxu(H[c], pk_subu(E[c], ge2));
+                v3A = max(v3A, (int)(he & 0xffffu) - dA + maxw * max(0, (int)lenA - col - 1));
+                v3B = max(v3B, (int)(he >> 16) - dB + maxw * max(0, (int)lenB - col - 1));
+            }
+            const int colr = CP + (g + 1) * C;
+            v3A = max(v3A, (int)(Fout & 0xffffu) - dA + maxw * max(0, (int)lenA - colr - 1));
+            v3B = max(v3B, (int)(Fout >> 16) - dB + maxw * max(0, (int)lenB - colr - 1));
+            if (g > 0) {  // the diagonal from the left neighbour's last column, one row up, into the first cell below this lane's rows
+                v3A = max(v3A, (int)(Hin_prev & 0xffffu) - dA + maxw * max(0, (int)lenA - (CP + g * C)));
+                v3B = max(v3B, (int)(Hin_prev >> 16) - dB + maxw * max(0, (int)lenB - (CP + g * C)));
+            }
         }
     }
     // V2: crossings in rows outside the window, block by block
@@ -439,8 +525,8 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
             const uint2 xA = kA[k], xB = kB[k];
             const int hA = (int)((ridA & 1) ? xA.x >> 16 : xA.x & 0xffffu), fA = (int)((ridA & 1) ? xA.y >> 16 : xA.y & 0xffffu);
             const int hB = (int)((ridB & 1) ? xB.x >> 16 : xB.x & 0xffffu), fB = (int)((ridB & 1) ? xB.y >> 16 : xB.y & 0xffffu);
-            if (remA > 0) v2A = max(v2A, max(hA + maxw * remA, fA + maxw * (remA - 1)));
-            if (remB > 0) v2B = max(v2B, max(hB + maxw * remB, fB + maxw * (remB - 1)));
+            if (remA > 0) v2A = max(v2A, max(hA + PcpA, fA + Pcp1A));
+            if (remB > 0) v2B = max(v2B, max(hB + PcpB, fB + Pcp1B));
         }
     }
     int wA = max(v2A, v3A), wB = max(v2B, v3B);
@@ -449,8 +535,8 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void prune_window_kernel
         wA = max(wA, __shfl_xor(wA, d, G));
         wB = max(wB, __shfl_xor(wB, d, G));
     }
-    wA = max(wA, maxw * remA);  // V1
-    wB = max(wB, maxw * remB);
+    wA = max(wA, PcpA);  // V1
+    wB = max(wB, PcpB);
     if (g < 2) {
         const bool second = g == 1;
         const bool v = second ? validB : validA;
@@ -530,13 +616,31 @@ bool prune_applicable(const ScoringDev& s, uint32_t max_len, uint32_t ref_len, u
 
 namespace {
 
-template <int CP, int G, int C>
-void launch_window(const PruneArgs& a, int mode, hipStream_t stream) {
+template <int CP, int G, int C, bool WIDE>
+void launch_window_t(const PruneArgs& a, int mode, hipStream_t stream) {
     const uint32_t groups = (a.n + 1) / 2, per_block = BLOCK / G;
     const dim3 grid((groups + per_block - 1) / per_block);
-    if (mode == 0) hipLaunchKernelGGL((prune_window_kernel<CP, G, C, 0>), grid, dim3(BLOCK), 0, stream, a);
-    else if (mode == 1) hipLaunchKernelGGL((prune_window_kernel<CP, G, C, 1>), grid, dim3(BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL((prune_window_kernel<CP, G, C, 2>), grid, dim3(BLOCK), 0, stream, a);
+    if (mode == 0) hipLaunchKernelGGL((prune_window_kernel<CP, G, C, 0, WIDE>), grid, dim3(BLOCK), 0, stream, a);
+    else if (mode == 1) hipLaunchKernelGGL((prune_window_kernel<CP, G, C, 1, WIDE>), grid, dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((prune_window_kernel<CP, G, C, 2, WIDE>), grid, dim3(BLOCK), 0, stream, a);
+}
+
+template <int CP, int G, int C>
+void launch_window(const PruneArgs& a, bool wide, int mode, hipStream_t stream) {
+    if (wide) launch_window_t<CP, G, C, true>(a, mode, stream);
+    else launch_window_t<CP, G, C, false>(a, mode, stream);
+}
+
+template <int CP>
+void launch_strip(const PruneArgs& a, bool wide, dim3 grid, hipStream_t stream) {
+    if (wide) hipLaunchKernelGGL((prune_strip_kernel<CP, true>), grid, dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((prune_strip_kernel<CP, false>), grid, dim3(BLOCK), 0, stream, a);
+}
+
+template <int CP>
+hipError_t strip_blocks_per_cu(bool wide, int* per_cu) {
+    return wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, prune_strip_kernel<CP, true>, BLOCK, 0)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, prune_strip_kernel<CP, false>, BLOCK, 0);
 }
 
 }  // namespace
@@ -547,7 +651,7 @@ void launch_window(const PruneArgs& a, int mode, hipStream_t stream) {
 // floor_window[2] are the drift floors for G = 1 and for the two classes' G.
 hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t n_cls, uint32_t floor_strip, const uint32_t* floor_window,
                                const ScoringDev& h_sc, uint8_t* work, size_t work_bytes, uint32_t chunk_reads, uint32_t* fail_list,
-                               uint32_t* fail_count, int mode, hipStream_t stream) {
+                               uint32_t* fail_count, int mode, bool wide, hipStream_t stream) {
     const uint32_t n = a2.b.n_items, R = a2.ref_len;
     if (n == 0) return hipSuccess;
     if (cls < 0 || cls >= PR_N_CLASSES || chunk_reads < 2 || work_bytes < prune_workspace_bytes(chunk_reads, R)) return hipErrorNotSupported;
@@ -560,6 +664,13 @@ hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t n_cls, u
     for (int r = 0; r < 9; ++r) {
         a.wtab[r][0] = a2.wtab[r][0];
         a.wtab[r][1] = a2.wtab[r][1];
+    }
+    for (int i = 0; i < 33 * 36; ++i) a.wide[i] = wide ? a2.wide[i] : (int8_t)0;
+    for (int q = 0; q < 36; ++q) {  // what a query column holding residue q can add to a path at most
+        int pot = 0;
+        if (wide && q < h_sc.S)
+            for (int r = 0; r < h_sc.S; ++r) pot = std::max(pot, (int)h_sc.w[r * h_sc.S + q]);
+        a.colpot[q] = (uint8_t)std::min(pot, 255);
     }
     a.ge2 = a2.ge2;
     a.gd2 = a2.gd2;
@@ -601,8 +712,7 @@ hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t n_cls, u
         hipError_t qe = hipGetDevice(&dev);
         if (qe == hipSuccess) qe = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (qe == hipSuccess)
-            qe = kPruneClasses[cls].cp == 24 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prune_strip_kernel<24>, BLOCK, 0)
-                                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, prune_strip_kernel<48>, BLOCK, 0);
+            qe = kPruneClasses[cls].cp == 24 ? strip_blocks_per_cu<24>(wide, &per_cu) : strip_blocks_per_cu<48>(wide, &per_cu);
         if (qe != hipSuccess) return qe;
         const uint64_t quantum = (uint64_t)cus * (uint64_t)per_cu * 2 * BLOCK;  // reads the chip holds at once
         if (quantum > 0 && n > chunk_reads && chunk_reads >= quantum) chunk_reads = (uint32_t)(chunk_reads / quantum * quantum);
@@ -614,8 +724,8 @@ hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t n_cls, u
         a.split = first >= n_cls ? 0u : std::min<uint32_t>(a.n, n_cls - first);  // entries of the chunk that belong to `cls`
         a.floor0 = floor_strip;
         const dim3 sgrid((a.n_pairs + BLOCK - 1) / BLOCK);
-        if (kPruneClasses[cls].cp == 24) hipLaunchKernelGGL((prune_strip_kernel<24>), sgrid, dim3(BLOCK), 0, stream, a);
-        else hipLaunchKernelGGL((prune_strip_kernel<48>), sgrid, dim3(BLOCK), 0, stream, a);
+        if (kPruneClasses[cls].cp == 24) launch_strip<24>(a, wide, sgrid, stream);
+        else launch_strip<48>(a, wide, sgrid, stream);
         hipLaunchKernelGGL(iota32_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, ids_in, a.n);
         hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t*)a.anchor, keys_out, (const uint32_t*)ids_in, ids_out,
                                                           (int)a.n, 0, key_bits, stream);
@@ -628,9 +738,9 @@ hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t n_cls, u
             a.n = part ? n_chunk - n_first : n_first;
             if (a.n == 0) continue;
             a.floor0 = floor_window[part];
-            if (c == 0) launch_window<24, 4, 32>(a, mode, stream);
-            else if (c == 1) launch_window<48, 8, 32>(a, mode, stream);
-            else launch_window<48, 16, 22>(a, mode, stream);
+            if (c == 0) launch_window<24, 4, 32>(a, wide, mode, stream);
+            else if (c == 1) launch_window<48, 8, 32>(a, wide, mode, stream);
+            else launch_window<48, 16, 22>(a, wide, mode, stream);
         }
         a.n = n_chunk;
         e = hipGetLastError();
