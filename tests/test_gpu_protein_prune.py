@@ -210,3 +210,37 @@ def test_wide_pruned_is_the_default_for_large_batches_and_equals_the_full_pass(z
     for i in range(0, n, 997):
         o_st, o_s, o_t = oracle.cascade_score(8, 256, sc, reads[i].tobytes(), ref)
         assert (int(got.status[i]), int(got.score[i]) if o_st == S_ else 0, int(got.tier[i])) == (o_st, o_s if o_st == S_ else 0, o_t), i
+
+
+def test_diverged_reads_take_the_bail_out(za):
+    """2 M unrelated protein sequences: the first chip-full goes through strip + window, nearly all of it is handed back, and the
+    rest of the batch takes the full pass at once — same results, and the call costs about the full pass (measured 1.04x)"""
+    import time
+
+    import torch
+
+    ctx = za.SwContext.get(0)
+    keys, mp, w, m = _matrix(za, 3)
+    rng = np.random.default_rng(41)
+    alpha = np.frombuffer(keys[:20], dtype=np.uint8)
+    ref = bytes(rng.choice(alpha, 2000))
+    n = 2_000_000
+    reads = rng.choice(alpha, (n, 150)).astype(np.uint8)
+    lp = za.LocalProfilesBatch.new_with_w256(_batch(za, reads), m, -11, -1)
+
+    def timed():
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = lp.sw_score_from_i8(ref)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return out, best
+
+    got, t_pruned = timed()
+    assert ctx.prune_rescored() == n  # the probe's reads failed their checks, the others were never tried
+    with full_pass(ctx):
+        want, t_full = timed()
+    assert torch.equal(got.score, want.score) and torch.equal(got.status, want.status) and torch.equal(got.tier, want.tier)
+    assert t_pruned <= 1.10 * t_full, (t_pruned, t_full)

@@ -88,8 +88,9 @@ __device__ __forceinline__ uint32_t column_selector(const BatchDev& b, const uin
     return sA | (sB << 16);
 }
 
+// WIDE, 24 columns: three waves per SIMD — at four (128 VGPRs) the two LDS lookups per column spill inside the row loop
 template <int C, bool WIDE>
-__global__ __launch_bounds__(BLOCK, min_waves(C, 0)) void prune_strip_kernel(PruneArgs a) {
+__global__ __launch_bounds__(BLOCK, (WIDE && C <= 24) ? 3 : min_waves(C, 0)) void prune_strip_kernel(PruneArgs a) {
     __shared__ uint2 rp[WIDE ? 1 : CH];
     __shared__ uint16_t rpw[WIDE ? CH : 1];       // WIDE: byte offset of each staged row's table row
     __shared__ uint32_t wt32[WIDE ? 33 * 9 : 1];  // WIDE: the score table
@@ -577,6 +578,14 @@ __global__ void iota32_kernel(uint32_t* v, uint32_t n) {
     if (i < n) v[i] = i;
 }
 
+// bail-out: entries [first, n) of the batch join the list of reads to be scored over all their cells
+__global__ void append_rest_kernel(const uint32_t* items, uint32_t first, uint32_t n, uint32_t* fail_list, const uint32_t* fail_count) {
+    const uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fail_list[*fail_count + (i - first)] = items ? items[i] : i;
+}
+
+__global__ void add_const_kernel(uint32_t* count, uint32_t v) { *count += v; }
+
 size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -704,6 +713,7 @@ hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t n_cls, u
     while ((1u << key_bits) < R + 1 && key_bits < 32) ++key_bits;
     if (n_cls < n) key_bits = 25;  // bit 24: the second class of the range
 
+    uint32_t probe_reads = 0;
     // a round of the strip kernel should not spill a few blocks into a second wave of blocks: every block walks all R rows,
     // so 545 blocks on 512 slots take twice as long as 512. When the batch needs several rounds, a round is a whole multiple of
     // what the chip holds at once.
@@ -716,10 +726,26 @@ hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t n_cls, u
         if (qe != hipSuccess) return qe;
         const uint64_t quantum = (uint64_t)cus * (uint64_t)per_cu * 2 * BLOCK;  // reads the chip holds at once
         if (quantum > 0 && n > chunk_reads && chunk_reads >= quantum) chunk_reads = (uint32_t)(chunk_reads / quantum * quantum);
+        // Bail-out probe: a batch of several chip-fulls runs one of them first and reads the number of handed-back reads back.
+        // Strip + window cost about a fifth of the full pass, so above PR_BAIL_PERCENT handed back the pass no longer pays and
+        // the rest of the batch is scored over all its cells at once (unrelated or strongly diverged reads: 1.2x -> 1.0x + the probe).
+        if (quantum > 0 && quantum <= chunk_reads && n >= 2 * quantum) probe_reads = (uint32_t)quantum;
     }
-    for (uint32_t first = 0; first < n; first += chunk_reads) {
+    for (uint32_t first = 0; first < n; first += (first == 0 && probe_reads ? probe_reads : chunk_reads)) {
+        const uint32_t this_chunk = first == 0 && probe_reads ? probe_reads : chunk_reads;
+        if (probe_reads && first == probe_reads) {
+            uint32_t failed = 0;
+            hipError_t be = hipMemcpyAsync(&failed, fail_count, sizeof(failed), hipMemcpyDeviceToHost, stream);
+            if (be == hipSuccess) be = hipStreamSynchronize(stream);
+            if (be != hipSuccess) return be;
+            if ((uint64_t)failed * 100 > (uint64_t)probe_reads * PR_BAIL_PERCENT) {
+                hipLaunchKernelGGL(append_rest_kernel, dim3((n - first + 255) / 256), dim3(256), 0, stream, a.b.items, first, n, fail_list, fail_count);
+                hipLaunchKernelGGL(add_const_kernel, dim3(1), dim3(1), 0, stream, fail_count, n - first);
+                return hipGetLastError();
+            }
+        }
         a.first = first;
-        a.n = std::min<uint32_t>(chunk_reads, n - first);
+        a.n = std::min<uint32_t>(this_chunk, n - first);
         a.n_pairs = (a.n + 1) / 2;
         a.split = first >= n_cls ? 0u : std::min<uint32_t>(a.n, n_cls - first);  // entries of the chunk that belong to `cls`
         a.floor0 = floor_strip;

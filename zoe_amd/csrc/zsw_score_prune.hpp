@@ -18,6 +18,7 @@ constexpr int PR_M1 = 8;    // window rows kept above the anchor
 constexpr int PR_M2 = 16;   // and below the row where an alignment without deletions ends (+8 per 8 lanes of the class)
 constexpr uint32_t PR_MIN_READS = 96u << 10;   // smaller batches cannot fill the chip with one pair per lane: the full pass is faster
                                                // (150 bp vs 2 kb: 65,536 reads 2.7 ms pruned / 2.4 ms full; 100,000 reads 2.9 / 4.4 ms)
+constexpr uint32_t PR_BAIL_PERCENT = 70;       // handed back by the first chip-full of a large batch: above this the rest takes the full pass
 constexpr uint32_t PR_CHUNK_READS = 2u << 20;  // reads per round of the two kernels, at most
 constexpr size_t PR_WORK_BYTES = size_t(32) << 30;  // and as many as this much boundary stream holds (8 B per pair and reference row)
 
