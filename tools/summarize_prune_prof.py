@@ -4,12 +4,22 @@ import collections, csv, glob, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 n_reads = float(sys.argv[3]) if len(sys.argv) > 3 else 2e6
+protein = len(sys.argv) > 4 and sys.argv[4] == "protein"  # tools/profile_protein.sh: the WIDE kernels on a 25-letter alphabet
 want = ("prune_strip_kernel", "prune_window_kernel", "score_kernel_v2")
 out = [f"# {tag}: rocprofv3 on `python3 tools/try_prune.py {int(n_reads)} --score-only` ({int(n_reads)} synthetic 150 bp reads vs 2 kb, sw_score_from_i8 w256:",
        "# the full pass (score_kernel_v2<4,38,0>, 4 launches) and the column-pruned pass (strip + window + score_kernel_v2 on the rescore list, 4 rounds) in one process)",
        "# passes: --kernel-trace --stats | --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE | --pmc FETCH_SIZE | --pmc WRITE_SIZE"]
+if protein:
+    n_call = n_reads
+    out[:2] = [f"# {tag}: rocprofv3 on `python3 tools/bench_protein.py {int(n_reads)} 0.03` ({int(n_reads)} sequences of 150 residues, pieces of a 2,000-residue reference with 3 % of",
+               "# the residues substituted + 2 % unrelated sequences, 25-letter BLOSUM-shaped matrix, sw_score_from_i8 w256: the column-pruned pass",
+               "# (prune_strip_kernel<24,WIDE> + prune_window_kernel<24,4,32,0,WIDE> + score_kernel_v2<4,38,0,WIDE> on the rescore list, 4 calls of 3 rounds: the",
+               "# first chip-full is the bail-out probe) and the full pass (score_kernel_v2<4,38,0,WIDE>, 4 launches) in one process).",
+               "# A call of 1 M reads is TWO launches of the strip and window kernels (393,216 reads: the probe; 606,784: the rest), so the per-launch",
+               "# averages below cover 500,000 reads and the per-read figures are computed with that."]
+    n_call, n_reads = n_reads, n_reads / 2
 for f in glob.glob(f"{src}/bench_stats.txt"):
-    out += ["# " + l.strip() for l in open(f) if l.startswith("n=")]
+    out += ["# " + l.strip() for l in open(f) if l.startswith(("n=", "pruned", "full pass", "identical", "---"))]
 dur = {}
 for f in glob.glob(f"{src}/stats/*/*kernel_stats.csv"):
     out.append("## kernel durations (score_kernel_v2: 4 full launches and 4 launches over the rescore list, see the trace split below)")
