@@ -581,9 +581,13 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         hipError_t pe = hipMemsetAsync(ws.prune_fail_count, 0, 4, stream);
         if (pe != hipSuccess) return pe;
         ap.b = bb;
+        uint32_t est_failed = 0xffffffffu;
         pe = launch_score_pruned(ap, cls, n_cls, floor_strip, floor_window, h_sc, ws.prune_work, ws.prune_bytes, ws.prune_chunk,
-                                 ws.prune_fail_list, ws.prune_fail_count, mode, wide, stream);
+                                 ws.prune_fail_list, ws.prune_fail_count, mode, wide, stream, &est_failed);
         if (pe != hipSuccess) return pe;
+        // a short list of handed-back reads is latency-bound in the narrowest configuration (20,000 reads of 150 residues: 3.4 ms
+        // at four lanes per pair, every block walking all R rows): with the probe's estimate it takes the small-batch configuration
+        if (est_failed != 0xffffffffu) (void)score_config_for_batch(kPruneClasses[last].max_len, est_failed + est_failed / 4 + 1024, &Gr, &Cr);
         if (!tables(Gr, &a2)) return hipErrorInvalidValue;
         a2.b = bb;
         a2.b.items = ws.prune_fail_list;

@@ -660,8 +660,9 @@ hipError_t strip_blocks_per_cu(bool wide, int* per_cu) {
 // floor_window[2] are the drift floors for G = 1 and for the two classes' G.
 hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t n_cls, uint32_t floor_strip, const uint32_t* floor_window,
                                const ScoringDev& h_sc, uint8_t* work, size_t work_bytes, uint32_t chunk_reads, uint32_t* fail_list,
-                               uint32_t* fail_count, int mode, bool wide, hipStream_t stream) {
+                               uint32_t* fail_count, int mode, bool wide, hipStream_t stream, uint32_t* est_failed) {
     const uint32_t n = a2.b.n_items, R = a2.ref_len;
+    if (est_failed) *est_failed = 0xffffffffu;
     if (n == 0) return hipSuccess;
     if (cls < 0 || cls >= PR_N_CLASSES || chunk_reads < 2 || work_bytes < prune_workspace_bytes(chunk_reads, R)) return hipErrorNotSupported;
     if (n_cls < n && (cls + 1 >= PR_N_CLASSES || kPruneClasses[cls + 1].cp != kPruneClasses[cls].cp || R >= (1u << 24))) return hipErrorNotSupported;
@@ -738,7 +739,9 @@ hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t n_cls, u
             hipError_t be = hipMemcpyAsync(&failed, fail_count, sizeof(failed), hipMemcpyDeviceToHost, stream);
             if (be == hipSuccess) be = hipStreamSynchronize(stream);
             if (be != hipSuccess) return be;
+            if (est_failed) *est_failed = (uint32_t)std::min<uint64_t>((uint64_t)failed * n / probe_reads, n);
             if ((uint64_t)failed * 100 > (uint64_t)probe_reads * PR_BAIL_PERCENT) {
+                if (est_failed) *est_failed = n;
                 hipLaunchKernelGGL(append_rest_kernel, dim3((n - first + 255) / 256), dim3(256), 0, stream, a.b.items, first, n, fail_list, fail_count);
                 hipLaunchKernelGGL(add_const_kernel, dim3(1), dim3(1), 0, stream, fail_count, n - first);
                 return hipGetLastError();

@@ -31,6 +31,7 @@ bool prune_applicable(const ScoringDev& s, uint32_t max_len, uint32_t ref_len, u
 hipError_t launch_score_pruned(const ScoreArgsV2& a2, int cls, uint32_t n_cls, uint32_t floor_strip, const uint32_t* floor_window,
                                const ScoringDev& h_sc, uint8_t* work, size_t work_bytes, uint32_t chunk_reads, uint32_t* fail_list,
                                uint32_t* fail_count, int mode /* as launch_score */, bool wide /* a2 carries the WIDE table */,
-                               hipStream_t stream);
+                               hipStream_t stream, uint32_t* est_failed = nullptr /* out: the handed-back reads to expect, from the
+                               bail-out probe (0xffffffff: no probe ran) */);
 
 }  // namespace zsw
