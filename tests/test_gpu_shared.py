@@ -123,10 +123,25 @@ def test_layout_dependent_pairs_with_the_roles_swapped(za, oracle):
                     assert got.key(i) == okey(oracle.align("i16", N, sc, long_seq, other, other_is_query=is_query)), (N, is_query, i)
 
 
+@pytest.fixture
+def any_size(za):
+    """the seeded pass for batches of every size (by default batches under 1,024 reads skip it)"""
+    from zoe_amd import _lib
+
+    ctx = za.SwContext.get(0)
+    ctx.debug_set(_lib.DEBUG_SCORE_PRUNE_ANY_SIZE)
+    yield ctx
+    ctx.debug_set(0)
+
+
+@pytest.mark.parametrize("seeded", [False, True])
 @pytest.mark.parametrize("scheme", [(4, -2, -3, -1), (2, -5, -10, -1), (3, -1, 0, 0), (1, -1, -1, -1), (5, -4, -2, 0)])
-def test_random_pairs_ragged_reads_ties_and_low_complexity(za, oracle, scheme):
+def test_random_pairs_ragged_reads_ties_and_low_complexity(za, oracle, scheme, seeded, request):
     """Ragged batches, reads with N and lower case, low-complexity reads against a low-complexity sequence (ties in every row):
-    ends, ranges and CIGARs at <i16, 4 / 16>."""
+    ends, ranges and CIGARs at <i16, 4 / 16>. `seeded`: the same batch through the role-swapped seeded pass (mode 3: a read whose
+    maximum sits in one cell keeps that pass's ends, every other read is recomputed under the shared role's own tie rule)."""
+    if seeded:
+        request.getfixturevalue("any_size")
     ma, mi, go, ge = scheme
     rng = np.random.default_rng(stable_seed("shared", scheme))
     m = za.WeightMatrix.new_dna_matrix(ma, mi, b"N")
@@ -169,6 +184,97 @@ def test_random_pairs_ragged_reads_ties_and_low_complexity(za, oracle, scheme):
             if st == S_:
                 assert (int(r.score[i]), (int(r.ref_start[i]), int(r.ref_end[i])), (int(r.query_start[i]), int(r.query_end[i]))) == (sv, rr, qr), (N, i)
             assert a.key(i) == okey(oracle.align("i16", N, sc, seq, rd, other_is_query=True)), (N, i)
+
+
+def _tie_rich_reads(rng, seq, n, L):
+    """reads of L bases built to hold their maximum in several cells, or in one cell the two tie rules would not both pick first:
+    pieces inside tandem repeats (equal scores on neighbouring diagonals), two pieces of equal length from different places in
+    either order (first row of the sequence vs first row of the read), a piece followed by two mismatches and five matches (the
+    peak is reached twice on one diagonal), plus ordinary reads with a few edits"""
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    sa = np.frombuffer(seq, dtype=np.uint8)
+    R = len(seq)
+    out = np.empty((n, L), dtype=np.uint8)
+    for i in range(n):
+        kind = i % 6
+        p = int(rng.integers(0, R - L))
+        r = sa[p:p + L].copy()
+        if kind == 1:  # two halves from different places
+            q = int(rng.integers(0, R - L))
+            h = L // 2
+            r = np.concatenate([sa[p:p + h], sa[q:q + L - h]])
+        elif kind == 2:  # peak reached twice on the diagonal
+            for k in (L - 7, L - 6):
+                r[k] = alpha[(int(np.where(alpha == r[k])[0][0]) + 1) % 4]
+        elif kind == 3:  # a few edits
+            for _ in range(int(rng.integers(1, 5))):
+                r[int(rng.integers(0, L))] = rng.choice(alpha)
+        elif kind == 4:  # junk start, then a piece
+            j = int(rng.integers(5, L // 2))
+            r[:j] = rng.choice(alpha, j)
+        elif kind == 5:
+            r = rng.choice(alpha[:2], L)
+        out[i] = r
+    return out
+
+
+@pytest.mark.parametrize("T,N", [("i16", 16), ("i8", 32)])
+def test_ends_through_the_seeded_pass_on_tie_rich_reads(za, oracle, T, N):
+    """2,400 reads of 150 bases (the default path: batches of 1,024 reads or more take the role-swapped seeded pass) against a
+    sequence with tandem repeats and a duplicated stretch: ends, ranges of every read, every eighth CIGAR, against the oracle with
+    the same roles"""
+    import torch
+
+    rng = np.random.default_rng(stable_seed("tie-rich", T, N))
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    parts = [bytes(rng.choice(alpha, 400)), b"ACG" * 30, bytes(rng.choice(alpha, 300)), b"TTGACA" * 20, bytes(rng.choice(alpha, 500)), b"AC" * 50]
+    dup = bytes(rng.choice(alpha, 200))
+    seq = b"".join(parts) + dup + bytes(rng.choice(alpha, 150)) + dup + bytes(rng.choice(alpha, 100))
+    reads2d = _tie_rich_reads(rng, seq, 2400, 150)
+    reads = [bytes(r) for r in reads2d]
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    sc = osc(oracle, dna, -10, -1)
+    rb = za.ReadBatch.from_fixed(torch.from_numpy(reads2d.reshape(-1)).cuda(), 150)
+    prof = za.SharedStripedProfile(seq, dna, -10, -1, T, N)
+    e = prof.sw_score_ends(za.SeqBatchSrc.Reference(rb))
+    r = prof.sw_score_ranges(za.SeqBatchSrc.Query(rb))
+    a = prof.sw_align(za.SeqBatchSrc.Query(rb))
+    for i, rd in enumerate(reads):
+        st, (sv, re_, qe) = oracle.score_ends(T, N, sc, seq, rd)
+        assert int(e.status[i]) == st, i
+        if st == S_:
+            assert (int(e.score[i]), int(e.ref_end[i]), int(e.query_end[i])) == (sv, re_, qe), i
+        st, sv, rr, qr = oracle.score_ranges(T, N, sc, seq, rd)
+        assert int(r.status[i]) == st, i
+        if st == S_:  # SeqSrc::Query: the ranges change names
+            assert (int(r.score[i]), (int(r.ref_start[i]), int(r.ref_end[i])), (int(r.query_start[i]), int(r.query_end[i]))) == (sv, qr, rr), i
+        if i % 8 == 0:
+            assert a.key(i) == okey(oracle.align(T, N, sc, seq, rd, other_is_query=True)), i
+
+
+def test_seeded_and_plain_shared_ends_agree_on_a_large_batch(za):
+    """300,000 synthetic reads + tie-rich ones: the default path (role-swapped seeded pass + the exact kernel on what it cannot
+    settle) against the exact shared-role kernel over every read (ZSW_OPTION_EXACT_PRUNING off)"""
+    import torch
+
+    from zoe_amd import _lib, synth
+
+    ctx = za.SwContext.get(0)
+    ref = synth.reference_host(2000)
+    host = synth.reads_host(ref, 5, 300_000, 150)
+    rng = np.random.default_rng(77)
+    host[::50] = _tie_rich_reads(rng, bytes(ref), len(host[::50]), 150)
+    rb = za.ReadBatch.from_fixed(torch.from_numpy(host.reshape(-1)).cuda(), 150)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    prof = za.SharedStripedProfile(ref, dna, -10, -1, "i16", 16)
+    got = prof.sw_score_ends(za.SeqBatchSrc.Reference(rb))
+    ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
+    try:
+        want = prof.sw_score_ends(za.SeqBatchSrc.Reference(rb))
+    finally:
+        ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
+    for name in ("score", "status", "ref_end", "query_end"):
+        assert torch.equal(getattr(got, name), getattr(want, name)), name
 
 
 def test_long_profile_sequence_takes_several_tiles_and_rows_in_hbm(za, oracle):

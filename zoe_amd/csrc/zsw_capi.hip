@@ -144,17 +144,31 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     ctx->seed_ready = false;
     const uint32_t flags = ctx->flags();
     const bool any_size = (flags & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE) != 0;
-    if (!ctx->shared_call && (flags & ZSW_DEBUG_SCORE_PRUNE) && !(flags & ZSW_DEBUG_PRUNE_STRIP) && n > 0 && (n >= SEED_MIN_READS || any_size) && ctx->ref_len > 0 &&
+    // a shared-role call (zsw_capi_shared.hip) scores the reads against the profile sequence with the roles swapped and the matrix
+    // transposed: its index is seed_shared, over h_pseq
+    const bool shared = ctx->shared_call;
+    const size_t seq_len = shared ? ctx->pseq_len : ctx->ref_len;
+    if ((!shared || ctx->shared_seedable) && (flags & ZSW_DEBUG_SCORE_PRUNE) && !(flags & ZSW_DEBUG_PRUNE_STRIP) && n > 0 && (n >= SEED_MIN_READS || any_size) && seq_len > 0 &&
         st->max_len >= SEED_MIN_LEN) {
         // the seeded exact pass: index of the reference (first use after a change of reference or matrix), 28 bytes + 4 bits per base
         // of workspace per read, the banded kernel's strip-boundary buffers and the worklist of the reads it hands back. If the device cannot spare them the full pass runs.
-        if (!ctx->seed.valid) ZSW_HIP(ctx, seed_index_update(&ctx->seed, ctx->h_sc, ctx->h_ref.data(), ctx->ref_len));
-        if (ctx->seed.usable) {
+        SeedIndex& index = shared ? ctx->seed_shared : ctx->seed;
+        if (!index.valid) {
+            if (shared) {
+                ScoringDev t = ctx->h_sc;
+                for (int r = 0; r < t.S; ++r)
+                    for (int q = 0; q < t.S; ++q) t.w[r * t.S + q] = ctx->h_sc.w[q * t.S + r];
+                ZSW_HIP(ctx, seed_index_update(&index, t, ctx->h_pseq.data(), seq_len));
+            } else {
+                ZSW_HIP(ctx, seed_index_update(&index, ctx->h_sc, ctx->h_ref.data(), seq_len));
+            }
+        }
+        if (index.usable) {
             // ragged batches: a region per length class (the banded pass's buffers are sized per region, by the reads in it)
             // (ragged: the classes' sort temporaries and round-ups, and SEED_BAND_CLASS_MIN_GRID blocks of boundary buffer each)
             const size_t want = seed_workspace_bytes(n, st->max_len) + 24 * seed_workspace_bytes(0, st->max_len) +
                                 (reads->offsets ? 24 * seed_workspace_bytes(std::min<uint32_t>(n, 2 * SEED_BAND_CLASS_MIN_GRID * 256), st->max_len, SEED_BAND_CLASS_MIN_GRID) : 0);
-            if (ctx->d_seed_work.ensure(want) == hipSuccess && ctx->d_seed_gtab.ensure((ctx->ref_len + 2 * SEED_GTAB_PAD) * 8) == hipSuccess &&
+            if (ctx->d_seed_work.ensure(want) == hipSuccess && ctx->d_seed_gtab.ensure((seq_len + 2 * SEED_GTAB_PAD) * 8) == hipSuccess &&
                 ctx->d_prune_list.ensure((size_t)n * 4 + 4) == hipSuccess &&
                 ctx->d_prune_count.ensure(64 * 4) == hipSuccess) {
                 ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 64 * 4, stream));  // [1] the call's total, [0], [2..] lists in flight
@@ -211,7 +225,7 @@ ScoreWorkspace score_ws(zsw_context* ctx) {
     w.side = ctx->side;
     w.debug = ctx->flags();
     if (ctx->seed_ready) {
-        w.seed = &ctx->seed;
+        w.seed = ctx->shared_call ? &ctx->seed_shared : &ctx->seed;
         w.seed_work = ctx->d_seed_work.as<uint8_t>();
         w.seed_bytes = ctx->d_seed_work.cap;
         w.seed_gtab = ctx->d_seed_gtab.as<uint2>();
@@ -891,6 +905,7 @@ void zsw_destroy(zsw_context* ctx) {
     for (DevBuf& b : ctx->r_ws) b.release();
     for (DevBuf& b : ctx->sh_ws) b.release();
     seed_index_release(&ctx->seed);
+    seed_index_release(&ctx->seed_shared);
     ctx->timer.destroy();
     ctx->timer_window.destroy();
     if (ctx->side) {
@@ -946,6 +961,7 @@ zsw_error zsw_set_scoring(zsw_context* ctx, const int8_t* weights, int S, const 
     }
     ctx->scoring_set = true;
     ctx->seed.valid = false;  // the index spells k-mers with the matrix's good residues
+    ctx->seed_shared.valid = false;
     return ZSW_OK;
 }
 

@@ -14,7 +14,7 @@ using namespace zsw::capi;
 
 namespace {
 
-enum { SH_SCORE = 0, SH_STATUS, SH_TIER, SH_REND, SH_QEND, SH_QEM, SH_RSCORE, SH_RSTATUS, SH_RRS, SH_RQS, SH_MIS, SH_LIST };
+enum { SH_SCORE = 0, SH_STATUS, SH_TIER, SH_REND, SH_QEND, SH_QEM, SH_RSCORE, SH_RSTATUS, SH_RRS, SH_RQS, SH_MIS, SH_LIST, SH_UNIQUE, SH_ULIST, SH_UCOUNT };
 
 __global__ void empty_is_unmapped_kernel(uint32_t n, uint8_t* status) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -35,6 +35,20 @@ __global__ void iota_some_kernel(uint32_t n, const uint8_t* status, const uint8_
     }
 }
 
+// reads whose ends the role-swapped seeded pass could not settle (unique[i] == 0): the list of the exact shared-role kernel
+__global__ void select_not_unique_kernel(uint32_t n, const uint8_t* unique, uint32_t* list, uint32_t* count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool take = i < n && unique[i] == 0;
+    const unsigned long long m = __ballot(take);
+    if (m) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (take) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    }
+}
+
 zsw_error check_shared(zsw_context* ctx) {
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     if (!ctx->scoring_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "scoring not set");
@@ -42,29 +56,64 @@ zsw_error check_shared(zsw_context* ctx) {
     return ZSW_OK;
 }
 
-// stage() wants a reference: the shared calls have none of their own, the profile sequence stands in (its length sizes nothing
-// that matters here) — and the seeded pass must stay off: its index describes the reference.
+// stage() wants a reference: the shared calls have none of their own, the profile sequence stands in. `seedable`: the call's
+// kernels can take the seeded pass (with the index of the profile sequence under the transposed matrix, ctx->seed_shared).
 struct SharedStage {
     zsw_context* ctx;
     bool ref_was_set;
     size_t ref_len;
-    explicit SharedStage(zsw_context* c) : ctx(c), ref_was_set(c->reference_set), ref_len(c->ref_len) {
+    explicit SharedStage(zsw_context* c, bool seedable = false) : ctx(c), ref_was_set(c->reference_set), ref_len(c->ref_len) {
         ctx->shared_call = true;
+        ctx->shared_seedable = seedable;
         ctx->reference_set = true;
-        if (!ref_was_set) ctx->ref_len = ctx->pseq_len;
+        ctx->ref_len = ctx->pseq_len;
     }
     ~SharedStage() {
         ctx->shared_call = false;
+        ctx->shared_seedable = false;
         ctx->reference_set = ref_was_set;
         ctx->ref_len = ref_len;
     }
 };
 
-// score + ends of every read against the shared profile, on the device
+// score + ends of every read against the shared profile, on the device.
+// With the seeded pass staged (SharedStage(ctx, true) + stage()): the roles are swapped — the read is the profile of the ordinary
+// kernels, the shared sequence their reference, the matrix transposed — and the banded seeded pass runs at mode 3: score, both
+// ends under ITS tie rule (first row of the sequence, then first column of the read) and whether the maximum sits in exactly one
+// cell of the matrix. For such a read the tie rule does not matter and the ends are the shared role's with the names swapped
+// (ref_end = row of the read, query_end = column of the profile sequence). Every other read — handed back by the seeded pass,
+// ties, no alignment — is computed by shared_ends_kernel, which walks all cells under the shared role's own rule.
 zsw_error shared_ends_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, const ScoreOut& out, hipStream_t stream) {
     if (st.max_len > shared_max_rows()) return fail(ctx, ZSW_ERR_UNSUPPORTED, "read too long for the shared-profile kernels");
-    hipError_t e = launch_shared_ends(st.b, std::max<uint32_t>(st.max_len, 1), ctx->d_pseq.as<uint8_t>(), (uint32_t)ctx->pseq_len,
-                                      ctx->d_sc.as<ScoringDev>(), rule, out, nullptr, nullptr, stream);
+    const uint32_t n = st.b.n_items;
+    BatchDev rest = st.b;
+    const uint32_t* rest_count = nullptr;
+    if (ctx->seed_ready && n > 0 && !st.b.items) {
+        DevBuf* ws = ctx->sh_ws;
+        ZSW_HIP(ctx, ws[SH_UNIQUE].ensure((size_t)n + 4));
+        ZSW_HIP(ctx, ws[SH_ULIST].ensure((size_t)n * 4 + 4));
+        ZSW_HIP(ctx, ws[SH_UCOUNT].ensure(16));
+        ZSW_HIP(ctx, hipMemsetAsync(ws[SH_UNIQUE].p, 0, n, stream));
+        ZSW_HIP(ctx, hipMemsetAsync(ws[SH_UCOUNT].p, 0, 4, stream));
+        ScoringDev h_t = ctx->h_sc;
+        for (int r = 0; r < h_t.S; ++r)
+            for (int q = 0; q < h_t.S; ++q) h_t.w[r * h_t.S + q] = ctx->h_sc.w[q * h_t.S + r];
+        ScoreOut o2 = out;
+        o2.ref_end = out.query_end;   // rows of the swapped problem are positions of the profile sequence
+        o2.query_end = out.ref_end;   // its columns positions of the read
+        o2.fb_list = ctx->d_fb_list.as<uint32_t>();
+        o2.fb_count = ctx->d_fb_count.as<uint32_t>();
+        o2.unique = ws[SH_UNIQUE].as<uint8_t>();
+        hipError_t e = launch_score(ctx->d_sc_t.as<ScoringDev>(), h_t, st.b, st.max_len, ctx->d_pseq.as<uint8_t>(), (uint32_t)ctx->pseq_len, rule, o2,
+                                    score_ws(ctx), stream, nullptr, 3);
+        if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "shared ends: role-swapped seeded pass", e);
+        hipLaunchKernelGGL(select_not_unique_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, ws[SH_UNIQUE].as<uint8_t>(),
+                           ws[SH_ULIST].as<uint32_t>(), ws[SH_UCOUNT].as<uint32_t>());
+        rest.items = ws[SH_ULIST].as<uint32_t>();
+        rest_count = ws[SH_UCOUNT].as<uint32_t>();
+    }
+    hipError_t e = launch_shared_ends(rest, std::max<uint32_t>(st.max_len, 1), ctx->d_pseq.as<uint8_t>(), (uint32_t)ctx->pseq_len,
+                                      ctx->d_sc.as<ScoringDev>(), rule, out, nullptr, nullptr, stream, rest_count);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "shared ends kernel", e);
     return ZSW_OK;
 }
@@ -75,7 +124,7 @@ zsw_error run_score_shared(zsw_context* ctx, const zsw_batch* reads, const Resul
     if (ze != ZSW_OK) return ze;
     DeviceGuard device_guard(ctx);
     hipStream_t stream = (hipStream_t)stream_;
-    SharedStage guard(ctx);
+    SharedStage guard(ctx, true);  // the score does not depend on the roles: the seeded pass applies with the sequence as its reference
     Staged st;
     ze = stage(ctx, reads, stream, out_tier != nullptr, false, out_score, out_status, out_tier, nullptr, nullptr, &st);
     if (ze != ZSW_OK) return ze;
@@ -107,7 +156,7 @@ zsw_error run_ends_shared(zsw_context* ctx, const zsw_batch* reads, const Result
     if (!out_rend || !out_qend) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard device_guard(ctx);
     hipStream_t stream = (hipStream_t)stream_;
-    SharedStage guard(ctx);
+    SharedStage guard(ctx, true);
     Staged st;
     ze = stage(ctx, reads, stream, false, true, out_score, out_status, nullptr, out_rend, out_qend, &st);
     if (ze != ZSW_OK) return ze;
@@ -134,7 +183,7 @@ zsw_error run_ranges_shared(zsw_context* ctx, const zsw_batch* reads, const Resu
     if (!reads || !out_score || !out_rs || !out_re || !out_qs || !out_qe || !out_status) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard device_guard(ctx);
     hipStream_t stream = (hipStream_t)stream_;
-    SharedStage guard(ctx);
+    SharedStage guard(ctx, true);
     Staged st;
     {
         uint32_t dummy_score = 0;
@@ -199,7 +248,7 @@ zsw_error run_align_shared(zsw_context* ctx, const zsw_batch* reads, const Resul
         return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard device_guard(ctx);
     hipStream_t stream = (hipStream_t)stream_;
-    SharedStage guard(ctx);
+    SharedStage guard(ctx, true);
     Staged st;
     {
         uint32_t dummy_score = 0;
@@ -324,6 +373,10 @@ zsw_error zsw_set_profile_sequence(zsw_context* ctx, const uint8_t* sequence, si
     if (ctx->pseq_set) ZSW_HIP(ctx, hipDeviceSynchronize());  // queued kernels may still read the previous sequence
     ZSW_HIP(ctx, ctx->d_pseq.ensure(len + 16));
     ZSW_HIP(ctx, hipMemcpy(ctx->d_pseq.p, sequence, len, mem == ZSW_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
+    ctx->h_pseq.resize(len);  // the seeded pass of the score calls builds its k-mer index from a host copy
+    if (mem == ZSW_MEM_HOST) memcpy(ctx->h_pseq.data(), sequence, len);
+    else ZSW_HIP(ctx, hipMemcpy(ctx->h_pseq.data(), sequence, len, hipMemcpyDeviceToHost));
+    ctx->seed_shared.valid = false;
     ctx->pseq_len = len;
     ctx->pseq_set = true;
     return ZSW_OK;

@@ -77,11 +77,15 @@ struct zsw_context {
     zsw::SideStreams* side = nullptr;
     // the one-profile-many-sequences role (zsw_capi_shared.hip): the sequence the shared profile is built from, the scoring with
     // the matrix transposed (score-only calls go through the ordinary kernels with the roles swapped), workspace
-    zsw::DevBuf d_pseq, d_sc_t, sh_ws[12];
+    zsw::DevBuf d_pseq, d_sc_t, sh_ws[16];
     std::vector<uint8_t> h_pseq;
     size_t pseq_len = 0;
     bool pseq_set = false;
-    bool shared_call = false;  // stage(): this call must not take the seeded pass (its index describes the reference, not d_pseq)
+    bool shared_call = false;  // stage(): the call scores against d_pseq with the transposed matrix: its seeded pass uses seed_shared
+    // index of the profile sequence under the transposed matrix: the seeded pass of the shared role's score calls (roles swapped:
+    // the sequence is the ordinary kernels' reference); rebuilt after zsw_set_scoring / zsw_set_profile_sequence
+    zsw::SeedIndex seed_shared;
+    bool shared_seedable = false;  // set by the shared entry points whose kernels can take the seeded pass (score; ends with MODE 3)
 };
 
 namespace zsw {

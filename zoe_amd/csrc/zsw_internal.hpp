@@ -67,6 +67,9 @@ struct ScoreOut {
     // optional (alignment's first pass): per read, the row from which the second pass may start with a zero state
     // (seed_safe_start, zsw_seed.hpp); the caller presets 0xffffffff = no certificate, the seeded window kernel fills the rest
     uint32_t* safe_row = nullptr;
+    // optional (mode 3, the banded seeded pass only): 1 where the read's maximum sits in exactly one cell of its matrix — the ends
+    // then do not depend on the tie rule (zsw_capi_shared.hip). The caller presets 0; kernels that do not know leave it
+    uint8_t* unique = nullptr;
 };
 
 struct KernelTimer;

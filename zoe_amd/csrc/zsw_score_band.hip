@@ -1,5 +1,7 @@
 // zsw_score_band.hip — the banded form of the seeded exact pass (sw_simd_score / sw_simd_score_ends, striped.rs:65-142, 153-336:
-// MODE 0 score only, 1 with the reference end, 2 with both ends). seed_window_kernel computes every query column for all
+// MODE 0 score only, 1 with the reference end, 2 with both ends, 3 = 2 + whether the maximum sits in exactly one cell: then the
+// tie rule does not matter and the shared-profile role, whose rule runs over the other sequence first, can use the result —
+// zsw_capi_shared.hip). seed_window_kernel computes every query column for all
 // ~len + 60 rows around the anchor; the alignment itself occupies a band of a few diagonals. Here a lane owns one read pair
 // (16-bit halves, as everywhere) and walks it strip by strip: strip k = query columns [kC, (k+1)C) in registers (score_kernel_v2's
 // packed column loop) against the reference rows [dt + kC - Wu, dt + (k+1)C + Wd) only, the strip's last column (H, outgoing F,
@@ -26,7 +28,8 @@ __device__ __forceinline__ uint32_t pk_subu_sat(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
 }
 
-constexpr int BC = 32;  // columns per strip (a multiple of 8: a strip's residue codes are whole dwords of the packed reads)
+constexpr int BC = 32;  // columns per strip (a multiple of 8: a strip's residue codes are whole dwords of the packed reads; MODE 3 keeps
+                        // one bit per column in a 32-bit mask)
 
 template <int C, int MINW, int MODE>
 __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) {
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
         // rows in order; strips overlap in rows, so each strip keeps its own (maximum, first row, H row of that row) and the strips
         // merge by (higher maximum, then earlier row; the same row in two strips: the earlier strip holds the earlier column).
         int bestA = 0, bestB = 0, rowA = 0x7fffffff, rowB = 0x7fffffff, colA = 0x7fffffff, colB = 0x7fffffff;
+        bool multA = false, multB = false;  // MODE 3: the maximum so far sits in more than one (real) cell
         int bndA = -1, bndB = -1;   // the exit bounds so far
         int prev_bot = 0;
 #pragma unroll 1
@@ -152,11 +156,17 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
             uint32_t uk = 0, ug = 0;
             uint32_t sbest = 0, snapD = 0;  // this strip's maximum (true scores) and, MODE 2, the H row and drift of each read's latest rise
             int srA = 0x7fffffff, srB = 0x7fffffff;
-            uint32_t snap[MODE == 2 ? C : 1];
-            if (MODE == 2) {
+            uint32_t snap[MODE >= 2 ? C : 1];
+            if (MODE >= 2) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) snap[MODE == 2 ? c : 0] = 0;
+                for (int c = 0; c < C; ++c) snap[MODE >= 2 ? c : 0] = 0;
             }
+            // MODE 3: the strip's real columns per read as bit masks (a padding column copies the value of its upper left
+            // neighbour: a copy of the maximum is not a second cell holding it), and whether a row after the strip's latest rise
+            // reached the same value again in a real column
+            const int nrA = max(0, min(C, (int)lenA - k * C)), nrB = max(0, min(C, (int)lenB - k * C));
+            const uint32_t realA = nrA >= 32 ? 0xffffffffu : ((1u << nrA) - 1u), realB = nrB >= 32 ? 0xffffffffu : ((1u << nrB) - 1u);
+            bool smA = false, smB = false;
             const int e_top = (dtmin + (k + 1) * C - wu) - 1 - top;  // the first row's distance from the last row above the next strip
             uint32_t dec = min(ge1 * (uint32_t)max(e_top - 1, 0), 0xffffu) * 0x00010001u;
 #pragma unroll 1
@@ -201,11 +211,30 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                     const uint32_t ch = nsb ^ sbest;
                     if (ch & 0xffffu) srA = r;
                     if (ch >> 16) srB = r;
-                    if (MODE == 2) {
+                    if (MODE >= 2) {
                         const uint32_t m = ((ch & 0xffffu) ? 0xffffu : 0u) | ((ch >> 16) ? 0xffff0000u : 0u);
 #pragma unroll
-                        for (int c = 0; c < C; ++c) snap[MODE == 2 ? c : 0] = (H[c] & m) | (snap[MODE == 2 ? c : 0] & ~m);
+                        for (int c = 0; c < C; ++c) snap[MODE >= 2 ? c : 0] = (H[c] & m) | (snap[MODE >= 2 ? c : 0] & ~m);
                         snapD = (Dr & m) | (snapD & ~m);
+                    }
+                    if (MODE == 3) {
+                        const uint32_t eq = tmax ^ nsb;  // a half is 0 where this row's maximum is the strip's
+                        const bool tA = !(ch & 0xffffu) && !(eq & 0xffffu) && (nsb & 0xffffu) != 0;
+                        const bool tB = !(ch >> 16) && !(eq >> 16) && (nsb >> 16) != 0;
+                        if (ch & 0xffffu) smA = false;
+                        if (ch >> 16) smB = false;
+                        if (tA || tB) {  // rare: which columns hold it
+                            const uint32_t target = pk_addu(nsb, Dr);
+                            uint32_t hitA = 0, hitB = 0;
+#pragma unroll
+                            for (int c = 0; c < C; ++c) {
+                                const uint32_t x = H[c] ^ target;
+                                if (!(x & 0xffffu)) hitA |= 1u << c;
+                                if (!(x >> 16)) hitB |= 1u << c;
+                            }
+                            if (tA && (hitA & realA)) smA = true;
+                            if (tB && (hitB & realB)) smB = true;
+                        }
                     }
                     sbest = nsb;
                 }
@@ -239,8 +268,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
             }
             if (MODE != 0) {  // merge the strip's maximum into the read's
                 const int sA = (int)(sbest & 0xffffu), sB = (int)(sbest >> 16);
-                const bool upA = sA > bestA || (sA == bestA && sA > 0 && srA < rowA);
-                const bool upB = sB > bestB || (sB == bestB && sB > 0 && srB < rowB);
+                const bool eqA = sA == bestA && sA > 0, eqB = sB == bestB && sB > 0;  // MODE 3: another strip held this value already
+                const bool upA = sA > bestA || (eqA && srA < rowA);
+                const bool upB = sB > bestB || (eqB && srB < rowB);
                 if (upA) {
                     bestA = sA;
                     rowA = srA;
@@ -249,17 +279,32 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                     bestB = sB;
                     rowB = srB;
                 }
-                if (MODE == 2 && (upA || upB)) {
+                if (MODE >= 2 && (upA || upB || (MODE == 3 && (eqA || eqB)))) {
                     int cA = 0x7fffffff, cB = 0x7fffffff;
+                    uint32_t hitA = 0, hitB = 0;
                     const int sdA = (int)(snapD & 0xffffu), sdB = (int)(snapD >> 16);
 #pragma unroll
                     for (int c = C - 1; c >= 0; --c) {
-                        const uint32_t sv = snap[MODE == 2 ? c : 0];
-                        if ((int)(sv & 0xffffu) - sdA == sA) cA = k * C + c;
-                        if ((int)(sv >> 16) - sdB == sB) cB = k * C + c;
+                        const uint32_t sv = snap[MODE >= 2 ? c : 0];
+                        if ((int)(sv & 0xffffu) - sdA == sA) {
+                            cA = k * C + c;
+                            hitA |= 1u << c;
+                        }
+                        if ((int)(sv >> 16) - sdB == sB) {
+                            cB = k * C + c;
+                            hitB |= 1u << c;
+                        }
                     }
                     if (upA) colA = cA;
                     if (upB) colB = cB;
+                    if (MODE == 3) {
+                        // cells of this strip holding its maximum: the real columns of the row of its latest rise, plus later rows
+                        const int nA = __popc(hitA & realA) + (smA ? 1 : 0), nB = __popc(hitB & realB) + (smB ? 1 : 0);
+                        if (sA > 0 && (upA && !eqA)) multA = nA > 1;   // a higher maximum: this strip's cells are all there are so far
+                        else if (eqA && nA > 0) multA = true;          // the same value in two strips: two cells
+                        if (sB > 0 && (upB && !eqB)) multB = nB > 1;
+                        else if (eqB && nB > 0) multB = true;
+                    }
                 }
             }
             prev_bot = bot;
@@ -294,7 +339,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                 if (a.out.tier) a.out.tier[id] = tier;
                 const bool some = status == ZSW_STATUS_SOME;
                 if (MODE != 0 && a.out.ref_end) a.out.ref_end[id] = some ? (uint32_t)(h ? rowB : rowA) + 1 : 0;
-                if (MODE == 2 && a.out.query_end) a.out.query_end[id] = some ? (uint32_t)(h ? colB : colA) + 1 : 0;
+                if (MODE >= 2 && a.out.query_end) a.out.query_end[id] = some ? (uint32_t)(h ? colB : colA) + 1 : 0;
+                if (MODE == 3 && a.out.unique) a.out.unique[id] = (some && !(h ? multB : multA)) ? 1 : 0;
                 if (MODE != 0 && a.out.safe_row)  // sw_simd_align's second pass may start this late (or 0xffffffff: no certificate)
                     a.out.safe_row[id] = (uint32_t)seed_safe_start(a.sp, h ? tallB : tallA, h ? dfaB : dfaA, h ? dtB : dtA, S);
             }
@@ -325,7 +371,8 @@ hipError_t launch_seed_band(const SeedBandArgs& a, int mode, hipStream_t stream)
     // MODE 2 keeps a snapshot of the H row (32 more registers): two waves per SIMD
     if (mode == 0) hipLaunchKernelGGL((seed_band_kernel<BC, 3, 0>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
     else if (mode == 1) hipLaunchKernelGGL((seed_band_kernel<BC, 3, 1>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL((seed_band_kernel<BC, 2, 2>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+    else if (mode == 2) hipLaunchKernelGGL((seed_band_kernel<BC, 2, 2>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((seed_band_kernel<BC, 2, 3>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -36,6 +36,7 @@ struct SharedArgs {
     uint32_t max_rows;   // longest read of the batch (LDS: residues + boundary of every row)
     const uint32_t* rev_ref_end;    // REV: forward ends (rows of the read / columns of the profile sequence used)
     const uint32_t* rev_query_end;
+    const uint32_t* n_items_dev;    // non-null: the number of items is on the device (a list filled by an earlier kernel of the stream)
 };
 
 template <bool REV>
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(64) void shared_ends_kernel(SharedArgs a) {
     __syncthreads();
     const int go = a.sc->gap_open, ge = a.sc->gap_extend;
 
-    for (uint32_t item = blockIdx.x; item < a.b.n_items; item += gridDim.x) {
+    const uint32_t n_items = a.n_items_dev ? min(*a.n_items_dev, a.b.n_items) : a.b.n_items;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint32_t id = a.b.items ? a.b.items[item] : item;
         uint64_t off = 0;
         uint32_t rows = read_len(a.b, id, &off);
@@ -181,7 +183,7 @@ size_t shared_ends_lds(uint32_t max_rows) { return (size_t)max_rows * 9 + 64; }
 
 hipError_t launch_shared_ends(const BatchDev& b, uint32_t max_rows, const uint8_t* d_pseq, uint32_t plen, const ScoringDev* d_sc,
                               const ResultRule& rule, const ScoreOut& out, const uint32_t* rev_ref_end, const uint32_t* rev_query_end,
-                              hipStream_t stream) {
+                              hipStream_t stream, const uint32_t* n_items_dev) {
     if (b.n_items == 0) return hipSuccess;
     SharedArgs a;
     a.b = b;
@@ -193,9 +195,11 @@ hipError_t launch_shared_ends(const BatchDev& b, uint32_t max_rows, const uint8_
     a.max_rows = (max_rows + 3) & ~3u;
     a.rev_ref_end = rev_ref_end;
     a.rev_query_end = rev_query_end;
+    a.n_items_dev = n_items_dev;
     const size_t lds = shared_ends_lds(a.max_rows);
     if (lds > SHARED_MAX_LDS) return hipErrorNotSupported;
-    const uint32_t grid = std::min<uint32_t>(b.n_items, 1u << 20);
+    // a device-side count: a grid that fills the chip strides over however many items there are
+    const uint32_t grid = std::min<uint32_t>(b.n_items, n_items_dev ? 16384u : 1u << 20);
     if (rev_ref_end) hipLaunchKernelGGL(shared_ends_kernel<true>, dim3(grid), dim3(64), lds, stream, a);
     else hipLaunchKernelGGL(shared_ends_kernel<false>, dim3(grid), dim3(64), lds, stream, a);
     return hipGetLastError();

@@ -12,7 +12,7 @@ inline uint32_t shared_max_rows() { return (uint32_t)((SHARED_MAX_LDS - 64) / 9)
 // sw_simd_score_ranges, out.ref_end / out.query_end = the inclusive starts.
 hipError_t launch_shared_ends(const BatchDev& b, uint32_t max_rows, const uint8_t* d_pseq, uint32_t plen, const ScoringDev* d_sc,
                               const ResultRule& rule, const ScoreOut& out, const uint32_t* rev_ref_end, const uint32_t* rev_query_end,
-                              hipStream_t stream);
+                              hipStream_t stream, const uint32_t* n_items_dev = nullptr /* the number of b.items, on the device */);
 
 // Pass 2 of sw_simd_align with the shared profile: <N lanes, nv = ceil(plen / N) vectors> striping over d_pseq, rows = the bases
 // of read i, every row's flags kept (W = the longest read). d_score / d_ref_end / d_status: the shared ends pass.
