@@ -180,7 +180,11 @@ zsw_error zsw_align_3pass_batch_from(zsw_context* ctx, const zsw_batch* reads, i
  *
  * zsw_set_profile_sequence: StripedProfile::new's sequence argument; len == 0 -> ZSW_ERR_EMPTY_SEQUENCE (profile.rs:32-44).
  * An empty READ is an empty `reference` argument here: status ZSW_STATUS_UNMAPPED (striped.rs:219-221).
- * Reads of up to 6,800 bases; the alignment calls keep plen x (longest read) flag bytes per read in flight. */
+ * Reads of up to 6,800 bases; the alignment calls keep plen x (longest read) flag bytes per read in flight.
+ * With ZSW_OPTION_EXACT_PRUNING (the default) the score calls, and the first pass of the ends / ranges / alignment calls, take the
+ * seeded exact pass with the roles swapped (an index of the profile sequence under the transposed matrix, built with the first
+ * such call): a read whose maximum sits in exactly one cell of its matrix has the same ends under either tie rule; every other
+ * read is computed over all its cells under this role's own rule. Same results either way. */
 zsw_error zsw_set_profile_sequence(zsw_context* ctx, const uint8_t* sequence, size_t len, zsw_mem mem);
 /* StripedProfile::<int_type,lanes,S>::new(sequence).sw_score(read_i) / ProfileSets::sw_score_from_i{from_width} */
 zsw_error zsw_score_shared_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, uint32_t* out_score,
@@ -304,6 +308,12 @@ zsw_error zsw_timing_read_window(zsw_context* ctx, double* seconds, uint64_t* la
  * roughly an order of magnitude fewer cells on reads that resemble the reference, the cost of the full pass plus a few per
  * cent on reads that do not. 28 bytes + 4 bits per base of device workspace per read, up to 0.3 GB of strip-boundary buffers per
  * call, and 8 * 4^K bytes of index (K = 8 for a 2 kb reference: 512 KiB; K = 10 for 30 kb: 8 MiB). Value 0 frees the workspace and computes every cell of every read.
+ * Alphabets of 8..32 letters (amino-acid matrices: a substituted residue may cost as little as 1, which leaves the k-mer argument
+ * nothing to prove with) take the column-pruned pass instead (zsw_score_prune.hip): the first 24 or 48 columns of
+ * a read against every row of the reference, the other columns in a window of rows around the strip's best row, and bounds that
+ * add each remaining column's own largest score; reads of 65..400 residues in batches of 98,304 or more, 8 bytes per read pair
+ * and reference row of workspace for up to 2 M reads at a time; the first chip-full of a large batch decides whether the rest is
+ * worth it (above 70 % handed back the others go straight to the full pass).
  * Unknown options or values return ZSW_ERR_INVALID_ARGUMENT. */
 typedef enum zsw_option { ZSW_OPTION_EXACT_PRUNING = 1 } zsw_option;
 zsw_error zsw_set_option(zsw_context* ctx, zsw_option option, int64_t value);
@@ -324,7 +334,8 @@ typedef enum zsw_debug_flag {
     /* with SCORE_PRUNE: round 2's column-pruned pass (zsw_score_prune.hip) instead of the seeded one: a narrow
      * strip of query columns against every reference row, the other columns in a window of rows around the strip's best row,
      * bound checks, the full pass for the reads that fail one. Reads of 65..400 bases, batches of 98,304 reads or more (or
-     * ANY_SIZE), up to 32 GiB of workspace. Kept as a cross-check of the seeded pass. */
+     * ANY_SIZE), up to 32 GiB of workspace. A cross-check of the seeded pass for the 5-letter tables; the default first pass of
+     * 8..32-letter alphabets (no flag needed there). */
     ZSW_DEBUG_PRUNE_STRIP = 512,
     /* align: the second pass starts warmup_rows before the first kept row for every read (round 2), not at the row the seeded
      * first pass certifies (zsw_seed.hpp: seed_safe_start) */
