@@ -1,5 +1,6 @@
 """Randomised parity sweep: random scoring schemes, alphabets, lengths, lane counts and batch shapes through every GPU entry
-point (score, ends, ranges, cascades, exact and 3-pass alignment, SeqSrc inversion) against the oracle.
+point (score, ends, ranges, cascades, exact and 3-pass alignment, SeqSrc inversion; the shared-profile role's score, ends, ranges
+and alignment with the reference as the profile sequence) against the oracle.
 usage: python tools/fuzz_gpu.py [iterations] [seed]     (FUZZ_PRUNE=1: the seeded exact first pass for batches of every size, FUZZ_PRUNE=strip: the column-pruned one; FUZZ_LONG_P: share of long-read cases)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,6 +33,8 @@ for it in range(iters):
         w = rng.integers(-6, 3, size=(S, S))
         w = np.minimum(w, w.T)
         np.fill_diagonal(w, rng.integers(2, 12, size=S))
+        if it % 3 == 0:  # an asymmetric matrix: the shared role scores with the transposed table
+            w[rng.integers(0, S, size=S), rng.integers(0, S, size=S)] -= 1
         m = za.WeightMatrix.new_custom(mp, w.astype(np.int8))
         alpha = np.frombuffer(keys, dtype=np.uint8)
     else:
@@ -100,6 +103,13 @@ for it in range(iters):
     c_al = lp._align(src, None, from_width=width, preset=preset)
     c_3p = lp._align(src, None, from_width=width, preset=preset, three_pass=True)
     c_rg = lp._ranges_from(za.SeqSrc.Reference(ref), width)
+    # the shared-profile role: the reference carries the profile, the reads are walked row by row (zsw_*_shared_batch)
+    shared = not long_case and all(len(r) > 0 for r in reads)
+    if shared:
+        sp = za.SharedStripedProfile(ref, m, go, ge, T, N)
+        s_sc, s_en = sp.sw_score(reads), sp.sw_score_ends(za.SeqBatchSrc.Reference(reads))
+        s_rg = sp.sw_score_ranges(za.SeqBatchSrc.Reference(reads))
+        s_al = sp.sw_align((za.SeqBatchSrc.Query if inv else za.SeqBatchSrc.Reference)(reads[:16]))
     # the same batch through HOST pointers (staging path of the C ABI) and the sneaky_snake filter on random windows
     import ctypes as C
     from zoe_amd import _lib
@@ -142,6 +152,19 @@ for it in range(iters):
         assert int(c_rg.status[i]) == st, ("cascade ranges status", ctxt)
         if st == S_:
             assert (int(c_rg.score[i]), (int(c_rg.ref_start[i]), int(c_rg.ref_end[i])), (int(c_rg.query_start[i]), int(c_rg.query_end[i])), int(c_rg.tier[i])) == (s, rr, qr, tier), ("cascade ranges", ctxt)
+        if shared:
+            st, s = oracle.score(T, N, sc, ref, rd)
+            assert (int(s_sc.status[i]), int(s_sc.score[i]) if st == S_ else 0) == (st, s if st == S_ else 0), ("shared score", ctxt)
+            st, (s, re_, qe) = oracle.score_ends(T, N, sc, ref, rd)
+            assert int(s_en.status[i]) == st, ("shared ends status", ctxt)
+            if st == S_:
+                assert (int(s_en.score[i]), int(s_en.ref_end[i]), int(s_en.query_end[i])) == (s, re_, qe), ("shared ends", ctxt)
+            st, s, rr, qr = oracle.score_ranges(T, N, sc, ref, rd)
+            assert int(s_rg.status[i]) == st, ("shared ranges status", ctxt)
+            if st == S_:
+                assert (int(s_rg.score[i]), (int(s_rg.ref_start[i]), int(s_rg.ref_end[i])), (int(s_rg.query_start[i]), int(s_rg.query_end[i]))) == (s, rr, qr), ("shared ranges", ctxt)
+            if i < 16:
+                assert s_al.key(i) == okey(oracle.align(T, N, sc, ref, rd, other_is_query=inv)), ("shared align", ctxt)
         n_checked += 1
     print(f"iteration {it}: ok ({len(reads)} reads, R={R}, T={T}x{N}, preset {preset} from i{width}, go={go} ge={ge}, {'protein S=%d' % len(m.mapping) if protein else 'dna'}, invert={inv}) [{time.time() - t_start:.0f} s]", flush=True)
-print(f"FUZZ OK: {n_checked} reads x 12 entry points")
+print(f"FUZZ OK: {n_checked} reads x 12 entry points + 4 of the shared-profile role")
