@@ -178,6 +178,9 @@ RANGES_HBM_PER_READ = 1_046 + 1_546
 THREEPASS_HBM_PER_READ = 2_244 + 4_722     # the third pass's DP rows and traceback cells in global memory (13.6 + 18.7 kB before the slots were interleaved)
 MIXED_HBM_PER_READ = 2_700 + 3_745
 ALIGN_HBM_PER_READ = 11_512 + 33_470       # the flag ring of pass 2 (30 kB per read) and its read-back by the traceback
+PROTEIN_PROFILE = "profiles/r03_protein_prune_summary.txt"
+PROTEIN_VALU_PER_READ = 3_940 + 2_155 + 496   # prune_strip_kernel<24,WIDE> + prune_window_kernel<24,4,32,0,WIDE> + score_kernel_v2<..,WIDE> over the 2.1 % handed back
+PROTEIN_HBM_PER_READ = 10_900 + 1_200 + 360 + 1_500   # the strip's boundary stream written, read back by the window kernel
 MIXED_VALU_PER_READ = 16_114      # 75-400 bp vs 30 kb: 13,800 of them are the full pass over the 3 % of reads handed back
 
 
@@ -355,6 +358,62 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
                                      "identical": bool(torch.equal(got.score, seeded_mixed.score) and torch.equal(got.status, seeded_mixed.status)
                                                        and torch.equal(got.tier, seeded_mixed.tier))}
     out["score_mixed_1M_x_75_400bp_vs_30kb"] = entry
+    del rr, pm, got, seeded_mixed
+    torch.cuda.empty_cache()
+    out.update(protein_and_shared(zoe_amd, synth, ctx, matrix, timed, with_full_first_pass))
+    return out
+
+
+def protein_and_shared(zoe_amd, synth, ctx, matrix, timed, with_full_first_pass):
+    """Two more users of the score pass on 1 M reads each: a 25-letter alphabet (the reference's amino-acid matrices are
+    WeightMatrix<i8, 25>, src/data/matrices/aa.rs; default first pass: the column-pruned one) and the shared-profile
+    role (one profile from the 2 kb reference, the reads as the other sequence: sw/mod.rs:63-67, profile_set.rs:552-560; 4.5)."""
+    import torch
+
+    out = {}
+    n = 1_000_000
+    keys = b"ACDEFGHIKLMNPQRSTVWYBJZX*"
+    rng = np.random.default_rng(3)
+    w = rng.integers(-4, 3, size=(25, 25))
+    w = np.minimum(w, w.T)
+    np.fill_diagonal(w, rng.integers(4, 12, size=25))
+    pm = zoe_amd.WeightMatrix.new_custom(zoe_amd.ByteIndexMap.new(keys, b"X"), w.astype(np.int8))
+    alpha = np.frombuffer(keys[:20], dtype=np.uint8)
+    refa = rng.choice(alpha, 2000).astype(np.uint8)
+    start = rng.integers(0, 2000 - READ_LEN, size=n)
+    reads = refa[start[:, None] + np.arange(READ_LEN)[None, :]]
+    reads = np.where(rng.random((n, READ_LEN)) < 0.03, rng.choice(alpha, (n, READ_LEN)), reads).astype(np.uint8)
+    junk = rng.random(n) < 0.02
+    reads[junk] = rng.choice(alpha, (int(junk.sum()), READ_LEN))
+    rb = zoe_amd.ReadBatch.from_fixed(torch.from_numpy(reads.reshape(-1)).to(f"cuda:{ctx.device}"), READ_LEN)
+    prof = zoe_amd.into_local_profile(rb, pm, -11, -1, device=ctx.device)
+    ctx.timing_enable(True)
+    got, dt, ks = timed(lambda: prof.sw_score_from_i8(refa.tobytes()))
+    handed_back = ctx.prune_rescored()
+    entry = {"reads_per_s": n / dt, "kernels_ms": ks * 1e3, "handed_back_fraction": handed_back / n,
+             "call": "sw_score_from_i8, 25-letter BLOSUM-shaped matrix, 150 residues vs 2,000 (pieces of the reference, 3 % substituted, + 2 % unrelated)",
+             "kernel": "prune_strip_kernel<24,WIDE> + prune_window_kernel<24,4,32,0,WIDE>, score_kernel_v2<..,WIDE> over the reads handed back"}
+    entry.update(rooflines(n * (READ_LEN + 4.0), ks if ks > 0 else dt, PROTEIN_VALU_PER_READ * n, PROTEIN_PROFILE, PROTEIN_HBM_PER_READ * n))
+    full, dtp, ksp = with_full_first_pass(lambda: prof.sw_score_from_i8(refa.tobytes()))
+    entry["with_full_first_pass"] = {"reads_per_s": n / dtp, "kernels_ms": ksp * 1e3,
+                                       "identical": bool(torch.equal(full.score, got.score) and torch.equal(full.status, got.status) and torch.equal(full.tier, got.tier))}
+    out["score_protein_25_letters_1M_x_150_vs_2000"] = entry
+    del rb, prof, got, full
+    torch.cuda.empty_cache()
+    # the shared-profile role on the headline's reads
+    ref2k = synth.reference_host(REF_LEN)
+    rb = synth.reads_device(ctx, ref2k, 0, n, READ_LEN)
+    sp = zoe_amd.SharedStripedProfile(ref2k, matrix, -10, -1, "i16", 16, device=ctx.device)
+    sc_, dt_s, ks_s = timed(lambda: sp.sw_score(rb))
+    en, dt_e, ks_e = timed(lambda: sp.sw_score_ends(zoe_amd.SeqBatchSrc.Reference(rb)))
+    en0, dt_e0, _ = with_full_first_pass(lambda: sp.sw_score_ends(zoe_amd.SeqBatchSrc.Reference(rb)))
+    ctx.timing_enable(False)
+    out["shared_profile_1M_x_150bp_vs_2kb"] = {
+        "score_reads_per_s": n / dt_s, "score_ends_reads_per_s": n / dt_e, "score_ends_kernels_ms": ks_e * 1e3,
+        "call": "StripedProfile::<i16,16,5>::new(reference) reused for every read: sw_score(read) / sw_score_ends(SeqSrc::Reference(read))",
+        "kernel": "the seeded pass with the roles swapped (seed_band_kernel<32,.,3>: ends + 'the maximum sits in one cell'), shared_ends_kernel for every other read",
+        "every_read_by_the_exact_shared_kernel": {"score_ends_reads_per_s": n / dt_e0,
+                                                    "identical": all(bool(torch.equal(getattr(en0, f), getattr(en, f))) for f in ("score", "status", "ref_end", "query_end"))}}
     return out
 
 
