@@ -654,16 +654,22 @@ size_t align_ring_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid) {
     return bytes;
 }
 // ---- the one-profile-many-sequences role (zsw_shared.hpp): generic kernel, rows in LDS or behind the ring ----
+// The profile is striped over the whole shared sequence (nv = 125 at <i16,16> for 2 kb: 80 KB of DP rows per wavefront), so rows
+// in LDS leave two wavefronts per CU — half a wavefront per SIMD, every instruction waiting for the one before. Beyond
+// SHARED_ROWS_LDS_LIMIT the rows live behind the flag ring in global memory (L2 / HBM) and the CU holds as many wavefronts as
+// its registers allow (100,000 reads vs 2 kb: 590 -> see DESIGN.md 4.5).
+constexpr size_t SHARED_ROWS_LDS_LIMIT = 16 * 1024;
+static bool shared_rows_global(uint32_t nv, int S) { return align_lds_bytes(nv, S) > SHARED_ROWS_LDS_LIMIT; }
 size_t align_shared_ring_bytes(int N, uint32_t plen, uint32_t W, uint32_t grid, int S) {
     const uint32_t nv = (plen + (uint32_t)N - 1) / (uint32_t)N;
     size_t bytes = ((size_t)grid * (64 / N) * (size_t)W * ((size_t)N * nv) + 255) / 256 * 256;
-    if (align_lds_bytes(nv, S) > ALIGN_LDS_LIMIT) bytes += (size_t)grid * align_rows_bytes(nv);
+    if (shared_rows_global(nv, S)) bytes += (size_t)grid * align_rows_bytes(nv);
     return bytes;
 }
 
 template <int N>
 static hipError_t launch_align_shared_n(const AlignArgs& a, int S, uint32_t grid, hipStream_t stream) {
-    if (align_lds_bytes(a.nv, S) > ALIGN_LDS_LIMIT) {
+    if (shared_rows_global(a.nv, S)) {
         hipLaunchKernelGGL((align_kernel<N, true, true>), dim3(grid), dim3(64), 0, stream, a);
         return hipGetLastError();
     }
@@ -700,9 +706,7 @@ hipError_t align_pass2_shared(int N, const uint8_t* d_pseq, uint32_t plen, const
     a.safe_row = nullptr;
     a.prof_seq = d_pseq;
     a.prof_len = plen;
-    a.rows = align_lds_bytes(nv, S) > ALIGN_LDS_LIMIT
-                 ? d_ring + ((size_t)grid * (64 / N) * (size_t)W * ((size_t)N * nv) + 255) / 256 * 256
-                 : nullptr;
+    a.rows = shared_rows_global(nv, S) ? d_ring + ((size_t)grid * (64 / N) * (size_t)W * ((size_t)N * nv) + 255) / 256 * 256 : nullptr;
     a.next_item = d_fb_count + 1;
     hipError_t ce = hipMemsetAsync(a.next_item, 0, 4, stream);
     if (ce != hipSuccess) return ce;

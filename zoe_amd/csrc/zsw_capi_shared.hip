@@ -299,8 +299,9 @@ zsw_error run_align_shared(zsw_context* ctx, const zsw_batch* reads, const Resul
     auto run_tier = [&](int N, const uint32_t* d_items, uint32_t count, uint32_t maxc, int by_item, DevBuf& ringbuf, DevBuf& cigbuf) -> zsw_error {
         if (!count) return ZSW_OK;
         uint32_t grid = std::min<uint32_t>((count + (64 / (uint32_t)N) - 1) / (64 / (uint32_t)N), 4096u);
-        while (grid > 1 && align_shared_ring_bytes(N, plen, W, grid, S) > (size_t(3) << 30)) grid /= 2;
-        if (align_shared_ring_bytes(N, plen, W, grid, S) > (size_t(6) << 30)) return fail(ctx, ZSW_ERR_UNSUPPORTED, "shared profile too long for the flag ring");
+        // every row's flags of every read in flight: plen x W bytes per read (300 KB at 2 kb x 150); 4,096 wavefronts are four per SIMD
+        while (grid > 1 && align_shared_ring_bytes(N, plen, W, grid, S) > (size_t(8) << 30)) grid /= 2;
+        if (align_shared_ring_bytes(N, plen, W, grid, S) > (size_t(12) << 30)) return fail(ctx, ZSW_ERR_UNSUPPORTED, "shared profile too long for the flag ring");
         ZSW_HIP(ctx, ringbuf.ensure(align_shared_ring_bytes(N, plen, W, grid, S) + 64));
         if (by_item) ZSW_HIP(ctx, cigbuf.ensure((uint64_t)count * maxc * 4 + 64));
         BatchDev b = st.b;
