@@ -551,7 +551,9 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         if (pe != hipSuccess) return pe;
         ap.b.items = ws.prune_fail_list + list_off;
         ap.n_items_dev = counter;
-        pe = launch_table_cfg_v2(ap, g, c, mode, stream);
+        // mode 3 (out.unique, the shared-profile role's first pass): the caller recomputes every read without the flag under its
+        // own tie rule, the handed-back reads among them — scoring them here would be thrown away
+        if (!out.unique) pe = launch_table_cfg_v2(ap, g, c, mode, stream);
         if (pe != hipSuccess) return pe;
         hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, stream, counter, ws.prune_fail_count + 1);
         return hipGetLastError();
