@@ -117,27 +117,26 @@ def _batch(za, reads2d):
     return za.ReadBatch.from_fixed(torch.from_numpy(np.ascontiguousarray(reads2d).reshape(-1)).cuda(), L)
 
 
-@pytest.mark.parametrize("L,R", [(150, 2000), (90, 700), (152, 333), (250, 1500), (380, 2500)])
-@pytest.mark.parametrize("seed", [3, 8])
+@pytest.mark.parametrize("L,R,seed", [(150, 2000, 3), (150, 2000, 8), (90, 700, 8), (152, 333, 3), (250, 1500, 8), (380, 2500, 3)])
 def test_wide_pruned_pass_equals_oracle(za, oracle, any_size, L, R, seed):
-    """score (w256 cascade), score + ends and ranges of 600 protein reads per case through the pruned pass, read by read against the
-    oracle; some reads pass the checks and some do not"""
+    """score (w256 cascade), score + ends and ranges of 400 protein reads per case through the pruned pass, read by read against the
+    oracle; some reads pass the checks and some do not (seed 8: an asymmetric matrix and free gap extension)"""
     keys, mp, w, m = _matrix(za, seed, symmetric=seed != 8)
     rng = np.random.default_rng(stable_seed(L, R, seed))
     alpha = np.frombuffer(keys[:20], dtype=np.uint8)
     ref = bytes(rng.choice(alpha, R))
-    reads = _reads(rng, ref, 600, L, alpha)
+    reads = _reads(rng, ref, 400, L, alpha)
     go, ge = (-11, -1) if seed == 3 else (-8, 0)
     sc = oracle.Scoring(w, mp.index_map, go, ge)
     rb = _batch(za, reads)
     lp = za.LocalProfilesBatch.new_with_w256(rb, m, go, ge)
     got = lp.sw_score_from_i8(ref)
     rescored = any_size.prune_rescored()
-    assert 0 < rescored < 600, rescored  # both outcomes occurred
+    assert 0 < rescored < 400, rescored  # both outcomes occurred
     rg = lp.sw_score_ranges_from_i8(za.SeqSrc.Reference(ref))
     p16 = za.StripedProfileBatch(rb, m, go, ge, "i16", 16)
     ends = p16.sw_score_ends(za.SeqSrc.Reference(ref))
-    for i in range(600):
+    for i in range(400):
         rd = reads[i].tobytes()
         o_st, o_s, o_t = oracle.cascade_score(8, 256, sc, rd, ref)
         assert (int(got.status[i]), int(got.score[i]) if o_st == S_ else 0, int(got.tier[i])) == (o_st, o_s if o_st == S_ else 0, o_t), i

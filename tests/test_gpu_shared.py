@@ -220,7 +220,7 @@ def _tie_rich_reads(rng, seq, n, L):
 
 @pytest.mark.parametrize("T,N", [("i16", 16), ("i8", 32)])
 def test_ends_through_the_seeded_pass_on_tie_rich_reads(za, oracle, T, N):
-    """2,400 reads of 150 bases (the default path: batches of 1,024 reads or more take the role-swapped seeded pass) against a
+    """1,500 reads of 150 bases (the default path: batches of 1,024 reads or more take the role-swapped seeded pass) against a
     sequence with tandem repeats and a duplicated stretch: ends, ranges of every read, every eighth CIGAR, against the oracle with
     the same roles"""
     import torch
@@ -230,7 +230,7 @@ def test_ends_through_the_seeded_pass_on_tie_rich_reads(za, oracle, T, N):
     parts = [bytes(rng.choice(alpha, 400)), b"ACG" * 30, bytes(rng.choice(alpha, 300)), b"TTGACA" * 20, bytes(rng.choice(alpha, 500)), b"AC" * 50]
     dup = bytes(rng.choice(alpha, 200))
     seq = b"".join(parts) + dup + bytes(rng.choice(alpha, 150)) + dup + bytes(rng.choice(alpha, 100))
-    reads2d = _tie_rich_reads(rng, seq, 2400, 150)
+    reads2d = _tie_rich_reads(rng, seq, 1500, 150)
     reads = [bytes(r) for r in reads2d]
     dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
     sc = osc(oracle, dna, -10, -1)
