@@ -254,7 +254,8 @@ def test_ends_through_the_seeded_pass_on_tie_rich_reads(za, oracle, T, N):
 
 def test_seeded_and_plain_shared_ends_agree_on_a_large_batch(za):
     """300,000 synthetic reads + tie-rich ones: the default path (role-swapped seeded pass + the exact kernel on what it cannot
-    settle) against the exact shared-role kernel over every read (ZSW_OPTION_EXACT_PRUNING off)"""
+    settle; for the ranges a second seeded pass over the reversed sequences) against the exact shared-role kernels over every read
+    (ZSW_OPTION_EXACT_PRUNING off)"""
     import torch
 
     from zoe_amd import _lib, synth
@@ -268,13 +269,17 @@ def test_seeded_and_plain_shared_ends_agree_on_a_large_batch(za):
     dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
     prof = za.SharedStripedProfile(ref, dna, -10, -1, "i16", 16)
     got = prof.sw_score_ends(za.SeqBatchSrc.Reference(rb))
+    got_r = prof.sw_score_ranges(za.SeqBatchSrc.Reference(rb))  # second pass: the seeded pass over the reversed sequences + the exact kernel
     ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
     try:
         want = prof.sw_score_ends(za.SeqBatchSrc.Reference(rb))
+        want_r = prof.sw_score_ranges(za.SeqBatchSrc.Reference(rb))
     finally:
         ctx.set_option(_lib.OPTION_EXACT_PRUNING, 1)
     for name in ("score", "status", "ref_end", "query_end"):
         assert torch.equal(getattr(got, name), getattr(want, name)), name
+    for name in ("score", "status", "ref_start", "ref_end", "query_start", "query_end"):
+        assert torch.equal(getattr(got_r, name), getattr(want_r, name)), "ranges " + name
 
 
 def test_long_profile_sequence_takes_several_tiles_and_rows_in_hbm(za, oracle):

@@ -898,7 +898,7 @@ void zsw_destroy(zsw_context* ctx) {
     DeviceGuard device_guard(ctx);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state, &ctx->d_prune, &ctx->d_prune_list, &ctx->d_prune_count, &ctx->d_seed_work, &ctx->d_seed_gtab, &ctx->d_pseq, &ctx->d_sc_t,
+    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state, &ctx->d_prune, &ctx->d_prune_list, &ctx->d_prune_count, &ctx->d_seed_work, &ctx->d_seed_gtab, &ctx->d_pseq, &ctx->d_pseq_rev, &ctx->d_sc_t,
                       &ctx->s_bases, &ctx->s_offsets, &ctx->s_score, &ctx->s_status, &ctx->s_tier, &ctx->s_rend, &ctx->s_qend};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->a_ws) b.release();
@@ -906,6 +906,7 @@ void zsw_destroy(zsw_context* ctx) {
     for (DevBuf& b : ctx->sh_ws) b.release();
     seed_index_release(&ctx->seed);
     seed_index_release(&ctx->seed_shared);
+    seed_index_release(&ctx->seed_shared_rev);
     ctx->timer.destroy();
     ctx->timer_window.destroy();
     if (ctx->side) {
@@ -962,6 +963,7 @@ zsw_error zsw_set_scoring(zsw_context* ctx, const int8_t* weights, int S, const 
     ctx->scoring_set = true;
     ctx->seed.valid = false;  // the index spells k-mers with the matrix's good residues
     ctx->seed_shared.valid = false;
+    ctx->seed_shared_rev.valid = false;
     return ZSW_OK;
 }
 

@@ -14,7 +14,8 @@ using namespace zsw::capi;
 
 namespace {
 
-enum { SH_SCORE = 0, SH_STATUS, SH_TIER, SH_REND, SH_QEND, SH_QEM, SH_RSCORE, SH_RSTATUS, SH_RRS, SH_RQS, SH_MIS, SH_LIST, SH_UNIQUE, SH_ULIST, SH_UCOUNT };
+enum { SH_SCORE = 0, SH_STATUS, SH_TIER, SH_REND, SH_QEND, SH_QEM, SH_RSCORE, SH_RSTATUS, SH_RRS, SH_RQS, SH_MIS, SH_LIST, SH_UNIQUE, SH_ULIST, SH_UCOUNT,
+       SH_UNIQUE_R, SH_RBASES };
 
 __global__ void empty_is_unmapped_kernel(uint32_t n, uint8_t* status) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,6 +40,51 @@ __global__ void iota_some_kernel(uint32_t n, const uint8_t* status, const uint8_
 __global__ void select_not_unique_kernel(uint32_t n, const uint8_t* unique, uint32_t* list, uint32_t* count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool take = i < n && unique[i] == 0;
+    const unsigned long long m = __ballot(take);
+    if (m) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (take) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    }
+}
+
+// every read of the batch reversed (same offsets): the other sequence of the reverse pass
+__global__ void reverse_reads_kernel(BatchDev b, uint64_t total_bases, uint8_t* out) {
+    if (!b.offsets) {
+        const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < total_bases) {
+            const uint64_t id = i / b.fixed_len, j = i % b.fixed_len;
+            out[id * b.fixed_len + (b.fixed_len - 1 - j)] = b.bases[i];
+        }
+    } else {
+        const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+        if (id < b.n_reads) {
+            const uint64_t o = b.offsets[id], e = b.offsets[id + 1];
+            for (uint64_t j = o; j < e; ++j) out[e - 1 - (j - o)] = b.bases[j];
+        }
+    }
+}
+
+// Second pass of sw_simd_score_ranges in the shared role, settled by the seeded pass over the REVERSED sequences: read i is done
+// if its forward maximum sits in one cell (uf), the reversed problem's maximum sits in one cell (ur) and the two scores agree —
+// then the starts are that cell's coordinates turned round (rs: position in rev(read) + 1 -> inclusive start in the read, qs
+// likewise in the profile sequence). Everything else joins the list of the exact reverse kernel.
+__global__ void settle_reverse_kernel(BatchDev b, uint32_t n, uint32_t plen, const uint8_t* uf, const uint8_t* ur, const uint32_t* fscore,
+                                      const uint8_t* fstatus, const uint32_t* rscore, const uint8_t* rstatus, uint32_t* rs, uint32_t* qs,
+                                      uint32_t* list, uint32_t* count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool settled = false;
+    if (i < n && uf[i] && ur[i] && fstatus[i] == ZSW_STATUS_SOME && rstatus[i] == ZSW_STATUS_SOME && rscore[i] == fscore[i]) {
+        const uint32_t len = b.offsets ? (uint32_t)(b.offsets[i + 1] - b.offsets[i]) : b.fixed_len;
+        if (rs[i] >= 1 && rs[i] <= len && qs[i] >= 1 && qs[i] <= plen) {
+            rs[i] = len - rs[i];
+            qs[i] = plen - qs[i];
+            settled = true;
+        }
+    }
+    const bool take = i < n && !settled;
     const unsigned long long m = __ballot(take);
     if (m) {
         const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
@@ -83,7 +129,9 @@ struct SharedStage {
 // cell of the matrix. For such a read the tie rule does not matter and the ends are the shared role's with the names swapped
 // (ref_end = row of the read, query_end = column of the profile sequence). Every other read — handed back by the seeded pass,
 // ties, no alignment — is computed by shared_ends_kernel, which walks all cells under the shared role's own rule.
-zsw_error shared_ends_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, const ScoreOut& out, hipStream_t stream) {
+zsw_error shared_ends_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, const ScoreOut& out, hipStream_t stream,
+                             bool* seeded = nullptr /* out: the seeded route ran and sh_ws[SH_UNIQUE] holds its flags */) {
+    if (seeded) *seeded = false;
     if (st.max_len > shared_max_rows()) return fail(ctx, ZSW_ERR_UNSUPPORTED, "read too long for the shared-profile kernels");
     const uint32_t n = st.b.n_items;
     BatchDev rest = st.b;
@@ -111,6 +159,7 @@ zsw_error shared_ends_device(zsw_context* ctx, const Staged& st, const ResultRul
                            ws[SH_ULIST].as<uint32_t>(), ws[SH_UCOUNT].as<uint32_t>());
         rest.items = ws[SH_ULIST].as<uint32_t>();
         rest_count = ws[SH_UCOUNT].as<uint32_t>();
+        if (seeded) *seeded = true;
     }
     hipError_t e = launch_shared_ends(rest, std::max<uint32_t>(st.max_len, 1), ctx->d_pseq.as<uint8_t>(), (uint32_t)ctx->pseq_len,
                                       ctx->d_sc.as<ScoringDev>(), rule, out, nullptr, nullptr, stream, rest_count);
@@ -209,7 +258,8 @@ zsw_error run_ranges_shared(zsw_context* ctx, const zsw_batch* reads, const Resu
     fo.fb_list = nullptr;
     fo.fb_count = nullptr;
     ctx->timer.begin(stream);
-    ze = shared_ends_device(ctx, st, rule, fo, stream);
+    bool seeded = false;
+    ze = shared_ends_device(ctx, st, rule, fo, stream, &seeded);
     if (ze != ZSW_OK) return ze;
     // reverse pass on the prefixes the forward pass found (reads without an alignment take part with empty prefixes)
     ZSW_HIP(ctx, launch_ranges_prep(n, fo.status, fo.query_end, ws[SH_QEM].as<uint32_t>(), stream));
@@ -221,8 +271,61 @@ zsw_error run_ranges_shared(zsw_context* ctx, const zsw_batch* reads, const Resu
     ro.query_end = ws[SH_RQS].as<uint32_t>();
     ro.fb_list = nullptr;
     ro.fb_count = nullptr;
-    hipError_t e = launch_shared_ends(st.b, std::max<uint32_t>(st.max_len, 1), ctx->d_pseq.as<uint8_t>(), (uint32_t)ctx->pseq_len,
-                                      ctx->d_sc.as<ScoringDev>(), rule, ro, fo.ref_end, ws[SH_QEM].as<uint32_t>(), stream);
+    BatchDev rest = st.b;
+    const uint32_t* rest_count = nullptr;
+    if (seeded) {
+        // The reverse pass as a seeded pass of its own: reversed reads against the reversed profile sequence, whole sequences. If
+        // the forward maximum sits in one cell, every alignment that scores it ends there, i.e. lies inside the prefixes the
+        // reverse pass of striped.rs:355-388 is restricted to; the cells of the reversed matrix that hold the score are then the
+        // same with or without the restriction, and if that is one cell too, it is the start under any tie rule.
+        const size_t plen = ctx->pseq_len;
+        ScoringDev h_t = ctx->h_sc;
+        for (int r = 0; r < h_t.S; ++r)
+            for (int q = 0; q < h_t.S; ++q) h_t.w[r * h_t.S + q] = ctx->h_sc.w[q * h_t.S + r];
+        if (!ctx->seed_shared_rev.valid) {
+            std::vector<uint8_t> rev(ctx->h_pseq.rbegin(), ctx->h_pseq.rend());
+            ZSW_HIP(ctx, ctx->d_pseq_rev.ensure(plen + 16));
+            ZSW_HIP(ctx, hipMemcpyAsync(ctx->d_pseq_rev.p, rev.data(), plen, hipMemcpyHostToDevice, stream));
+            ZSW_HIP(ctx, hipStreamSynchronize(stream));  // `rev` goes out of scope
+            ZSW_HIP(ctx, seed_index_update(&ctx->seed_shared_rev, h_t, rev.data(), plen));
+        }
+        if (ctx->seed_shared_rev.usable) {
+            const uint64_t total = st.b.offsets ? 0 : (uint64_t)n * st.b.fixed_len;
+            uint64_t bytes = total;
+            if (st.b.offsets) {
+                uint64_t last = 0;
+                ZSW_HIP(ctx, hipMemcpyAsync(&last, st.b.offsets + n, 8, hipMemcpyDeviceToHost, stream));
+                ZSW_HIP(ctx, hipStreamSynchronize(stream));
+                bytes = last;
+            }
+            ZSW_HIP(ctx, ws[SH_RBASES].ensure(bytes + 16));
+            ZSW_HIP(ctx, ws[SH_UNIQUE_R].ensure((size_t)n + 4));
+            ZSW_HIP(ctx, hipMemsetAsync(ws[SH_UNIQUE_R].p, 0, n, stream));
+            if (st.b.offsets) hipLaunchKernelGGL(reverse_reads_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, st.b, bytes, ws[SH_RBASES].as<uint8_t>());
+            else if (bytes) hipLaunchKernelGGL(reverse_reads_kernel, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, stream, st.b, bytes, ws[SH_RBASES].as<uint8_t>());
+            BatchDev brev = st.b;
+            brev.bases = ws[SH_RBASES].as<uint8_t>();
+            ScoreOut o3 = ro;
+            o3.ref_end = ro.query_end;   // rows of the swapped problem: positions of the reversed profile sequence
+            o3.query_end = ro.ref_end;   // columns: positions of the reversed read
+            o3.fb_list = ctx->d_fb_list.as<uint32_t>();
+            o3.fb_count = ctx->d_fb_count.as<uint32_t>();
+            o3.unique = ws[SH_UNIQUE_R].as<uint8_t>();
+            ScoreWorkspace w = score_ws(ctx);
+            w.seed = &ctx->seed_shared_rev;
+            hipError_t e3 = launch_score(ctx->d_sc_t.as<ScoringDev>(), h_t, brev, st.max_len, ctx->d_pseq_rev.as<uint8_t>(), (uint32_t)plen, rule, o3, w,
+                                         stream, nullptr, 3);
+            if (e3 != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "shared ranges: seeded reverse pass", e3);
+            ZSW_HIP(ctx, hipMemsetAsync(ws[SH_UCOUNT].p, 0, 4, stream));
+            hipLaunchKernelGGL(settle_reverse_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, st.b, n, (uint32_t)plen, ws[SH_UNIQUE].as<uint8_t>(),
+                               ws[SH_UNIQUE_R].as<uint8_t>(), fo.score, fo.status, ro.score, ro.status, ro.ref_end, ro.query_end,
+                               ws[SH_ULIST].as<uint32_t>(), ws[SH_UCOUNT].as<uint32_t>());
+            rest.items = ws[SH_ULIST].as<uint32_t>();
+            rest_count = ws[SH_UCOUNT].as<uint32_t>();
+        }
+    }
+    hipError_t e = launch_shared_ends(rest, std::max<uint32_t>(st.max_len, 1), ctx->d_pseq.as<uint8_t>(), (uint32_t)ctx->pseq_len,
+                                      ctx->d_sc.as<ScoringDev>(), rule, ro, fo.ref_end, ws[SH_QEM].as<uint32_t>(), stream, rest_count);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "shared ranges reverse pass", e);
     ZSW_HIP(ctx, hipMemsetAsync(ws[SH_MIS].p, 0, 4, stream));
     ZSW_HIP(ctx, launch_ranges_combine(n, fo.score, fo.status, fo.ref_end, fo.query_end, ro.score, ro.status, ro.ref_end, ro.query_end,
@@ -378,6 +481,7 @@ zsw_error zsw_set_profile_sequence(zsw_context* ctx, const uint8_t* sequence, si
     if (mem == ZSW_MEM_HOST) memcpy(ctx->h_pseq.data(), sequence, len);
     else ZSW_HIP(ctx, hipMemcpy(ctx->h_pseq.data(), sequence, len, hipMemcpyDeviceToHost));
     ctx->seed_shared.valid = false;
+    ctx->seed_shared_rev.valid = false;
     ctx->pseq_len = len;
     ctx->pseq_set = true;
     return ZSW_OK;

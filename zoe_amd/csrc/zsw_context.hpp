@@ -77,7 +77,7 @@ struct zsw_context {
     zsw::SideStreams* side = nullptr;
     // the one-profile-many-sequences role (zsw_capi_shared.hip): the sequence the shared profile is built from, the scoring with
     // the matrix transposed (score-only calls go through the ordinary kernels with the roles swapped), workspace
-    zsw::DevBuf d_pseq, d_sc_t, sh_ws[16];
+    zsw::DevBuf d_pseq, d_pseq_rev, d_sc_t, sh_ws[20];
     std::vector<uint8_t> h_pseq;
     size_t pseq_len = 0;
     bool pseq_set = false;
@@ -85,6 +85,9 @@ struct zsw_context {
     // index of the profile sequence under the transposed matrix: the seeded pass of the shared role's score calls (roles swapped:
     // the sequence is the ordinary kernels' reference); rebuilt after zsw_set_scoring / zsw_set_profile_sequence
     zsw::SeedIndex seed_shared;
+    // the same for the REVERSED profile sequence (d_pseq_rev): the second pass of the shared role's sw_simd_score_ranges as a
+    // seeded pass over the reversed reads (zsw_capi_shared.hip, run_ranges_shared); built with the first such call
+    zsw::SeedIndex seed_shared_rev;
     bool shared_seedable = false;  // set by the shared entry points whose kernels can take the seeded pass (score; ends with MODE 3)
 };
 
