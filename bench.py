@@ -407,11 +407,17 @@ def protein_and_shared(zoe_amd, synth, ctx, matrix, timed, with_full_first_pass)
     sc_, dt_s, ks_s = timed(lambda: sp.sw_score(rb))
     en, dt_e, ks_e = timed(lambda: sp.sw_score_ends(zoe_amd.SeqBatchSrc.Reference(rb)))
     en0, dt_e0, _ = with_full_first_pass(lambda: sp.sw_score_ends(zoe_amd.SeqBatchSrc.Reference(rb)))
+    rg, dt_r, ks_r = timed(lambda: sp.sw_score_ranges(zoe_amd.SeqBatchSrc.Reference(rb)))
+    rg0, dt_r0, _ = with_full_first_pass(lambda: sp.sw_score_ranges(zoe_amd.SeqBatchSrc.Reference(rb)))
     ctx.timing_enable(False)
     out["shared_profile_1M_x_150bp_vs_2kb"] = {
         "score_reads_per_s": n / dt_s, "score_ends_reads_per_s": n / dt_e, "score_ends_kernels_ms": ks_e * 1e3,
-        "call": "StripedProfile::<i16,16,5>::new(reference) reused for every read: sw_score(read) / sw_score_ends(SeqSrc::Reference(read))",
-        "kernel": "the seeded pass with the roles swapped (seed_band_kernel<32,.,3>: ends + 'the maximum sits in one cell'), shared_ends_kernel for every other read",
+        "score_ranges_reads_per_s": n / dt_r, "score_ranges_kernels_ms": ks_r * 1e3,
+        "score_ranges_every_read_by_the_exact_shared_kernels": {
+            "reads_per_s": n / dt_r0, "identical": all(bool(torch.equal(getattr(rg0, f), getattr(rg, f)))
+                                                        for f in ("score", "status", "ref_start", "ref_end", "query_start", "query_end"))},
+        "call": "StripedProfile::<i16,16,5>::new(reference) reused for every read: sw_score(read) / sw_score_ends / sw_score_ranges(SeqSrc::Reference(read))",
+        "kernel": "the seeded pass with the roles swapped (seed_band_kernel<32,.,3>: ends + 'the maximum sits in one cell'; ranges: again over the reversed sequences), shared_ends_kernel for every other read",
         "every_read_by_the_exact_shared_kernel": {"score_ends_reads_per_s": n / dt_e0,
                                                     "identical": all(bool(torch.equal(getattr(en0, f), getattr(en, f))) for f in ("score", "status", "ref_end", "query_end"))}}
     return out
