@@ -5,7 +5,10 @@
 // it — that
 //   * no path of layer 1 scores more than the largest of the bounds (fresh starts above / below the band, exits through the right
 //     edge of a strip above the next strip's first row, exits through a strip's last row), for every read, passing or not;
-//   * hence a read whose bounds are all <= the band's maximum S' has S' as its score (all < S': also the first row and column).
+//   * hence a read whose bounds are all <= the band's maximum S' has S' as its score (all < S': also the first row and column);
+//   * mode 3 (the shared-profile role, zsw_capi_shared.hip): with all bounds < S' the cells of the whole matrix that hold the
+//     maximum are exactly the band's cells that hold S' — so "S' sits in one cell of the band" means "the maximum sits in one cell",
+//     and that cell is the answer under the other tie rule (first column, then first row) as well.
 // Reads, references and schemes as in seed_bounds.cpp. usage: seed_band <iterations> <seed>
 #include <algorithm>
 #include <cstdint>
@@ -51,7 +54,7 @@ struct Geometry {
 };
 
 struct Counters {
-    long reads = 0, anchored = 0, pass_score = 0, pass_ends = 0, plain = 0, plain_pass = 0;
+    long reads = 0, anchored = 0, pass_score = 0, pass_ends = 0, plain = 0, plain_pass = 0, unique = 0;
 };
 
 bool check_read(const Scheme& s, const SeedParams& p, const std::vector<uint32_t>& table, const std::vector<uint8_t>& ref,
@@ -90,6 +93,7 @@ bool check_read(const Scheme& s, const SeedParams& p, const std::vector<uint32_t
     auto at = [&](std::vector<int>& v, int r, int c) -> int& { return v[(size_t)r * W + c]; };  // r, c 1-based; 0 = border
     auto clampneg = [](int x) { return x < NEG / 2 ? NEG : x; };
     int best0 = 0, row0 = -1, col0 = -1, best1 = 0, truth = 0, trow = -1, tcol = -1;
+    int n_best0 = 0, n_truth = 0, trow2 = -1, tcol2 = -1;  // cells holding the two maxima; the truth under the transposed tie rule
     int best_cls[NL] = {0, 0, 0, 0, 0};
     for (int r = 1; r <= R; ++r)
         for (int c = 1; c <= L; ++c) {
@@ -125,6 +129,9 @@ bool check_read(const Scheme& s, const SeedParams& p, const std::vector<uint32_t
                 best0 = at(H0, r, c);
                 row0 = r - 1;
                 col0 = c - 1;
+                n_best0 = 1;
+            } else if (at(H0, r, c) == best0 && best0 > 0) {
+                ++n_best0;
             }
             int h = at(H0, r, c);
             for (int j = 1; j < NL; ++j) {
@@ -134,8 +141,15 @@ bool check_read(const Scheme& s, const SeedParams& p, const std::vector<uint32_t
             }
             if (h > truth) {
                 truth = h;
-                trow = r - 1;
-                tcol = c - 1;
+                trow = trow2 = r - 1;
+                tcol = tcol2 = c - 1;
+                n_truth = 1;
+            } else if (h == truth && truth > 0) {
+                ++n_truth;
+                if (c - 1 < tcol2 || (c - 1 == tcol2 && r - 1 < trow2)) {
+                    tcol2 = c - 1;
+                    trow2 = r - 1;
+                }
             }
         }
     // ---- the bounds, as the kernel assembles them ----
@@ -208,6 +222,17 @@ bool check_read(const Scheme& s, const SeedParams& p, const std::vector<uint32_t
         if (best0 != truth || row0 != trow || col0 != tcol) {
             printf("passing read with wrong ends: band %d (%d,%d), truth %d (%d,%d)\n", best0, row0, col0, truth, trow, tcol);
             ok = false;
+        }
+        if (n_best0 != n_truth) {  // mode 3: every cell holding the maximum is a cell of the band holding S'
+            printf("passing read (ends): %d cells of the band hold S' = %d, %d cells of the matrix hold the maximum\n", n_best0, best0, n_truth);
+            ok = false;
+        }
+        if (n_best0 == 1) {
+            ++cnt->unique;
+            if (row0 != trow2 || col0 != tcol2) {
+                printf("unique maximum, but the transposed tie rule picks (%d,%d), the band (%d,%d)\n", trow2, tcol2, row0, col0);
+                ok = false;
+            }
         }
     }
     if (!ok) {
@@ -306,8 +331,8 @@ int main(int argc, char** argv) {
             all_ok = check_read(s, p, table, ref, q, kind <= 4, rnd(5, 30), &cnt);
         }
     }
-    printf("reads %ld, anchored %ld, passed (score) %ld, passed (ends) %ld; plain reads %ld, of which passed %ld\n", cnt.reads, cnt.anchored,
-           cnt.pass_score, cnt.pass_ends, cnt.plain, cnt.plain_pass);
+    printf("reads %ld, anchored %ld, passed (score) %ld, passed (ends) %ld, of which with the maximum in one cell %ld; plain reads %ld, of which passed %ld\n",
+           cnt.reads, cnt.anchored, cnt.pass_score, cnt.pass_ends, cnt.unique, cnt.plain, cnt.plain_pass);
     if (!all_ok) return 1;
     if (cnt.plain > 200 && cnt.plain_pass * 5 < cnt.plain) {
         printf("the checks are vacuous: fewer than a fifth of the plain reads pass\n");
