@@ -242,4 +242,4 @@ def test_diverged_reads_take_the_bail_out(za):
     with full_pass(ctx):
         want, t_full = timed()
     assert torch.equal(got.score, want.score) and torch.equal(got.status, want.status) and torch.equal(got.tier, want.tier)
-    assert t_pruned <= 1.10 * t_full, (t_pruned, t_full)
+    assert t_pruned <= 1.15 * t_full, (t_pruned, t_full)
