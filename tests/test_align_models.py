@@ -87,3 +87,15 @@ def test_banded_pass_bounds_model(tmp_path, seed):
     out = subprocess.run([_build(tmp_path, "seed_band"), "250", str(seed)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "seed_band OK" in out.stdout
+
+
+@pytest.mark.parametrize("seed", [3, 20261005])
+def test_reversed_pass_over_whole_sequences_model(tmp_path, seed):
+    """The shared role's sw_score_ranges runs its second pass over the whole reversed sequences (a seeded pass) instead of the
+    reversed prefixes of striped.rs:355-388 and accepts a read only if the forward maximum and the reversed maximum each sit in
+    one cell (zsw_capi_shared.hip, settle_reverse_kernel). Claim, against plain Gotoh matrices: with the forward maximum in one
+    cell, the cells holding the score in the reversed matrix of the prefixes and of the whole sequences are the same positions —
+    random schemes (asymmetric matrices, N scoring -1/0/+1, free gap extension), repeats, low-complexity pairs."""
+    out = subprocess.run([_build(tmp_path, "reverse_unique"), "4000", str(seed)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "reverse_unique OK" in out.stdout
