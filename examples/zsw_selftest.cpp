@@ -49,6 +49,25 @@ int main() {
             auto e = p.sw_score_ends(ref1);
             CHECK(e[0].is_some() && e[0].value.ref_end == 31 && e[0].value.query_end == 15, "striped.rs:153 sw_simd_score_ends = (31, 15)");
         }
+        {  // the same pair with the roles of sw/mod.rs:63-67: ONE profile from the reference, the read as the other sequence
+           // (SharedProfiles, profile_set.rs:552-560); SeqSrc::Query(read) hands the roles back (alignment/mod.rs:176-190)
+            zoe::SharedStripedProfile sp(ctx, ref1, m42, -3, -1, ZSW_I8, 32);
+            auto s = sp.sw_score({q1});
+            CHECK(s[0].is_some() && s[0].value == 26, "shared profile: sw_score = 26");
+            auto e = sp.sw_score_ends({q1});
+            CHECK(e[0].is_some() && e[0].value.ref_end == 15 && e[0].value.query_end == 31, "shared profile: sw_score_ends = (15 in the read, 31 in the sequence)");
+            auto r = sp.sw_score_ranges({q1});
+            CHECK(r[0].is_some() && r[0].value.ref_start == 0 && r[0].value.ref_end == 15 && r[0].value.query_start == 14 && r[0].value.query_end == 31,
+                  "shared profile: sw_score_ranges = read 0..15, sequence 14..31");
+            auto a = sp.sw_align({q1});  // SeqSrc::Query
+            CHECK(a[0].is_some() && a[0].value.score == 26 && a[0].value.cigar() == "6M2D9M3S" && a[0].value.ref_start == 14 && a[0].value.ref_end == 31,
+                  "shared profile: sw_align(SeqSrc::Query(read)) = 26, 6M2D9M3S, ref 14..31");
+            auto ar = sp.sw_align({q1}, false);  // SeqSrc::Reference: the read is the alignment's reference
+            CHECK(ar[0].is_some() && ar[0].value.cigar() == "14S6M2I9M1S", "shared profile: sw_align(SeqSrc::Reference(read)) = 14S6M2I9M1S");
+            zoe::SharedProfilesBatch sb(ctx, ref1, m42, -3, -1, 256);
+            auto ac = sb.sw_align_from_i8({q1});
+            CHECK(ac[0].is_some() && ac[0].value.cigar() == "6M2D9M3S" && sb.last_tiers()[0] == 8, "into_shared_profile(..).sw_align_from_i8(SeqSrc::Query(read)) = 6M2D9M3S at i8");
+        }
         {  // src/alignment/sw/mod.rs:164-188 and scalar.rs:165-169
             zoe::StripedProfileBatch p(ctx, {"CTCAGATTG"}, m42, -3, -1, ZSW_I8, 32);
             auto a = p.sw_align("GGCCACAGGATTGAG");

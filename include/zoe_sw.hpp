@@ -367,4 +367,166 @@ class LocalProfilesBatch : public ProfileBatchBase {
     std::vector<uint8_t> tier_;
 };
 
+// The other role of the striped functions (sw/mod.rs:63-67; SharedProfiles, profile_set.rs:552-560;
+// Nucleotides::into_shared_profile, nucleotides/mod.rs:295-299): ONE profile built from `sequence`, used against every read of a
+// batch — the reads are the sequences sw_simd_* walks row by row, so in the results `ref_*` is the read and `query_*` the profile
+// sequence unless seq_is_query (SeqSrc::Query(read), alignment/mod.rs:176-190) hands the roles back.
+class SharedProfileBase {
+  protected:
+    SharedProfileBase(GpuContext& ctx, const std::string& sequence, const WeightMatrix& matrix, int8_t gap_open, int8_t gap_extend) : ctx_(ctx) {
+        if (sequence.empty()) throw ProfileError(1);  // StripedProfile::new -> ProfileError::EmptySequence (profile.rs:32-44)
+        ctx_.check(zsw_set_scoring(ctx_.raw(), matrix.weights.data(), matrix.S, matrix.mapping->index_map.data(), gap_open, gap_extend));
+        ctx_.check(zsw_set_profile_sequence(ctx_.raw(), (const uint8_t*)sequence.data(), sequence.size(), ZSW_MEM_HOST));
+    }
+    // the reads as one host batch (an empty read is an empty `reference` argument: Unmapped, striped.rs:219-221)
+    struct HostReads {
+        std::vector<uint8_t> bases;
+        std::vector<uint64_t> offsets;
+        zsw_batch batch() const {
+            zsw_batch b;
+            b.bases = bases.data();
+            b.offsets = offsets.data();
+            b.fixed_len = 0;
+            b.n_reads = offsets.size() - 1;
+            b.mem = ZSW_MEM_HOST;
+            return b;
+        }
+    };
+    static HostReads pack(const std::vector<std::string>& reads) {
+        HostReads h;
+        h.offsets.push_back(0);
+        for (auto& r : reads) {
+            h.bases.insert(h.bases.end(), r.begin(), r.end());
+            h.offsets.push_back(h.bases.size());
+        }
+        return h;
+    }
+    template <typename Call>
+    std::vector<MaybeAligned<Alignment>> collect(size_t n, Call call) {
+        std::vector<zsw_alignment> aln(n);
+        std::vector<uint8_t> status(n);
+        std::vector<uint32_t> inc(16 * n + 64);
+        std::vector<uint8_t> op(inc.size());
+        uint64_t total = 0;
+        zsw_error e = call(aln.data(), status.data(), inc.data(), op.data(), (uint64_t)inc.size(), &total);
+        if (e == ZSW_ERR_INVALID_ARGUMENT && total > inc.size()) {
+            inc.resize(total);
+            op.resize(total);
+            e = call(aln.data(), status.data(), inc.data(), op.data(), (uint64_t)inc.size(), &total);
+        }
+        ctx_.check(e);
+        std::vector<MaybeAligned<Alignment>> out(n);
+        for (size_t i = 0; i < n; ++i) {
+            out[i].status = (Status)status[i];
+            if (status[i] != 0) continue;
+            Alignment& a = out[i].value;
+            a.score = aln[i].score;
+            a.ref_start = aln[i].ref_start;
+            a.ref_end = aln[i].ref_end;
+            a.query_start = aln[i].query_start;
+            a.query_end = aln[i].query_end;
+            a.ref_len = aln[i].ref_len;
+            a.query_len = aln[i].query_len;
+            for (uint32_t k = 0; k < aln[i].n_ciglets; ++k)
+                a.states.push_back({inc[aln[i].ciglet_offset + k], op[aln[i].ciglet_offset + k]});
+        }
+        return out;
+    }
+    GpuContext& ctx_;
+};
+
+// `StripedProfile::<T, N, S>::new(sequence, ..)` once; sw_score / sw_score_ends / sw_score_ranges / sw_align against a batch of reads
+class SharedStripedProfile : public SharedProfileBase {
+  public:
+    SharedStripedProfile(GpuContext& ctx, const std::string& sequence, const WeightMatrix& matrix, int8_t gap_open, int8_t gap_extend,
+                         zsw_int_type T, int N)
+        : SharedProfileBase(ctx, sequence, matrix, gap_open, gap_extend), T_(T), N_(N) {}
+    std::vector<MaybeAligned<uint32_t>> sw_score(const std::vector<std::string>& reads) {
+        const HostReads h = pack(reads);
+        const zsw_batch b = h.batch();
+        const size_t n = reads.size();
+        std::vector<uint32_t> score(n);
+        std::vector<uint8_t> status(n);
+        ctx_.check(zsw_score_shared_batch(ctx_.raw(), &b, T_, N_, score.data(), status.data(), nullptr));
+        std::vector<MaybeAligned<uint32_t>> out(n);
+        for (size_t i = 0; i < n; ++i) out[i] = {(Status)status[i], score[i]};
+        return out;
+    }
+    // ref_end: exclusive end in the read, query_end: in the profile sequence (first read position holding the maximum, then the
+    // first sequence position)
+    std::vector<MaybeAligned<ScoreEnds>> sw_score_ends(const std::vector<std::string>& reads) {
+        const HostReads h = pack(reads);
+        const zsw_batch b = h.batch();
+        const size_t n = reads.size();
+        std::vector<uint32_t> score(n), re(n), qe(n);
+        std::vector<uint8_t> status(n);
+        ctx_.check(zsw_score_ends_shared_batch(ctx_.raw(), &b, T_, N_, score.data(), re.data(), qe.data(), status.data(), nullptr));
+        std::vector<MaybeAligned<ScoreEnds>> out(n);
+        for (size_t i = 0; i < n; ++i) out[i] = {(Status)status[i], ScoreEnds{score[i], re[i], qe[i]}};
+        return out;
+    }
+    std::vector<MaybeAligned<ScoreAndRanges>> sw_score_ranges(const std::vector<std::string>& reads) {
+        const HostReads h = pack(reads);
+        const zsw_batch b = h.batch();
+        const size_t n = reads.size();
+        std::vector<uint32_t> score(n), rs(n), re(n), qs(n), qe(n);
+        std::vector<uint8_t> status(n);
+        ctx_.check(zsw_score_ranges_shared_batch(ctx_.raw(), &b, T_, N_, score.data(), rs.data(), re.data(), qs.data(), qe.data(), status.data(), nullptr));
+        std::vector<MaybeAligned<ScoreAndRanges>> out(n);
+        for (size_t i = 0; i < n; ++i) out[i] = {(Status)status[i], ScoreAndRanges{score[i], rs[i], re[i], qs[i], qe[i]}};
+        return out;
+    }
+    // seq_is_query = true: SeqSrc::Query(read) — the usual call when the profile is the reference
+    std::vector<MaybeAligned<Alignment>> sw_align(const std::vector<std::string>& reads, bool seq_is_query = true) {
+        const HostReads h = pack(reads);
+        const zsw_batch b = h.batch();
+        return collect(reads.size(), [&](zsw_alignment* aln, uint8_t* st, uint32_t* inc, uint8_t* op, uint64_t cap, uint64_t* total) {
+            return zsw_align_shared_batch(ctx_.raw(), &b, T_, N_, seq_is_query, aln, st, inc, op, cap, total, nullptr);
+        });
+    }
+
+  private:
+    zsw_int_type T_;
+    int N_;
+};
+
+// `sequence.into_shared_profile(&matrix, gap_open, gap_extend)`: SharedProfiles with the i8 -> i16 -> i32 cascade
+class SharedProfilesBatch : public SharedProfileBase {
+  public:
+    SharedProfilesBatch(GpuContext& ctx, const std::string& sequence, const WeightMatrix& matrix, int8_t gap_open, int8_t gap_extend,
+                        int preset_bits = 256)
+        : SharedProfileBase(ctx, sequence, matrix, gap_open, gap_extend), preset_(preset_bits) {}
+    std::vector<MaybeAligned<uint32_t>> sw_score_from_i8(const std::vector<std::string>& reads) { return score_from(reads, 8); }
+    std::vector<MaybeAligned<uint32_t>> sw_score_from_i16(const std::vector<std::string>& reads) { return score_from(reads, 16); }
+    std::vector<MaybeAligned<uint32_t>> sw_score_from_i32(const std::vector<std::string>& reads) { return score_from(reads, 32); }
+    std::vector<MaybeAligned<Alignment>> sw_align_from_i8(const std::vector<std::string>& reads, bool seq_is_query = true) { return align_from(reads, seq_is_query, 8); }
+    std::vector<MaybeAligned<Alignment>> sw_align_from_i16(const std::vector<std::string>& reads, bool seq_is_query = true) { return align_from(reads, seq_is_query, 16); }
+    std::vector<MaybeAligned<Alignment>> sw_align_from_i32(const std::vector<std::string>& reads, bool seq_is_query = true) { return align_from(reads, seq_is_query, 32); }
+    const std::vector<uint8_t>& last_tiers() const { return tier_; }
+
+  private:
+    std::vector<MaybeAligned<uint32_t>> score_from(const std::vector<std::string>& reads, int width) {
+        const HostReads h = pack(reads);
+        const zsw_batch b = h.batch();
+        const size_t n = reads.size();
+        std::vector<uint32_t> score(n);
+        std::vector<uint8_t> status(n);
+        tier_.assign(n, 0);
+        ctx_.check(zsw_score_shared_batch_from(ctx_.raw(), &b, width, preset_, score.data(), status.data(), tier_.data(), nullptr));
+        std::vector<MaybeAligned<uint32_t>> out(n);
+        for (size_t i = 0; i < n; ++i) out[i] = {(Status)status[i], score[i]};
+        return out;
+    }
+    std::vector<MaybeAligned<Alignment>> align_from(const std::vector<std::string>& reads, bool seq_is_query, int width) {
+        const HostReads h = pack(reads);
+        const zsw_batch b = h.batch();
+        tier_.assign(reads.size(), 0);
+        return collect(reads.size(), [&](zsw_alignment* aln, uint8_t* st, uint32_t* inc, uint8_t* op, uint64_t cap, uint64_t* total) {
+            return zsw_align_shared_batch_from(ctx_.raw(), &b, width, preset_, seq_is_query, aln, st, tier_.data(), inc, op, cap, total, nullptr);
+        });
+    }
+    int preset_;
+    std::vector<uint8_t> tier_;
+};
+
 }  // namespace zoe
