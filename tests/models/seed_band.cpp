@@ -8,7 +8,10 @@
 //   * hence a read whose bounds are all <= the band's maximum S' has S' as its score (all < S': also the first row and column);
 //   * mode 3 (the shared-profile role, zsw_capi_shared.hip): with all bounds < S' the cells of the whole matrix that hold the
 //     maximum are exactly the band's cells that hold S' — so "S' sits in one cell of the band" means "the maximum sits in one cell",
-//     and that cell is the answer under the other tie rule (first column, then first row) as well.
+//     and that cell is the answer under the other tie rule (first column, then first row) as well. The kernel's bookkeeping
+//     for that flag (per strip: maximum, row of the latest rise, a later row reaching it again, the columns of the snapshot row;
+//     strips merged) is restated here and must say exactly whether more than one cell of the band holds S' (dropping the
+//     tie events or the cross-strip rule is caught within a hundred iterations).
 // Reads, references and schemes as in seed_bounds.cpp. usage: seed_band <iterations> <seed>
 #include <algorithm>
 #include <cstdint>
@@ -94,6 +97,7 @@ bool check_read(const Scheme& s, const SeedParams& p, const std::vector<uint32_t
     auto clampneg = [](int x) { return x < NEG / 2 ? NEG : x; };
     int best0 = 0, row0 = -1, col0 = -1, best1 = 0, truth = 0, trow = -1, tcol = -1;
     int n_best0 = 0, n_truth = 0, trow2 = -1, tcol2 = -1;  // cells holding the two maxima; the truth under the transposed tie rule
+    bool ok_mode3 = true;
     int best_cls[NL] = {0, 0, 0, 0, 0};
     for (int r = 1; r <= R; ++r)
         for (int c = 1; c <= L; ++c) {
@@ -152,6 +156,46 @@ bool check_read(const Scheme& s, const SeedParams& p, const std::vector<uint32_t
                 }
             }
         }
+    // ---- mode 3's bookkeeping as seed_band_kernel<.., 3> keeps it: per strip the maximum, the row of its latest rise, whether a
+    // later row reached it again (a tie event), the columns of the snapshot row that hold it; strips merged by (higher, or equal:
+    // two cells). `mult` must say exactly whether more than one cell of the band holds S'.
+    {
+        int bbest = 0, brow = 0x7fffffff;
+        bool mult = false;
+        for (int k = 0; k < g.K; ++k) {
+            const int c_lo = k * C, c_hi = std::min(L, (k + 1) * C);  // real columns (padding columns only ever hold copies)
+            int sbest = 0, sr = 0x7fffffff, snaprow = -1;
+            bool sm = false;
+            for (int r = g.top(k); r < g.bot(k); ++r) {
+                int tmax = 0;
+                for (int c = c_lo; c < c_hi; ++c) tmax = std::max(tmax, at(H0, r + 1, c + 1));
+                const int nsb = std::max(sbest, tmax);
+                if (nsb > sbest) {
+                    sr = snaprow = r;
+                    sm = false;
+                } else if (tmax == nsb && nsb > 0) {
+                    sm = true;
+                }
+                sbest = nsb;
+            }
+            const bool eq = sbest == bbest && sbest > 0, up = sbest > bbest || (eq && sr < brow);
+            if (up) {
+                bbest = sbest;
+                brow = sr;
+            }
+            if (up || eq) {
+                int hits = 0;
+                for (int c = c_lo; c < c_hi && snaprow >= 0; ++c) hits += at(H0, snaprow + 1, c + 1) == sbest;
+                const int n = hits + (sm ? 1 : 0);
+                if (sbest > 0 && up && !eq) mult = n > 1;
+                else if (eq && n > 0) mult = true;
+            }
+        }
+        if (bbest != best0 || (best0 > 0 && mult != (n_best0 > 1))) {
+            printf("mode 3 bookkeeping: best %d (band %d), mult %d, cells of the band holding S' %d\n", bbest, best0, (int)mult, n_best0);
+            ok_mode3 = false;
+        }
+    }
     // ---- the bounds, as the kernel assembles them ----
     int m, stride, c0;
     zsw::seed_layout(L, p.K, p.spacer, &m, &stride, &c0);
@@ -194,7 +238,7 @@ bool check_read(const Scheme& s, const SeedParams& p, const std::vector<uint32_t
             bound_cls[XL] = std::max(bound_cls[XL], zsw::seed_band_lower(p, mk, mg, xl, L, g.wd, sr.t_all, m, c0, stride, qfb));
         }
     }
-    bool ok = true;
+    bool ok = ok_mode3;
     int bound = -1;
     static const char* const cls_name[NL] = {"", "fresh start above", "fresh start below", "upper exit", "lower exit"};
     for (int j = 1; j < NL; ++j) {
