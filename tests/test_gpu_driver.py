@@ -62,4 +62,4 @@ def test_cpp_mirror_known_answer_vectors():
     out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ALL PASSED" in out.stdout and "FAIL" not in out.stdout.replace("FAILED", "")
-    assert out.stdout.count("ok ") == 17
+    assert out.stdout.count("ok ") == 23
