@@ -136,6 +136,7 @@ unsafe extern "C" {
     fn zsw_timing_read(ctx: *mut ZswContext, seconds: *mut f64, launches: *mut u64) -> i32;
     fn zsw_timing_read_window(ctx: *mut ZswContext, seconds: *mut f64, launches: *mut u64) -> i32;
     fn zsw_debug_set(ctx: *mut ZswContext, flags: u32) -> i32;
+    fn zsw_debug_band_records(ctx: *mut ZswContext, records: *mut i32) -> i32;
     fn zsw_prune_rescored(ctx: *mut ZswContext, out_reads: *mut u64) -> i32;
     fn zsw_set_option(ctx: *mut ZswContext, option: i32, value: i64) -> i32;
 }
@@ -706,6 +707,15 @@ impl GpuContext {
     pub fn debug_set(&self, flags: u32) -> Result<(), GpuError> {
         // SAFETY: live context
         self.check(unsafe { zsw_debug_set(self.raw, flags) }, 0, 0)
+    }
+
+    /// `zsw_debug_band_records`: tests only — the banded seeded pass reports, per read, the values its decision rests on
+    /// (8 `i32` per read in device memory; null = off).
+    ///
+    /// # Safety
+    /// `records` must be null or device memory for `8 * n_reads` `i32` that outlives the following calls.
+    pub unsafe fn debug_band_records(&self, records: *mut i32) -> Result<(), GpuError> {
+        self.check(zsw_debug_band_records(self.raw, records), 0, 0)
     }
 
     /// `zsw_set_option(ZSW_OPTION_EXACT_PRUNING)`: the exact column-pruned first pass (same results for every input,

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../zoe_amd/csrc/zsw_seed.hpp"
+#include "adversarial_reads.hpp"
 
 namespace {
 
@@ -182,8 +183,11 @@ int main(int argc, char** argv) {
     std::mt19937_64 rng(seed);
     auto rnd = [&](int lo, int hi) { return lo + (int)(rng() % (uint64_t)(hi - lo + 1)); };
     const Scheme schemes[] = {dna(2, -5, 0, 10, 1), dna(1, -1, 0, 2, 1), dna(3, -2, 0, 5, 0), dna(1, -3, 0, 5, 2), dna(5, -4, 0, 8, 0),
-                              dna(2, -5, -1, 10, 1), dna(4, -6, 1, 12, 2), dna(2, -2, 0, 3, 3)};
+                              dna(2, -5, -1, 10, 1), dna(4, -6, 1, 12, 2), dna(2, -2, 0, 3, 3),
+                              // mismatch loss >= gap_open: lambda = gap_open, an insertion run is the cheapest way through a k-mer
+                              dna(2, -10, 0, 10, 1), dna(2, -5, 0, 5, 1), dna(3, -9, 0, 6, 1), dna(2, -10, 0, 10, 0)};
     Counters cnt;
+    long adversarial_reads = 0;
     bool all_ok = true;
     for (int it = 0; it < iters && all_ok; ++it) {
         const Scheme& s = schemes[it % (sizeof(schemes) / sizeof(schemes[0]))];
@@ -267,9 +271,30 @@ int main(int argc, char** argv) {
                 for (int x = rnd(1, 3); x > 0; --x) q[rnd(0, L - 1)] = 4;
             all_ok = check_read(s, p, table, ref, q, plain && kind <= 4, rnd(0, 3) ? 0 : rnd(0, 12), rnd(0, 3) ? 0 : rnd(0, 12), &cnt);
         }
+        // structured cases (adversarial_reads.hpp): residues without potential between the sampled k-mers, a far copy that skips
+        // them and an anchor copy that loses about twice lambda; each with a reference (and index) of its own
+        for (int k = 0; k < 24 && all_ok; ++k) {
+            std::vector<uint8_t> aref, aq;
+            SeedParams pa;
+            bool has[32] = {false};
+            has[0] = has[1] = has[2] = has[3] = true;
+            if (!zsw::seed_analyze(s.S, s.w.data(), s.go, s.ge, has, K, &pa)) break;
+            pa.M1 = p.M1;
+            pa.M1_per8 = p.M1_per8;
+            pa.M2 = p.M2;
+            pa.Dn = p.Dn;
+            pa.tol = p.tol;
+            if (rnd(0, 3) == 0) pa.spacer += rnd(0, 3);
+            if (!adversarial::spacer_case(rng, pa, rnd(2 * (K + pa.spacer), 96), &aref, &aq)) continue;
+            std::vector<uint32_t> atable((size_t)2 << (2 * K), 0);
+            zsw::seed_index_build(pa, aref.data(), (uint64_t)aref.size(), atable.data());
+            Counters unused;
+            all_ok = check_read(s, pa, atable, aref, aq, false, 0, 0, &unused);
+            ++adversarial_reads;
+        }
     }
-    printf("reads %ld, anchored %ld, passed (score) %ld, passed (ends) %ld; plain reads %ld, of which passed %ld\n", cnt.reads, cnt.anchored,
-           cnt.pass_score, cnt.pass_ends, cnt.plain, cnt.plain_pass);
+    printf("reads %ld, anchored %ld, passed (score) %ld, passed (ends) %ld; plain reads %ld, of which passed %ld; structured cases %ld\n", cnt.reads,
+           cnt.anchored, cnt.pass_score, cnt.pass_ends, cnt.plain, cnt.plain_pass, adversarial_reads);
     if (!all_ok) return 1;
     if (cnt.plain > 200 && cnt.plain_pass * 4 < cnt.plain) {
         printf("the checks are vacuous: fewer than a quarter of the plain reads pass\n");

@@ -13,6 +13,7 @@
 
 #include "../../oracle/zoe_oracle.hpp"
 #include "../../zoe_amd/csrc/zsw_seed.hpp"
+#include "adversarial_reads.hpp"
 
 using namespace zor;
 
@@ -44,8 +45,9 @@ int main(int argc, char** argv) {
     struct Sch {
         int match, mismatch, go, ge;
     };
-    const Sch schemes[] = {{2, -5, 10, 1}, {1, -1, 2, 1}, {3, -2, 5, 1}, {1, -3, 5, 2}, {5, -4, 8, 1}, {2, -2, 3, 3}, {4, -6, 12, 2}};
-    long reads = 0, certified = 0, late_rows = 0;
+    const Sch schemes[] = {{2, -5, 10, 1}, {1, -1, 2, 1}, {3, -2, 5, 1}, {1, -3, 5, 2}, {5, -4, 8, 1}, {2, -2, 3, 3}, {4, -6, 12, 2},
+                           {2, -10, 10, 1}, {2, -5, 5, 1}};  // the last two: mismatch loss >= gap_open (lambda = gap_open)
+    long reads = 0, certified = 0, late_rows = 0, structured = 0;
     for (int it = 0; it < iters; ++it) {
         const Sch& sc = schemes[it % (sizeof(schemes) / sizeof(schemes[0]))];
         const WeightMatrixI8 wm = WeightMatrixI8::make(map, (int8_t)sc.match, (int8_t)sc.mismatch, 'N');
@@ -82,6 +84,41 @@ int main(int argc, char** argv) {
         p.tol = rnd(0, 5);
         std::vector<uint32_t> table((size_t)2 << (2 * K), 0);
         zsw::seed_index_build(p, res.data(), (uint64_t)R, table.data());
+        // one read against one reference (and its index): a certificate must not change the alignment. Returns false on a violation.
+        auto check = [&](const std::vector<uint8_t>& ref, const std::vector<uint8_t>& q, const zsw::SeedParams& p, const std::vector<uint32_t>& table) -> bool {
+            const int R = (int)ref.size(), L = (int)q.size();
+            ++reads;
+            auto cell = [&](int c) { return zsw::seed_cell(p, (int)map.to_index(q[c])); };
+            auto look = [&](uint32_t code, uint32_t* f1, uint32_t* l1) {
+                *f1 = table[2 * (size_t)code];
+                *l1 = table[2 * (size_t)code + 1];
+            };
+            const zsw::SeedRead sr = zsw::seed_read(p, L, cell, look);
+            if (!sr.ok) return true;
+            // the read's score (any lane count: the score is layout-invariant)
+            auto prof = StripedProfile<int16_t, 8>::make(q.data(), (size_t)L, pw, map, -sc.go, -sc.ge);
+            uint32_t S = 0;
+            if (sw_simd_score<int16_t, 8>(ref.data(), (size_t)R, prof, &S) != SOME) return true;
+            const int r0 = zsw::seed_safe_start(p, sr.t_all, sr.d_fa, sr.dt, (int)S);
+            if (r0 < 0) return true;
+            if (r0 >= R) return true;
+            ++certified;
+            late_rows += r0;
+            bool mapped = false;
+            const bool ok = same_alignment<4>(ref.data(), (size_t)R, q.data(), (size_t)L, pw, map, sc.go, sc.ge, r0, &mapped) &&
+                            same_alignment<8>(ref.data(), (size_t)R, q.data(), (size_t)L, pw, map, sc.go, sc.ge, r0, &mapped) &&
+                            same_alignment<16>(ref.data(), (size_t)R, q.data(), (size_t)L, pw, map, sc.go, sc.ge, r0, &mapped);
+            if (!ok) {
+                printf("late start changes the alignment: r0 %d, S %u, t_all %d, d_fa %d, dt %d, go %d ge %d match %d mismatch %d K %d\n  ref  ", r0, S,
+                       sr.t_all, sr.d_fa, sr.dt, sc.go, sc.ge, sc.match, sc.mismatch, K);
+                for (uint8_t x : ref) putchar(x);
+                printf("\n  read ");
+                for (uint8_t x : q) putchar(x);
+                printf("\n");
+                return false;
+            }
+            return true;
+        };
         for (int k = 0; k < 40; ++k) {
             const int L = rnd(K + 4, std::min(R, 100));
             std::vector<uint8_t> q;
@@ -105,39 +142,32 @@ int main(int argc, char** argv) {
                 int j = i - (L - cut) + skip;
                 for (int c = cut; c < L; ++c, ++j) q[c] = (j >= 0 && j < R) ? ref[j] : keys[rnd(0, 3)];
             }
-            ++reads;
-            auto cell = [&](int c) { return zsw::seed_cell(p, (int)map.to_index(q[c])); };
-            auto look = [&](uint32_t code, uint32_t* f1, uint32_t* l1) {
-                *f1 = table[2 * (size_t)code];
-                *l1 = table[2 * (size_t)code + 1];
-            };
-            const zsw::SeedRead sr = zsw::seed_read(p, L, cell, look);
-            if (!sr.ok) continue;
-            // the read's score (any lane count: the score is layout-invariant)
-            auto prof = StripedProfile<int16_t, 8>::make(q.data(), (size_t)L, pw, map, -sc.go, -sc.ge);
-            uint32_t S = 0;
-            if (sw_simd_score<int16_t, 8>(ref.data(), (size_t)R, prof, &S) != SOME) continue;
-            const int r0 = zsw::seed_safe_start(p, sr.t_all, sr.d_fa, sr.dt, (int)S);
-            if (r0 < 0) continue;
-            if (r0 >= R) continue;
-            ++certified;
-            late_rows += r0;
-            bool mapped = false;
-            const bool ok = same_alignment<4>(ref.data(), (size_t)R, q.data(), (size_t)L, pw, map, sc.go, sc.ge, r0, &mapped) &&
-                            same_alignment<8>(ref.data(), (size_t)R, q.data(), (size_t)L, pw, map, sc.go, sc.ge, r0, &mapped) &&
-                            same_alignment<16>(ref.data(), (size_t)R, q.data(), (size_t)L, pw, map, sc.go, sc.ge, r0, &mapped);
-            if (!ok) {
-                printf("late start changes the alignment: r0 %d, S %u, t_all %d, d_fa %d, dt %d, go %d ge %d match %d mismatch %d K %d\n  ref  ", r0, S,
-                       sr.t_all, sr.d_fa, sr.dt, sc.go, sc.ge, sc.match, sc.mismatch, K);
-                for (uint8_t x : ref) putchar(x);
-                printf("\n  read ");
-                for (uint8_t x : q) putchar(x);
-                printf("\n");
-                return 1;
-            }
+            if (!check(ref, q, p, table)) return 1;
+        }
+        for (int k = 0; k < 16; ++k) {  // structured cases (adversarial_reads.hpp), each with a reference and an index of its own
+            zsw::SeedParams pa;
+            bool has[32] = {false};
+            has[0] = has[1] = has[2] = has[3] = true;
+            if (!zsw::seed_analyze(5, w, sc.go, sc.ge, has, K, &pa)) break;
+            pa.M1 = p.M1;
+            pa.M1_per8 = p.M1_per8;
+            pa.M2 = p.M2;
+            pa.Dn = p.Dn;
+            pa.tol = p.tol;
+            std::vector<uint8_t> ares, aq;
+            if (!adversarial::spacer_case(rng, pa, rnd(2 * (K + pa.spacer), 100), &ares, &aq)) continue;
+            std::vector<uint32_t> atable((size_t)2 << (2 * K), 0);
+            zsw::seed_index_build(pa, ares.data(), (uint64_t)ares.size(), atable.data());
+            std::vector<uint8_t> aref(ares.size()), aread(aq.size());
+            for (size_t i = 0; i < ares.size(); ++i) aref[i] = keys[ares[i]];
+            for (size_t i = 0; i < aq.size(); ++i) aread[i] = keys[aq[i]];
+            const long before = reads;
+            if (!check(aref, aread, pa, atable)) return 1;
+            reads = before;  // (not part of the vacuity count)
+            ++structured;
         }
     }
-    printf("reads %ld, certified %ld, mean late-start row %.1f\n", reads, certified, certified ? (double)late_rows / certified : 0.0);
+    printf("reads %ld, certified %ld, mean late-start row %.1f; structured cases %ld\n", reads, certified, certified ? (double)late_rows / certified : 0.0, structured);
     if (certified * 5 < reads) {
         printf("the certificate is vacuous: fewer than a fifth of the reads get one\n");
         return 1;

@@ -77,13 +77,19 @@ def test_late_start_certificate_model(tmp_path, seed):
 
 @pytest.mark.parametrize("seed", [20261004, 7, 41])
 def test_banded_pass_bounds_model(tmp_path, seed):
-    """The banded form of the seeded pass for score-only calls (zoe_amd/csrc/zsw_score_band.hip; bounds: zsw_seed.hpp,
-    seed_band_upper / seed_band_lower / seed_gap_up / seed_gap_down), against a layered Gotoh DP that classes every path with a
-    cell outside the band by how it first got there — a fresh start above / below the band, an exit through a strip's right edge,
-    an exit through a strip's last row — and checks each class's best path against that class's own bound, for every read
-    (passing or not), so that a weak bound cannot hide behind a larger one; a passing read has the true score (and, with the
-    strict checks, the true first row and column). Exact copies, errors, chimeras, long deletions / insertions, overhanging and
-    random reads; free gap extension; strips of 5-30 columns; band widths of a few diagonals."""
+    """The banded form of the seeded pass (zoe_amd/csrc/zsw_score_band.hip) in its injected form (zsw_seed.hpp, "banded pass"):
+    what enters the band from outside is an upper bound of the outside cell's value — from two bound programmes along the query
+    columns, one per side (seed_col_step / seed_col_join / seed_strip_events / seed_exit_is_free) —, doubled and made odd, so that
+    an even maximum is the score of a real path inside the band that no path through an outside cell reaches. The model walks
+    a read as the kernel does and checks against the full Gotoh matrix, for every read whether accepted or not: every cell of the
+    band holds a bound >= its true H; every cell above / below the band is <= a(c) / b(c) of its column and <= oa / ob; what the
+    next strip's first column receives covers the cells left of it; per class of paths (wholly outside; leaving strip k through
+    its right edge / its last row) the class's best path stays under the bound programme of that class alone, so that a weak
+    bound cannot hide behind a larger one; an accepted read has the true score (ends tag: the true first row and column, and the
+    true number of cells holding the maximum). Copies with 0-12 % substitutions + indels, chimeras, long deletions / insertions,
+    overhanging and random reads, structured cases (residues without potential between the sampled k-mers, tests/models/
+    adversarial_reads.hpp); eleven schemes (free gap extension, mismatch loss >= gap_open); strips of 5-32 columns, bands of a few
+    diagonals, lane partners that widen the band or add strips of padding."""
     out = subprocess.run([_build(tmp_path, "seed_band"), "250", str(seed)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "seed_band OK" in out.stdout

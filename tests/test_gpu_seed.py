@@ -247,7 +247,7 @@ def test_every_length_class_of_a_large_ragged_batch_takes_the_seeded_pass(za):
     prof = za.LocalProfilesBatch.new_with_w256(rb, dna, -10, -1)
     got = prof.sw_score_from_i8(ref)
     back = ctx.prune_rescored()
-    assert 0.023 * n < back < 0.04 * n, back
+    assert 0.019 * n < back < 0.04 * n, back  # the 2 % random reads of every class, and little else
     ctx.set_option(_lib.OPTION_EXACT_PRUNING, 0)
     try:
         full = prof.sw_score_from_i8(ref)

@@ -37,7 +37,7 @@ SYMBOLS = [
     "zsw_set_profile_sequence", "zsw_score_shared_batch", "zsw_score_shared_batch_from", "zsw_score_ends_shared_batch", "zsw_score_ranges_shared_batch",
     "zsw_score_ranges_shared_batch_from", "zsw_align_shared_batch", "zsw_align_shared_batch_from",
     "zsw_synth_reads", "zsw_synth_reads_ragged", "zsw_synth_length", "zsw_synth_reference_host", "zsw_synth_reads_host",
-    "zsw_synth_reads_ragged_host", "zsw_selftest", "zsw_timing_enable", "zsw_timing_read", "zsw_timing_read_window", "zsw_debug_set", "zsw_prune_rescored", "zsw_set_option",
+    "zsw_synth_reads_ragged_host", "zsw_selftest", "zsw_timing_enable", "zsw_timing_read", "zsw_timing_read_window", "zsw_debug_set", "zsw_debug_band_records", "zsw_prune_rescored", "zsw_set_option",
     "zsw_group_create", "zsw_group_destroy", "zsw_group_size", "zsw_group_context", "zsw_group_last_error_string", "zsw_group_set_scoring",
     "zsw_group_set_reference", "zsw_group_score_batch_from", "zsw_group_score_batch_from_device", "zsw_group_align_batch_from",
     "zsw_group_align_3pass_batch_from",
@@ -132,6 +132,7 @@ def load() -> C.CDLL:
     lib.zsw_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.zsw_timing_read_window.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.zsw_debug_set.argtypes = [vp, C.c_uint32]
+    lib.zsw_debug_band_records.argtypes = [vp, vp]
     lib.zsw_prune_rescored.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.zsw_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.zsw_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]

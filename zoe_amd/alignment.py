@@ -254,6 +254,14 @@ class SwContext:
         """zsw_debug_set: kernel-selection overrides (_lib.DEBUG_*) for the parity tests; 0 restores the defaults."""
         self.check(self.lib.zsw_debug_set(self.h, int(flags)))
 
+    def debug_band_records(self, records=None):
+        """zsw_debug_band_records (tests): the banded seeded pass writes 8 int32 per read — the values its decision rests on —
+        into `records` (a CUDA int32 tensor of 8 * n_reads elements that the caller keeps alive); None switches it off."""
+        if records is not None:
+            assert records.is_cuda and records.dtype == _torch().int32 and records.is_contiguous()
+        self._band_records = records
+        self.check(self.lib.zsw_debug_band_records(self.h, C.c_void_p(records.data_ptr() if records is not None else None)))
+
     def set_profile_sequence(self, sequence: bytes):
         """zsw_set_profile_sequence: the sequence the shared profile is built from (skipped when it is the one already set)"""
         sequence = bytes(sequence)

@@ -168,7 +168,7 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
             // (ragged: the classes' sort temporaries and round-ups, and SEED_BAND_CLASS_MIN_GRID blocks of boundary buffer each)
             const size_t want = seed_workspace_bytes(n, st->max_len) + 24 * seed_workspace_bytes(0, st->max_len) +
                                 (reads->offsets ? 24 * seed_workspace_bytes(std::min<uint32_t>(n, 2 * SEED_BAND_CLASS_MIN_GRID * 256), st->max_len, SEED_BAND_CLASS_MIN_GRID) : 0);
-            if (ctx->d_seed_work.ensure(want) == hipSuccess && ctx->d_seed_gtab.ensure((seq_len + 2 * SEED_GTAB_PAD) * 8) == hipSuccess &&
+            if (ctx->d_seed_work.ensure(want) == hipSuccess && ctx->d_seed_gtab.ensure(2 * (seq_len + 2 * SEED_GTAB_PAD) * 8) == hipSuccess &&
                 ctx->d_prune_list.ensure((size_t)n * 4 + 4) == hipSuccess &&
                 ctx->d_prune_count.ensure(64 * 4) == hipSuccess) {
                 ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 64 * 4, stream));  // [1] the call's total, [0], [2..] lists in flight
@@ -229,6 +229,7 @@ ScoreWorkspace score_ws(zsw_context* ctx) {
         w.seed_work = ctx->d_seed_work.as<uint8_t>();
         w.seed_bytes = ctx->d_seed_work.cap;
         w.seed_gtab = ctx->d_seed_gtab.as<uint2>();
+        w.band_dbg = ctx->band_dbg;
         w.window_timer = &ctx->timer_window;
         w.prune_fail_list = ctx->d_prune_list.as<uint32_t>();
         w.prune_fail_count = ctx->d_prune_count.as<uint32_t>();
@@ -1180,6 +1181,12 @@ zsw_error zsw_selftest(zsw_context* ctx) {
 zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags) {
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     ctx->debug = flags;
+    return ZSW_OK;
+}
+
+zsw_error zsw_debug_band_records(zsw_context* ctx, int32_t* records) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    ctx->band_dbg = records;
     return ZSW_OK;
 }
 

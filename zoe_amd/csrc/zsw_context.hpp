@@ -68,6 +68,7 @@ struct zsw_context {
     zsw::KernelTimer timer_window;  // seed_window_kernel launches alone
     std::string err;
     uint32_t debug = 0;    // zsw_debug_set (kernel-selection overrides for tests)
+    int32_t* band_dbg = nullptr;  // zsw_debug_band_records (tests: the banded seeded pass reports the values it decides with)
     uint32_t options = ZSW_DEBUG_SCORE_PRUNE;  // zsw_set_option, as ZSW_DEBUG_* bits; exact pruning is on by default
     uint32_t flags() const { return debug | options; }
     // host batches: reads of chunk k+1 cross PCIe on this stream while chunk k computes

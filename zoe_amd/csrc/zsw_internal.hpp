@@ -109,7 +109,9 @@ struct ScoreWorkspace {
     uint8_t* seed_work = nullptr;
     size_t seed_bytes = 0;
     KernelTimer* window_timer = nullptr;  // events around the window kernel of the seeded pass (bench.py's roofline)
-    uint2* seed_gtab = nullptr;   // ref_len + 2 * SEED_GTAB_PAD entries: the per-row score table for blocks without an LDS table
+    uint2* seed_gtab = nullptr;   // 2 x (ref_len + 2 * SEED_GTAB_PAD) entries: the per-row score table for blocks without an LDS table, then
+                                  // the same with every score doubled (the banded kernel's domain, zsw_score_band.hip)
+    int32_t* band_dbg = nullptr;  // zsw_debug_band_records
     uint32_t debug = 0;           // ZSW_DEBUG_* bits of the context (zsw_debug_set) | its options: kernel-selection overrides
 };
 

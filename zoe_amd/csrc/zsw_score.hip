@@ -287,6 +287,16 @@ static bool build_tables_v2(const ScoringDev& s, int G, ScoreArgsV2* a) {
     return v2_range_setup(s, G, a);
 }
 
+// The banded seeded kernel's tables: every weight and gap penalty doubled (strip width 1: a lane owns whole strips). false when the
+// doubled weights do not fit the table bytes.
+static bool doubled_tables(const ScoringDev& s, ScoreArgsV2* a) {
+    ScoringDev d = s;
+    for (int i = 0; i < s.S * s.S; ++i) d.w[i] = 2 * s.w[i];
+    d.gap_open = 2 * s.gap_open;
+    d.gap_extend = 2 * s.gap_extend;
+    return v2_ok(d, 0) && build_tables_v2(d, 1, a);
+}
+
 // WIDE kernels: 8..32 letters, every score + ge must fit a signed byte.
 static bool wide_ok(const ScoringDev& s, uint32_t debug) {
     if (debug & ZSW_DEBUG_NO_WIDE) return false;
@@ -536,16 +546,25 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         if (!build_tables_v2(h_sc, g, &ap) || !seed_applicable(*ws.seed, longest, ref_len, ap.limit)) return hipErrorNotSupported;
         if (!ws.seed_gtab) return hipErrorNotSupported;
         hipError_t pe = hipSuccess;
+        // the banded kernel works on doubled scores (zsw_seed.hpp: an odd value marks a path through a cell outside the band): its own
+        // drift constants and per-row table, if the doubled weights fit the table bytes
+        ScoreArgsV2 ab = a2;
+        const bool band_ok = !(ws.debug & ZSW_DEBUG_SEED_NO_BAND) && doubled_tables(h_sc, &ab);
+        uint2* const gtab_band = ws.seed_gtab + (ref_len + 2 * SEED_GTAB_PAD);
         if (!gtab_built) {  // the per-row score table, for blocks whose windows do not fit one LDS table (same bytes for every g)
             pe = seed_build_gtab(ap, ws.seed_gtab, stream);
             if (pe != hipSuccess) return pe;
+            if (band_ok) {
+                pe = seed_build_gtab(ab, gtab_band, stream);
+                if (pe != hipSuccess) return pe;
+            }
             gtab_built = true;
         }
         pe = hipMemsetAsync(counter, 0, 4, stream);
         if (pe != hipSuccess) return pe;
         ap.b = bb;
         pe = launch_score_seeded(ap, g, c, longest, *ws.seed, ws.seed_work + work_off, seed_workspace_bytes(bb.n_items, longest, band_grid_cap), ws.seed_gtab,
-                                 ws.prune_fail_list + list_off, counter, mode, !(ws.debug & ZSW_DEBUG_SEED_NO_BAND),
+                                 ws.prune_fail_list + list_off, counter, mode, band_ok ? &ab : nullptr, gtab_band, ws.band_dbg,
                                  (ws.debug & ZSW_DEBUG_SEED_WIDE_BAND) ? 0xffffffffu : (ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE) ? 0u : SEED_NARROW_MIN_READS, band_grid_cap, stream,
                                  ws.window_timer);
         if (pe != hipSuccess) return pe;
@@ -639,6 +658,11 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
             if (build_tables_v2(h_sc, 4, &ag)) {
                 e = seed_build_gtab(ag, ws.seed_gtab, stream);
                 if (e != hipSuccess) return e;
+                ScoreArgsV2 ab = a2;
+                if (!(ws.debug & ZSW_DEBUG_SEED_NO_BAND) && doubled_tables(h_sc, &ab)) {
+                    e = seed_build_gtab(ab, ws.seed_gtab + (ref_len + 2 * SEED_GTAB_PAD), stream);
+                    if (e != hipSuccess) return e;
+                }
                 gtab_built = true;
             }
         }

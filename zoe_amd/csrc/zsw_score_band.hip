@@ -6,14 +6,17 @@
 // (16-bit halves, as everywhere) and walks it strip by strip: strip k = query columns [kC, (k+1)C) in registers (score_kernel_v2's
 // packed column loop) against the reference rows [dt + kC - Wu, dt + (k+1)C + Wd) only, the strip's last column (H, outgoing F,
 // true scores) handed to the next strip through a per-lane buffer in global memory (8 bytes per row, written and re-read once).
-// No lane talks to another. What lies outside the band is covered by the bounds of zsw_seed.hpp ("banded pass": fresh starts
-// above / below the band, exits through a strip's right edge above the next strip's first row, exits through a strip's last
-// row); host model against a layered Gotoh DP, one layer per class of paths: tests/models/seed_band.cpp. The launch's band
-// (SeedBandArgs::wu0 ...) is either the full one or, for short reads, a narrow first tier whose failures are flagged in place
-// (`retry`), selected in anchor order and walked again in the full band (launch_score_seeded, zsw_score_seed.hip); a read whose
-// bounds fail in the last tier joins the same worklist as in the window kernel and is scored over all its cells.
-// 150 bp: 5 strips x 63 (narrow) or 92 (full) rows x 32 columns per pair in one lane instead of 4 lanes x 211 steps x 38 columns.
+// No lane talks to another.
+// What lies outside the band enters it as an UPPER BOUND, not as zero (zsw_seed.hpp, "banded pass"): every score is doubled, a
+// value that comes from outside is odd, and the two bound programmes along the columns (SeedColDP: what a path above / below
+// the band can hold after each column, k-mer by k-mer) run between the strips. An even maximum is the score of a real path
+// inside the band that no path through an outside cell reaches; the reads whose maximum is odd, or below what a path ending
+// outside may score, are flagged (`retry`: walked again in the launch's wider band, launch_score_seeded) or join the worklist
+// of reads scored over all their cells. Host model, cell by cell against the full Gotoh matrix: tests/models/seed_band.cpp; the
+// same model as a library checks this kernel's own values (maximum, oa, ob) on the GPU: tests/test_gpu_bounds.py.
+// 150 bp: 5 strips x 46 (narrow) or 92 (full) rows x 32 columns per pair in one lane instead of 4 lanes x 211 steps x 38 columns.
 #include <algorithm>
+#include <type_traits>
 
 #include "zsw_score_seed.hpp"
 #include "zsw_score_v2.hpp"
@@ -23,19 +26,98 @@ namespace zsw {
 
 namespace {
 
-// a - b per 16-bit half, 0 where b > a (v_pk_sub_u16 with clamp)
-__device__ __forceinline__ uint32_t pk_subu_sat(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
-}
-
 constexpr int BC = 32;  // columns per strip (a multiple of 8: a strip's residue codes are whole dwords of the packed reads; MODE 3 keeps
                         // one bit per column in a 32-bit mask)
 
+// What the kernel keeps per lane between strips, in LDS ([field][lane]: the registers of the row loop hold nothing but the strip):
+// the k-mer layout and masks of the lane's two reads, and the two bound programmes of zsw_seed.hpp (SeedColDP) for BOTH reads at
+// once — 16-bit halves like everything else, the tracks biased by PKB so that "no such path" (0) stays below every real value.
+// The host model (tests/models/seed_band.cpp) runs the same programmes with plain integers through the header's functions;
+// tests/test_gpu_bounds.py requires this kernel's values to equal the model's.
+enum BandField {
+    BF_M_A, BF_STRIDE_A, BF_C0_A, BF_MAGIC_A, BF_MASKS_A, BF_M_B, BF_STRIDE_B, BF_C0_B, BF_MAGIC_B, BF_MASKS_B, BF_LAM2,
+    BF_UP_CH, BF_UP_FR, BF_LO_CH, BF_LO_FR, BF_OA, BF_OB, BF_YH, BF_YF, BF_N
+};
+constexpr uint32_t PKB = 0x2000u, PKB2 = PKB * 0x00010001u;
+
+struct BandLayout {
+    int m, stride, c0;
+    uint32_t magic, fa, fb;
+};
+struct BandPk {
+    uint32_t ch, fr;  // pays / does not pay for the next k-mer of the mask that ends (per half: value + PKB, 0 = none)
+};
+
+__device__ __forceinline__ void band_lane_init(const SeedParams& p, int* st, int lenA, uint32_t masksA, int lenB, uint32_t masksB) {
+    int m, stride, c0;
+    seed_layout(lenA, p.K, p.spacer, &m, &stride, &c0);
+    st[BF_M_A * BLOCK] = m;
+    st[BF_STRIDE_A * BLOCK] = stride;
+    st[BF_C0_A * BLOCK] = c0;
+    st[BF_MAGIC_A * BLOCK] = (int)seed_div_magic(stride);
+    st[BF_MASKS_A * BLOCK] = (int)masksA;
+    const uint32_t lamA = (uint32_t)seed_lambda(p, stride);
+    seed_layout(lenB, p.K, p.spacer, &m, &stride, &c0);
+    st[BF_M_B * BLOCK] = m;
+    st[BF_STRIDE_B * BLOCK] = stride;
+    st[BF_C0_B * BLOCK] = c0;
+    st[BF_MAGIC_B * BLOCK] = (int)seed_div_magic(stride);
+    st[BF_MASKS_B * BLOCK] = (int)masksB;
+    st[BF_LAM2 * BLOCK] = (int)(lamA | ((uint32_t)seed_lambda(p, stride) << 16));
+    st[BF_UP_CH * BLOCK] = st[BF_LO_CH * BLOCK] = (int)PKB2;
+    st[BF_UP_FR * BLOCK] = st[BF_LO_FR * BLOCK] = 0;
+    st[BF_OA * BLOCK] = st[BF_OB * BLOCK] = 0;
+    st[BF_YH * BLOCK] = st[BF_YF * BLOCK] = 0;
+}
+__device__ __forceinline__ BandLayout band_layout(const int* st, bool second) {
+    BandLayout y;
+    const int o = second ? (BF_M_B - BF_M_A) * BLOCK : 0;
+    y.m = st[BF_M_A * BLOCK + o];
+    y.stride = st[BF_STRIDE_A * BLOCK + o];
+    y.c0 = st[BF_C0_A * BLOCK + o];
+    y.magic = (uint32_t)st[BF_MAGIC_A * BLOCK + o];
+    const uint32_t masks = (uint32_t)st[BF_MASKS_A * BLOCK + o];
+    y.fa = masks & 0xffffu;
+    y.fb = masks >> 16;
+    return y;
+}
+
+// 0xffff in the half whose read has bit c set
+__device__ __forceinline__ uint32_t half_mask(uint32_t bitsA, uint32_t bitsB, int c) {
+    const uint32_t mA = (uint32_t)__builtin_amdgcn_sbfe((int)bitsA, (uint32_t)c, 1u), mB = (uint32_t)__builtin_amdgcn_sbfe((int)bitsB, (uint32_t)c, 1u);
+    return __builtin_amdgcn_perm(mB, mA, 0x05040100u);
+}
+__device__ __forceinline__ uint32_t pk_subu_sat(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_shr1(uint32_t a) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) >> (us2){1, 1}); }
+// seed_tag / seed_untag per half: 2v + TAG, a bound of 0 stays the plain zero floor
+template <int TAG>
+__device__ __forceinline__ uint32_t pk_tag(uint32_t v) {
+    if (TAG < 0) return pk_maxu(v << 1, 0x00010001u) - 0x00010001u;
+    uint32_t nz;  // 1 in the halves that are not 0 (written as min(v, 1) the compiler turns it into four compares)
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(v), "v"(0x00010001u));
+    return (v << 1) | nz;
+}
+template <int TAG>
+__device__ __forceinline__ uint32_t pk_untag(uint32_t t2) {
+    return TAG > 0 ? pk_shr1(t2) : pk_shr1(pk_addu(t2, 0x00010001u));
+}
+// seed_col_step's events per half (sm / em: the halves in which a k-mer of the mask starts / ends in this column)
+__device__ __forceinline__ void pk_events(BandPk* t, uint32_t sm, uint32_t em, uint32_t lam2) {
+    t->fr = pk_maxu(t->fr, PKB2 & sm);
+    t->ch = pk_subu(t->ch, lam2 & em);
+    t->ch = pk_maxu(t->ch, t->fr & em);
+    t->fr &= ~em;
+}
+
 template <int C, int MINW, int MODE>
 __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) {
+    constexpr int TAG = MODE == 0 ? -1 : 1;
     __shared__ uint16_t sel_lut[16];
-    __shared__ uint16_t sq[BLOCK * 4 * (SEED_MAX_KMERS + 1)];  // per lane: seed_suffix_q of (read A, B) x (fa, fb), private slices
+    __shared__ int sst[BF_N * BLOCK];
     const int tid = threadIdx.x;
+    int* const st = sst + tid;
     if (tid < 16) {
         const uint32_t k = (uint32_t)tid;
         sel_lut[tid] = (uint16_t)(k < 4 ? (2 * k + 1) | ((8 + k) << 8) : (k == 15 ? 0x0c00u : (2 * (k - 3)) | 0x0c00u));
@@ -44,10 +126,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
     const int R = (int)a.ref_len;
     const uint32_t n_items = a.n_dev ? min(*a.n_dev, a.n) : a.n;
     const uint32_t n_pairs = (n_items + 1) / 2;
-    const uint32_t ge2 = a.ge2, gd2 = a.gd2;
+    const uint32_t ge2 = a.ge2, gd2 = a.gd2;  // doubled gap penalties (the tables hold doubled scores)
     const uint32_t ge1 = ge2 & 0xffffu;
-    const int maxw = a.sp.maxw;
-    uint16_t* q = sq + (size_t)tid * 4 * (SEED_MAX_KMERS + 1);
+    const uint32_t maxw2 = (uint32_t)a.sp.maxw * 0x00010001u, go2p = (uint32_t)a.sp.go * 0x00010001u;  // plain (not doubled) scores of the bound programmes
     uint2* bnd = a.bnd + (size_t)blockIdx.x * (size_t)a.nb * BLOCK + tid;  // row j of this lane: bnd[j * BLOCK]
 
     // Work queue: a wavefront takes the next 64 pairs of the anchor order (one atomic per wavefront), so that no lane waits for
@@ -88,38 +169,18 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
         const int n_strips = (lenmax + C - 1) / C;
         const int wu = a.wu0 + lenmax * a.wu_per16 / 16, wd = a.wd0 + lenmax * a.wd_per32 / 32;
         const int dtmin = min(dtA, dtB), dtmax = max(dtA, dtB);
-        // what the seed kernel left: potentials, k-mer bounds, masks; the suffix bounds of the two masks per read
+        // what the seed kernel left: the k-mer masks of the two sides; (potential and d_fa: seed_safe_start below)
         const uint32_t infoA = a.info[ridA], infoB = a.info[ridB];
-        const uint32_t mkA = a.band_masks[ridA], mkB = a.band_masks[ridB];
-        const int tallA = (int)(infoA & 0xffffu), tallB = (int)(infoB & 0xffffu);
-        const int dfaA = (int)((infoA >> 16) & 0xffu), dfaB = (int)((infoB >> 16) & 0xffu);
-        const int dfbA = (int)a.band_dfb[ridA], dfbB = (int)a.band_dfb[ridB];
-        int mA, strA, c0A, mB, strB, c0B;
-        seed_layout((int)lenA, a.sp.K, a.sp.spacer, &mA, &strA, &c0A);
-        seed_layout((int)lenB, a.sp.K, a.sp.spacer, &mB, &strB, &c0B);
-        {
-            int tmp[SEED_MAX_KMERS + 1];
-            seed_suffix_q(mA, a.sp.K, c0A, strA, (int)lenA, maxw, mkA & 0xffffu, seed_lambda(a.sp, strA), tmp);
-            for (int i = 0; i <= SEED_MAX_KMERS; ++i) q[i] = (uint16_t)tmp[i <= mA ? i : mA];
-            seed_suffix_q(mA, a.sp.K, c0A, strA, (int)lenA, maxw, mkA >> 16, seed_lambda(a.sp, strA), tmp);
-            for (int i = 0; i <= SEED_MAX_KMERS; ++i) q[(SEED_MAX_KMERS + 1) + i] = (uint16_t)tmp[i <= mA ? i : mA];
-            seed_suffix_q(mB, a.sp.K, c0B, strB, (int)lenB, maxw, mkB & 0xffffu, seed_lambda(a.sp, strB), tmp);
-            for (int i = 0; i <= SEED_MAX_KMERS; ++i) q[2 * (SEED_MAX_KMERS + 1) + i] = (uint16_t)tmp[i <= mB ? i : mB];
-            seed_suffix_q(mB, a.sp.K, c0B, strB, (int)lenB, maxw, mkB >> 16, seed_lambda(a.sp, strB), tmp);
-            for (int i = 0; i <= SEED_MAX_KMERS; ++i) q[3 * (SEED_MAX_KMERS + 1) + i] = (uint16_t)tmp[i <= mB ? i : mB];
-        }
-        const int gup = seed_gap_up(a.sp, wu);
-        const int gdnA = seed_gap_down(a.sp, wd, (int)lenA, tallA), gdnB = seed_gap_down(a.sp, wd, (int)lenB, tallB);
+        band_lane_init(a.sp, st, (int)lenA, a.band_masks[ridA], (int)lenB, validB ? a.band_masks[ridB] : 0u);
 
         const uint32_t* codeA = a.codes + (size_t)ridA * a.cs;
         const uint32_t* codeB = a.codes + (size_t)ridB * a.cs;
-        uint32_t best = 0;          // true scores
+        uint32_t best = 0;          // doubled scores, odd: held by a path that touched a cell outside the band
         // ends (MODE 1, 2): first row holding the maximum, then the first column of that row (striped.rs:296-321). A strip walks its
         // rows in order; strips overlap in rows, so each strip keeps its own (maximum, first row, H row of that row) and the strips
         // merge by (higher maximum, then earlier row; the same row in two strips: the earlier strip holds the earlier column).
         int bestA = 0, bestB = 0, rowA = 0x7fffffff, rowB = 0x7fffffff, colA = 0x7fffffff, colB = 0x7fffffff;
         bool multA = false, multB = false;  // MODE 3: the maximum so far sits in more than one (real) cell
-        int bndA = -1, bndB = -1;   // the exit bounds so far
         int prev_bot = 0;
 #pragma unroll 1
         for (int k = 0; k < n_strips; ++k) {
@@ -137,23 +198,55 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
             const int top = max(0, min(R, dtmin + k * C - wu)), bot = max(0, min(R, dtmax + (k + 1) * C + wd));
             const bool has_next = k + 1 < n_strips;
             const int next_top = max(0, min(R, dtmin + (k + 1) * C - wu));  // first row of the next strip
+            const int nrA = max(0, min(C, (int)lenA - k * C)), nrB = max(0, min(C, (int)lenB - k * C));  // the strip's real columns per read
             uint32_t Dr = (a.floor0 - ge1) * 0x00010001u;                   // D of the row before the strip's first row
+            // above the strip's columns: a(c) of either read; the strip's first row receives it (its E: less gap_open)
             uint32_t H[C], E[C];
+            const bool all_full = __ballot(nrA != C || nrB != C) == 0;  // no lane of the wavefront has a padding column in this strip
+            const uint32_t lam2 = (uint32_t)st[BF_LAM2 * BLOCK];
+            {
+                const BandLayout yA = band_layout(st, false), yB = band_layout(st, true);
+                const SeedStripEvents eA = seed_strip_events(k * C, C, yA.m, yA.c0, yA.stride, a.sp.K, yA.magic, yA.fa);
+                const SeedStripEvents eB = seed_strip_events(k * C, C, yB.m, yB.c0, yB.stride, a.sp.K, yB.magic, yB.fa);
+                const uint32_t any = eA.start | eA.end | eB.start | eB.end;
+                BandPk up;
+                up.ch = (uint32_t)st[BF_UP_CH * BLOCK];
+                up.fr = (uint32_t)st[BF_UP_FR * BLOCK];
+                uint32_t oa2 = (uint32_t)st[BF_OA * BLOCK];
+                const uint32_t above = top > 0 ? 0xffffffffu : 0u;
+                const uint32_t DrE = pk_addu(Dr, ge2);
+                auto sweep = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
+                    const uint32_t realA = nrA >= 32 ? 0xffffffffu : ((1u << nrA) - 1u), realB = nrB >= 32 ? 0xffffffffu : ((1u << nrB) - 1u);
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                H[c] = Dr;
-                E[c] = pk_addu(Dr, ge2);
+                    for (int c = 0; c < C; ++c) {
+                        up.ch += maxw2;
+                        up.fr += maxw2;
+                        if (__ballot((any >> c) & 1u) != 0) pk_events(&up, half_mask(eA.start, eB.start, c), half_mask(eA.end, eB.end, c), lam2);
+                        uint32_t v = pk_subu_sat(pk_maxu(up.ch, up.fr), PKB2) & above;
+                        if (!FULL) v &= half_mask(realA, realB, c);
+                        oa2 = pk_maxu(oa2, v);
+                        H[c] = pk_addu(Dr, pk_tag<TAG>(v));
+                        E[c] = pk_addu(DrE, pk_tag<TAG>(pk_subu_sat(v, go2p)));
+                    }
+                };
+                if (all_full) sweep(std::true_type{});
+                else sweep(std::false_type{});
+                st[BF_UP_CH * BLOCK] = (int)up.ch;
+                st[BF_UP_FR * BLOCK] = (int)up.fr;
+                st[BF_OA * BLOCK] = (int)oa2;
             }
-            // the previous strip's last column: rows [top - 1, prev_bot) wait in bnd[row - (top - 1)] as true scores
+            // the previous strip's last column: rows [top - 1, prev_bot) wait in bnd[row - (top - 1)] as true scores; below them the
+            // strip receives the bound of the cells below the previous strip
             const bool have_left = k > 0;
+            const uint32_t yh2 = have_left ? pk_tag<TAG>((uint32_t)st[BF_YH * BLOCK]) : 0u;
+            const uint32_t yf2 = have_left ? pk_tag<TAG>((uint32_t)st[BF_YF * BLOCK]) : 0u;
             uint32_t Hin_prev = Dr;
-            if (have_left && top >= 1 && top - 1 < prev_bot) Hin_prev = pk_addu(Dr, bnd[0].x);
+            if (have_left && top >= 1) Hin_prev = pk_addu(Dr, top - 1 < prev_bot ? bnd[0].x : yh2);
             uint2 w = a.gtab[SEED_GTAB_PAD + top];
             uint2 bl = make_uint2(0u, 0u);
             if (have_left && top < prev_bot) bl = bnd[(size_t)1 * BLOCK];
-            // exits through the right edge in the rows above the next strip: largest H / outgoing F of the last column, plain and
-            // less gap_extend per diagonal beyond the first outside the band's edge (seed_band_upper)
-            uint32_t uk = 0, ug = 0;
+            uint32_t uk = 0;                // the largest H leaving through the right edge in the rows above the next strip
             uint32_t sbest = 0, snapD = 0;  // this strip's maximum (true scores) and, MODE 2, the H row and drift of each read's latest rise
             int srA = 0x7fffffff, srB = 0x7fffffff;
             uint32_t snap[MODE >= 2 ? C : 1];
@@ -164,11 +257,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
             // MODE 3: the strip's real columns per read as bit masks (a padding column copies the value of its upper left
             // neighbour: a copy of the maximum is not a second cell holding it), and whether a row after the strip's latest rise
             // reached the same value again in a real column
-            const int nrA = max(0, min(C, (int)lenA - k * C)), nrB = max(0, min(C, (int)lenB - k * C));
             const uint32_t realA = nrA >= 32 ? 0xffffffffu : ((1u << nrA) - 1u), realB = nrB >= 32 ? 0xffffffffu : ((1u << nrB) - 1u);
             bool smA = false, smB = false;
-            const int e_top = (dtmin + (k + 1) * C - wu) - 1 - top;  // the first row's distance from the last row above the next strip
-            uint32_t dec = min(ge1 * (uint32_t)max(e_top - 1, 0), 0xffffu) * 0x00010001u;
 #pragma unroll 1
             for (int r = top; r < bot; ++r) {
                 const uint2 wn = a.gtab[SEED_GTAB_PAD + r + 1];
@@ -177,8 +267,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                 if (have_left && r + 1 < prev_bot) bln = bnd[(size_t)(r + 1 - top + 1) * BLOCK];
                 Dr = pk_addu(Dr, ge2);
                 const uint32_t Dn = pk_addu(Dr, ge2);
-                const uint32_t Hin = left ? pk_addu(Dr, bl.x) : Dr;
-                uint32_t F = left ? pk_addu(Dr, bl.y) : Dr;
+                const uint32_t Hin = pk_addu(Dr, left ? bl.x : yh2);
+                uint32_t F = pk_addu(Dr, left ? bl.y : yf2);
                 uint32_t hd = pk_addu(Hin_prev, __builtin_amdgcn_perm(w.y, w.x, sel[0]));
                 Hin_prev = Hin;
                 uint32_t rmax = 0x04000400u;
@@ -195,16 +285,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                     else if (c == C - 1) rmax = pk_max3(rmax, h, h);
                     hd = hd_next;
                 }
-                const uint32_t tH = pk_subu(H[C - 1], Dr), tF = pk_subu(F, Dr);  // true scores leaving the strip in this row
+                const uint32_t tH = pk_subu(H[C - 1], Dr);  // true (doubled) score leaving the strip in this row
                 if (has_next) {
-                    if (r >= next_top - 1) bnd[(size_t)(r - (next_top - 1)) * BLOCK] = make_uint2(tH, tF);
-                    if (r < next_top) {
-                        const uint32_t v = pk_maxu(tH, tF);
-                        uk = pk_maxu(uk, v);
-                        ug = pk_maxu(ug, pk_subu_sat(v, dec));
-                    }
+                    if (r >= next_top - 1) bnd[(size_t)(r - (next_top - 1)) * BLOCK] = make_uint2(tH, pk_subu(F, Dr));
+                    if (r < next_top) uk = pk_maxu(uk, tH);  // (the outgoing F of a cell never exceeds its H)
                 }
-                dec = pk_subu_sat(dec, ge2);
                 const uint32_t tmax = pk_subu(rmax, Dr);
                 if (MODE != 0) {
                     const uint32_t nsb = pk_maxu(sbest, tmax);
@@ -241,30 +326,6 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                 best = pk_maxu(best, tmax);
                 w = wn;
                 bl = bln;
-            }
-            // exits through the right edge above the next strip (they continue left of the band: fa mask, deletions to come back)
-            if (has_next && next_top > top) {
-                const int x = (k + 1) * C - 1;
-                bndA = max(bndA, seed_band_upper(a.sp, (int)(uk & 0xffffu), (int)(ug & 0xffffu), x, (int)lenA, wu, mA, c0A, strA, q));
-                bndB = max(bndB, seed_band_upper(a.sp, (int)(uk >> 16), (int)(ug >> 16), x, (int)lenB, wu, mB, c0B, strB, q + 2 * (SEED_MAX_KMERS + 1)));
-            }
-            // exits through the strip's last row (they continue below the band: fb mask, insertions to come back). Two packed
-            // maxima over the strip's columns serve both reads (seed_band_lower): the exit value plus the columns up to the strip's
-            // last at full potential, and the exit value less what the longer way back costs.
-            if (bot < R && bot > top) {
-                uint32_t mk = 0, mg = 0;
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const uint32_t he = pk_subu(pk_maxu(H[c], pk_subu(E[c], ge2)), Dr);
-                    const int e = C - 1 - c;
-                    mk = pk_maxu(mk, pk_addu(he, (uint32_t)(maxw * e) * 0x00010001u));
-                    mg = pk_maxu(mg, pk_addu(pk_subu_sat(he, (uint32_t)(ge1 * (uint32_t)(e > 1 ? e - 1 : 0)) * 0x00010001u), (uint32_t)(e >= 1 ? maxw : 0) * 0x00010001u));
-                }
-                const int xl = (k + 1) * C - 1;
-                if (k * C < (int)lenA)
-                    bndA = max(bndA, seed_band_lower(a.sp, (int)(mk & 0xffffu), (int)(mg & 0xffffu), xl, (int)lenA, wd, tallA, mA, c0A, strA, q + (SEED_MAX_KMERS + 1)));
-                if (k * C < (int)lenB)
-                    bndB = max(bndB, seed_band_lower(a.sp, (int)(mk >> 16), (int)(mg >> 16), xl, (int)lenB, wd, tallB, mB, c0B, strB, q + 3 * (SEED_MAX_KMERS + 1)));
             }
             if (MODE != 0) {  // merge the strip's maximum into the read's
                 const int sA = (int)(sbest & 0xffffu), sB = (int)(sbest >> 16);
@@ -307,26 +368,85 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                     }
                 }
             }
+            // what left the band through the right edge joins the paths above it after the strip's last column
+            const int xl = (k + 1) * C - 1;
+            const BandLayout yA = band_layout(st, false), yB = band_layout(st, true);
+            if (has_next && min(bot, next_top) > top) {
+                const uint32_t joinA = xl < (int)lenA - 1 ? 0xffffu : 0u, joinB = xl < (int)lenB - 1 ? 0xffff0000u : 0u;
+                const uint32_t freeA = seed_exit_is_free(xl, yA.m, yA.c0, yA.stride, a.sp.K, a.sp.spacer, yA.magic, yA.fa) ? 0xffffu : 0u;
+                const uint32_t freeB = seed_exit_is_free(xl, yB.m, yB.c0, yB.stride, a.sp.K, a.sp.spacer, yB.magic, yB.fa) ? 0xffff0000u : 0u;
+                const uint32_t ux = pk_addu(pk_untag<TAG>(uk), PKB2) & (joinA | joinB);
+                st[BF_UP_FR * BLOCK] = (int)pk_maxu((uint32_t)st[BF_UP_FR * BLOCK], ux & (freeA | freeB));
+                st[BF_UP_CH * BLOCK] = (int)pk_maxu((uint32_t)st[BF_UP_CH * BLOCK], ux & ~(freeA | freeB));
+            }
+            // below the strip's columns: b(c) of either read, joined by the cells of the strip's last row (H holds them)
+            {
+                const uint32_t below = bot < R ? 0xffffffffu : 0u, exits = (bot < R && bot > top) ? 0xffffffffu : 0u;
+                const SeedStripEvents eA = seed_strip_events(k * C, C, yA.m, yA.c0, yA.stride, a.sp.K, yA.magic, yA.fb);
+                const SeedStripEvents eB = seed_strip_events(k * C, C, yB.m, yB.c0, yB.stride, a.sp.K, yB.magic, yB.fb);
+                const uint32_t any = eA.start | eA.end | eB.start | eB.end;
+                BandPk lo;
+                lo.ch = (uint32_t)st[BF_LO_CH * BLOCK];
+                lo.fr = (uint32_t)st[BF_LO_FR * BLOCK];
+                uint32_t ob2 = (uint32_t)st[BF_OB * BLOCK], b2 = 0;
+                auto sweep = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
+                    const uint32_t realA = nrA >= 32 ? 0xffffffffu : ((1u << nrA) - 1u), realB = nrB >= 32 ? 0xffffffffu : ((1u << nrB) - 1u);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        lo.ch += maxw2;
+                        lo.fr += maxw2;
+                        if (__ballot((any >> c) & 1u) != 0) pk_events(&lo, half_mask(eA.start, eB.start, c), half_mask(eA.end, eB.end, c), lam2);
+                        uint32_t he = pk_addu(pk_untag<TAG>(pk_subu(H[c], Dr)), PKB2) & exits;
+                        uint32_t rm = 0xffffffffu;
+                        if (!FULL) {
+                            rm = half_mask(realA, realB, c);
+                            he &= rm;
+                        }
+                        const uint32_t im = half_mask(eA.inside, eB.inside, c);
+                        lo.fr = pk_maxu(lo.fr, he & im);
+                        lo.ch = pk_maxu(lo.ch, he & ~im);
+                        b2 = pk_subu_sat(pk_maxu(lo.ch, lo.fr), PKB2) & rm;
+                        ob2 = pk_maxu(ob2, b2 & below);
+                    }
+                };
+                if (all_full) sweep(std::true_type{});
+                else sweep(std::false_type{});
+                st[BF_LO_CH * BLOCK] = (int)lo.ch;
+                st[BF_LO_FR * BLOCK] = (int)lo.fr;
+                st[BF_OB * BLOCK] = (int)ob2;
+                // the next strip's first column, rows below this strip's last: H of the cell to the left; F entering (the bound may
+                // have stood lambda - maxw higher just before a k-mer's last column; a horizontal run opens with gap_open)
+                const uint32_t nm = ((nrA == C ? 0xffffu : 0u) | (nrB == C ? 0xffff0000u : 0u)) & below;
+                st[BF_YH * BLOCK] = (int)(b2 & nm);
+                st[BF_YF * BLOCK] = (int)(pk_subu_sat(pk_addu(b2, pk_subu_sat(lam2, maxw2)), go2p) & nm);
+            }
             prev_bot = bot;
         }
-        // fresh starts outside the band
-        const int SA = (int)(best & 0xffffu), SB = (int)(best >> 16);
-        if (dtmin + (n_strips - 1) * C - wu > 0) {
-            bndA = max(bndA, tallA - min(dfaA, gup));
-            bndB = max(bndB, tallB - min(dfaB, gup));
-        }
-        if (dtmax + C + wd < R) {
-            bndA = max(bndA, tallA - min(dfbA, gdnA));
-            bndB = max(bndB, tallB - min(dfbB, gdnB));
-        }
+        const uint32_t best2A = best & 0xffffu, best2B = best >> 16;
+        const int tallA = (int)(infoA & 0xffffu), tallB = (int)(infoB & 0xffffu);
+        const int dfaA = (int)((infoA >> 16) & 0xffu), dfaB = (int)((infoB >> 16) & 0xffu);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 1 && !validB) break;
             const uint32_t id = h ? idB : idA;
-            const int S = h ? SB : SA, bound = h ? bndB : bndA;
-            // score only: a path outside the band matters if it can score MORE than S; with ends also if it can score S (it could
-            // end in an earlier row or column)
-            const bool redo = MODE == 0 ? bound > S : bound >= S;
+            const uint32_t b2 = h ? best2B : best2A;
+            const int oa = (int)(((uint32_t)st[BF_OA * BLOCK] >> (h ? 16 : 0)) & 0xffffu), ob = (int)(((uint32_t)st[BF_OB * BLOCK] >> (h ? 16 : 0)) & 0xffffu);
+            const int S = (int)(b2 >> 1), outside = max(oa, ob);
+            // an odd maximum: a path through a cell outside the band may hold it. Score only: a path that ends outside matters if it
+            // can score MORE than S; with ends also if it can score S (it could end in an earlier row or column)
+            const bool redo = (b2 & 1u) != 0 || (MODE == 0 ? outside > S : outside >= S);
+            if (a.dbg) {  // tests/test_gpu_bounds.py: the kernel's own values against the host model's
+                int* rec = a.dbg + (size_t)id * 8;
+                rec[0] = (int)b2;
+                rec[1] = oa;
+                rec[2] = ob;
+                rec[3] = dtmin;
+                rec[4] = dtmax;
+                rec[5] = n_strips | (wu << 8) | (wd << 20);
+                rec[6] = h ? dtB : dtA;
+                rec[7] = ((h ? lenB : lenA) == 0 || redo) ? 0 : 1;
+            }
             if ((h ? lenB : lenA) == 0 || redo) {
                 if (a.retry) a.retry[h ? itemB : itemA] = 1;
                 else a.fail_list[atomicAdd(a.fail_count, 1u)] = id;
@@ -362,8 +482,12 @@ size_t seed_band_buffer_bytes(const SeedParams& p, uint32_t n, uint32_t max_len,
     return n ? (size_t)seed_band_grid(n, grid_cap) * BLOCK * (size_t)seed_band_rows(p, max_len) * sizeof(uint2) : 0;
 }
 
-bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase_rows) {
-    // a strip's rows must fit one drift period of the packed domain (no re-basing inside a strip)
+bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase_rows, uint32_t limit) {
+    // a strip's rows must fit one drift period of the packed domain (no re-basing inside a strip); doubled scores (+ the mark)
+    // must stay inside the packed range, the bound programmes' plain values below their bias; the masks are relative to Dn / Dm
+    static_assert(SEED_NARROW_WU >= SEED_DN && SEED_NARROW_WD >= SEED_DM, "the band must hold the diagonals that count as near the anchor");
+    if (p.M1 < p.Dn || p.Wd < p.Dm) return false;
+    if (2ull * (uint64_t)p.maxw * max_len + 8 >= limit || (uint64_t)p.maxw * (max_len + BC) >= 0x2000u) return false;
     return (uint32_t)BC + seed_band_rows(p, max_len) + 2 <= rebase_rows;
 }
 

@@ -189,13 +189,13 @@ bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, ui
 }
 
 hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max_len, const SeedIndex& ix, uint8_t* work, size_t work_bytes,
-                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, bool band, uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream,
-                               KernelTimer* window_timer) {
+                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, const ScoreArgsV2* band_tabs, const uint2* gtab_band, int32_t* band_dbg,
+                               uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream, KernelTimer* window_timer) {
     const uint32_t n = a2.b.n_items;
     if (n == 0) return hipSuccess;
     if (!work || !gtab || work_bytes < seed_workspace_bytes(n, max_len, band_grid_cap)) return hipErrorNotSupported;
-    // the banded kernel (zsw_score_band.hip) when a strip's rows fit one drift period
-    band = band && seed_band_applicable(ix.params, max_len, a2.K);
+    // the banded kernel (zsw_score_band.hip) when a strip's rows fit one drift period of the doubled scoring
+    const bool band = band_tabs != nullptr && gtab_band != nullptr && seed_band_applicable(ix.params, max_len, band_tabs->K, band_tabs->limit);
     const size_t per = round256((size_t)n * 4 + 8);
     uint32_t* keys = reinterpret_cast<uint32_t*>(work);
     uint32_t* keys_out = reinterpret_cast<uint32_t*>(work + per);
@@ -250,9 +250,9 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
         SeedBandArgs b;
         b.b = a2.b;
         b.ref_len = a2.ref_len;
-        b.ge2 = a2.ge2;
-        b.gd2 = a2.gd2;
-        b.floor0 = a2.floor0;
+        b.ge2 = band_tabs->ge2;
+        b.gd2 = band_tabs->gd2;
+        b.floor0 = band_tabs->floor0;
         b.rule = a2.rule;
         b.out = a2.out;
         b.sp = ix.params;
@@ -264,8 +264,9 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
         b.band_dfb = band_dfb;
         b.codes = codes;
         b.cs = cs;
-        b.gtab = gtab;
+        b.gtab = gtab_band;
         b.bnd = band_buf;
+        b.dbg = band_dbg;
         b.nb = seed_band_rows(ix.params, max_len);
         b.grid = seed_band_grid(n, band_grid_cap);
         b.key_bias = SEED_KEY_BIAS;

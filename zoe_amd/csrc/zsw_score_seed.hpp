@@ -17,8 +17,8 @@ constexpr int SEED_WD_PER16 = 1;  // coming back from beyond them takes insertio
 // A narrow first band for short reads (two tiers): most reads lose little to their own errors and prove their score inside
 // 12 + len/16 diagonals above and 6 + len/32 below the anchor; the reads that cannot are walked again in the full band
 // (SEED_M1 + len/8, SEED_WD + len/16), and only what fails there is scored over all its cells.
-constexpr int SEED_NARROW_WU = 12, SEED_NARROW_WU_PER16 = 1, SEED_NARROW_WD = 6, SEED_NARROW_WD_PER32 = 1;
-constexpr uint32_t SEED_NARROW_MAX_LEN = 192;  // beyond: a read's errors outgrow what a narrower band can prove
+constexpr int SEED_NARROW_WU = 8, SEED_NARROW_WU_PER16 = 0, SEED_NARROW_WD = 6, SEED_NARROW_WD_PER32 = 0;
+constexpr uint32_t SEED_NARROW_MAX_LEN = 640;  // beyond: a read's own indels drift further than the narrow band is wide
 constexpr uint32_t SEED_NARROW_MIN_READS = 200000;  // below: two more launches cost more than the narrower band saves (length classes of a ragged batch)
 constexpr int SEED_BAND_SLACK = 32;           // banded pass: two reads share a lane if their anchors are at most this far apart
 constexpr uint32_t SEED_BAND_MAX_GRID = 1024;  // banded pass: persistent blocks (each lane owns a boundary buffer in HBM)
@@ -63,7 +63,7 @@ struct SeedWindowArgs {
 struct SeedBandArgs {
     BatchDev b;
     uint32_t ref_len;
-    uint32_t ge2, gd2, floor0;
+    uint32_t ge2, gd2, floor0;         // of the DOUBLED scoring (the tables of gtab hold 2 * (score + gap_extend))
     ResultRule rule;
     ScoreOut out;
     SeedParams sp;
@@ -83,6 +83,7 @@ struct SeedBandArgs {
     const uint32_t* n_dev;             // non-null: the number of items in `order` (a device-side count, at most n)
     uint32_t* next_pair;               // work queue: the next pair to hand out (zeroed before the launch)
     uint8_t* retry;                    // non-null (first tier): a read whose bounds fail sets retry[its position in `order`] instead of joining the list
+    int* dbg;                          // non-null (tests): 8 ints per read — the walk's own values (maximum, oa, ob) and its geometry
     uint32_t key_bias, fail_key;
     uint32_t* fail_list;
     uint32_t* fail_count;
@@ -90,7 +91,8 @@ struct SeedBandArgs {
 uint32_t seed_band_rows(const SeedParams& p, uint32_t max_len);
 uint32_t seed_band_grid(uint32_t n, uint32_t grid_cap);
 size_t seed_band_buffer_bytes(const SeedParams& p, uint32_t n, uint32_t max_len, uint32_t grid_cap);
-bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase_rows);
+// rebase_rows / limit: of the doubled scoring's drift domain (a strip's rows must fit one drift period, twice the largest score the range)
+bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase_rows, uint32_t limit);
 hipError_t launch_seed_band(const SeedBandArgs& a, int mode, hipStream_t stream);
 
 struct ScoreArgsV2;
@@ -111,9 +113,11 @@ bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, ui
 // anchor and reads whose bounds fail are appended to fail_list (count at fail_count, not reset here).
 // gtab: (ref_len + 2 * SEED_GTAB_PAD) uint2, filled by seed_build_gtab (once per call of launch_score, from a2's tables).
 hipError_t seed_build_gtab(const ScoreArgsV2& a2, uint2* gtab, hipStream_t stream);
+// band_tabs: non-null = the banded kernel may run: drift constants of the DOUBLED scoring (ge2, gd2, floor0, K, limit), whose
+// per-row table is gtab_band (seed_build_gtab with those tables); band_dbg: zsw_debug_band_records.
 hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max_len, const SeedIndex& ix, uint8_t* work, size_t work_bytes,
-                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, bool band, uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream,
-                               KernelTimer* window_timer);
+                               uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, const ScoreArgsV2* band_tabs, const uint2* gtab_band, int32_t* band_dbg,
+                               uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream, KernelTimer* window_timer);
 // (Re)builds the index for a reference given as residue indices on the host.
 hipError_t seed_index_update(SeedIndex* ix, const ScoringDev& sc, const uint8_t* h_ref, size_t ref_len);
 void seed_index_release(SeedIndex* ix);

@@ -11,7 +11,9 @@
 //     spans completely is either aligned diagonally, without a gap, to an identical piece of the reference (an exact
 //     occurrence), or costs the path at least lambda of that potential: a mismatch costs maxw - w[x][q] >= lambda1, a deletion
 //     inside it gap_open, an inserted column maxw + gap_open (run starts in the k-mer's territory) or (s + 1) * (maxw +
-//     gap_extend) (run started before the s spacer columns in front of the k-mer, which belong to no other k-mer);
+//     gap_extend) (run started before the s spacer columns in front of the k-mer, which belong to no other k-mer) — provided
+//     those columns have the potential maxw: seed_read sums what the columns in front of each k-mer really lose to a run
+//     (their own potential + gap_extend each) and does not use a k-mer for which that stays below lambda;
 //   * the reference index holds, per k-mer, the first and last position at which it occurs, so "no exact occurrence on a
 //     diagonal left of the window" and "none below the window" are two comparisons per k-mer.
 //
@@ -214,15 +216,25 @@ ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetCell cell, Looku
     int pot_lo[SEED_MAX_KMERS], pot_hi[SEED_MAX_KMERS], dlo[SEED_MAX_KMERS], dhi[SEED_MAX_KMERS], last[SEED_MAX_KMERS];
     bool usable[SEED_MAX_KMERS], has[SEED_MAX_KMERS];
     int pot = 0, c = 0;
+    const int lam = seed_lambda(p, stride);
 #pragma unroll
     for (int j = 0; j < SEED_MAX_KMERS; ++j) {
         pot_lo[j] = pot_hi[j] = dlo[j] = dhi[j] = last[j] = 0;
         usable[j] = has[j] = false;
         if (j >= m) continue;
         const int cj = c0 + j * stride;
-        for (; c < cj; ++c) pot += (int)(cell(c) & 0xffu);
+        // An insertion run that opened inside the previous k-mer (which charged it lambda for the opening) reaches this k-mer by
+        // swallowing the columns between the two: each of them loses its OWN potential + gap_extend — nothing but gap_extend if
+        // its residue has no potential (N) — and this k-mer's first column loses maxw + gap_extend. Only if that comes to lambda
+        // does a path that spans the k-mer without traversing it exactly pay lambda for it on top of the previous one's.
+        int run = p.ins_col;
+        for (; c < cj; ++c) {
+            const int wpc = (int)(cell(c) & 0xffu);
+            pot += wpc;
+            run += wpc + p.ge;
+        }
         uint32_t code = 0;
-        bool ok = true;
+        bool ok = j == 0 || run >= lam;
         for (int k = 0; k < p.K; ++k, ++c) {
             const uint32_t x = cell(c);
             pot += (int)(x & 0xffu);
@@ -259,7 +271,6 @@ ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetCell cell, Looku
         out.fa_mask |= fa[i] ? 1u << i : 0u;
         out.fb_mask |= fb[i] ? 1u << i : 0u;
     }
-    const int lam = seed_lambda(p, stride);
     const int u_fa = seed_span_bound(m, pot_lo, pot_hi, pot, fa, lam);
     const int u_bl = seed_span_bound(m, pot_lo, pot_hi, pot, bl, lam);
     out.ok = 1;
@@ -272,79 +283,112 @@ ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetCell cell, Looku
 }
 
 // ---- banded pass (seed_band_kernel): the computed cells are a band of diagonals around the anchor, strip by strip ----------
-// Strip k holds query columns [kC, (k+1)C) and the reference rows [dt + kC - Wu, dt + (k+1)C + Wd). Every cell above the band
-// ("upper": right of it in a row) lies on a diagonal <= dt - Wu - 1, every cell below it ("lower") on a diagonal >= dt + Wd + 1.
-// A path with a cell outside the band either starts out there or leaves the band from a computed cell; from its first outside
-// cell on:
-//   upper  it never reaches diagonal dt - Dn again — then every k-mer it traverses exactly sits at an occurrence left of that
-//          diagonal, and the k-mers of fa_mask cost lambda each — or it does, by deleting at least Wu + 1 - Dn reference rows:
-//          seed_gap_up;
-//   lower  it never gets back to diagonal dt + Dm — k-mers of fb_mask cost lambda — or it does, by inserting at least
-//          Wd + 1 - Dm query columns, which cost the gap AND the potential of those columns (at least maxw each, less the read's
-//          total deficit maxw * len - t_all): seed_gap_down.
-// So: a fresh start outside scores at most t_all - min(d_fa, gap_up) resp. t_all - min(d_fb, gap_down); an exit from a computed
-// cell with value v in column x at most v + max(suffix bound of the mask (seed_exit_bound), maxw * (len - 1 - x) - gap)
-// (seed_band_upper / seed_band_lower, which also count how far outside the band's edge the exit cell's successor lies).
-ZSW_SEED_HD int seed_gap_up(const SeedParams& p, int wu) {
-    const int need = wu + 1 - p.Dn;
-    return need >= 1 ? p.go + (need - 1) * p.ge : 0;
+// Strip k holds query columns [kC, (k+1)C) and the reference rows [top_k, bot_k) = [dt + kC - Wu, dt + (k+1)C + Wd) (clamped to
+// the reference; dt = the smaller / larger anchor of the lane's two reads). Cells of a strip's columns in rows < top_k lie ABOVE
+// the band (on diagonals < dt - Wu <= dt - Dn), cells in rows >= bot_k BELOW it (diagonals > dt + Wd >= dt + Dm). A path changes
+// region only in these ways: above -> band through a strip's first row (vertical or diagonal step), below -> band through a
+// strip's first column in rows >= bot_{k-1} (horizontal or diagonal step), band -> above through the right edge of strip k in
+// rows < top_{k+1}, band -> below through a strip's last row.
+//
+// The banded pass is ONE dynamic programme over the band whose inputs from outside are not zero but UPPER BOUNDS of what any
+// path can hold in the outside cell it comes from ("injection"), every score doubled and an injected value made odd:
+//   * with all inputs >= the truth the recurrence (max and + only) keeps every cell >= the truth: U(cell) >= H(cell);
+//   * even values descend from the zero floor through even weights only: they are scores of real paths inside the band;
+//   * so if the band's maximum M is even, M / 2 is the score of a real path and no path that ever touched an outside cell and
+//     ends inside the band scores more (injected = 2 * bound - 1: score-only calls) or as much (2 * bound + 1: calls that want
+//     the ends, where an equal score elsewhere could end in an earlier row or column);
+//   * paths that END outside are bounded by the same outside bounds (oa / ob below) and compared with M / 2 the same way.
+// The outside bounds are two small dynamic programmes along the query columns, one per side (SeedColDP), run strip by strip
+// between the band's strips: a(c) / b(c) = the most any path can hold in a cell above / below the band after consuming column c.
+//   * A path above the band stays left of diagonal dt - Dn: every sampled k-mer of fa_mask (no occurrence out there) that it
+//     spans completely costs it lambda; below the band: fb_mask, right of dt + Dm. Each column adds at most maxw.
+//   * Two tracks: `vch` will pay for the next k-mer of the mask that ends, `vfr` will not (paths that started, or arrived from the
+//     band, inside that k-mer — or, above the band, within `spacer` columns before it in an open insertion run, which swallows the
+//     k-mer's first column for less than lambda); at the k-mer's last column vch pays, the tracks merge.
+//   * What leaves the band joins them: above, the largest value (H or outgoing F) on strip k's right edge in rows < top_{k+1},
+//     after column xl; below, the H of every cell of strip k's last row, after its own column (into the free track if that
+//     column lies inside a k-mer of the mask: the path has taken part of it in the band).
+// Strip k + 1 receives a(c) above its columns (E: minus gap_open) and b(xl) left of its first column in rows >= bot_k (as F: the
+// bound may have stood lambda - maxw higher just before a k-mer's last column, minus gap_open). The bounds are exact in the
+// k-mer charges column by column — a value that enters a strip's corner far from the anchor and leaves it again through the
+// right edge must not gain more than a path outside would, or the charges would be lost strip after strip.
+// The band's width is no longer the read's error budget: an injected path must still PAY the gap back to the anchor's diagonals
+// inside the band, and it competes there with the band's own paths, which have the read's real errors — not with the potential
+// of all columns. Host model: tests/models/seed_band.cpp (every cell of the band and every bound against the full Gotoh matrix).
+
+// floor(x / d) for 0 <= x < 4095 * d with x * d < 2^20 (columns of reads of up to 2,432 bases + a strip, strides of len / 16 at most)
+ZSW_SEED_HD uint32_t seed_div_magic(int d) { return (1u << 20) / (uint32_t)(d > 0 ? d : 1) + 1u; }
+ZSW_SEED_HD int seed_div(int x, uint32_t magic) { return (int)(((uint32_t)x * magic) >> 20); }
+// sampled k-mers whose first column is <= x
+ZSW_SEED_HD int seed_started(int x, int m, int c0, uint32_t magic) {
+    if (x < c0) return 0;
+    const int n = seed_div(x - c0, magic) + 1;
+    return n < m ? n : m;
 }
-ZSW_SEED_HD int seed_gap_down(const SeedParams& p, int wd, int len, int t_all) {
-    const int need = wd + 1 - p.Dm;
-    if (need < 1) return 0;
-    const int lost = p.maxw * need - (p.maxw * len - t_all);
-    return p.go + (need - 1) * p.ge + (lost > 0 ? lost : 0);
+
+constexpr int SEED_COL_NONE = -(1 << 20);
+
+struct SeedColDP {  // one side of one read: the most a path outside the band holds after the current column
+    int vch, vfr;   // pays / does not pay for the next k-mer of the mask that ends (vfr < 0: no such path)
+};
+// fresh = false (host model only): no path starts outside the band — what is left is the class of paths that came from the band
+ZSW_SEED_HD void seed_col_init(SeedColDP* s, bool fresh = true) {
+    s->vch = fresh ? 0 : SEED_COL_NONE;
+    s->vfr = SEED_COL_NONE;
 }
-// An exit cell that lies e diagonals further out than the band's edge needs e more gap positions to come back, except for the
-// first one (the diagonal step out of a cell one diagonal inside the edge lands on the edge's neighbour all the same): the
-// kernel keeps, next to the plain maximum of the exit values, the maximum of [value - gap_extend * max(e - 1, 0)], and the lower
-// exits, whose way back also loses the inserted columns' potential, add maxw for e >= 1 only (instead of maxw * e).
-// seed_gap_down(wd + e') >= seed_gap_down(wd) + (ge + maxw) * e' - seed_gap_down_slack: the potential lost to insertions is
-// counted from the read's total deficit on only.
-ZSW_SEED_HD int seed_gap_down_slack(const SeedParams& p, int wd, int len, int t_all) {
-    const int need = wd + 1 - p.Dm;
-    const int d = (p.maxw * len - t_all) - p.maxw * need;
-    return d > 0 ? d : 0;
-}
-// Upper exits of a strip whose last column is xl (right edge, rows above the next strip's first row; e = rows above the last of
-// them): uk = max v, ug = max [v - ge * max(e - 1, 0)] (floored at 0) over the exit cells' values v = max(H, outgoing F).
-template <typename Q>
-ZSW_SEED_HD int seed_band_upper(const SeedParams& p, int uk, int ug, int xl, int len, int wu, int m, int c0, int stride, const Q* q_fa) {
-    if (xl >= len - 1) return -1;  // no column left: the path ends here, the band's own maximum covers it
-    // The outgoing F is an insertion run already open: it swallows the next columns at ins_col each, and running into a k-mer that
-    // starts fewer than `spacer` columns away costs it less than lambda (seed_analyze chose the spacer so that a run across a whole
-    // spacer and into the k-mer pays lambda). Such a k-mer counts as plain potential: i = the first one at least `spacer` columns on.
-    int i = 0;
-    if (m > 0 && xl + p.spacer >= c0) {
-        i = (xl + p.spacer - c0) / stride + 1;
-        if (i > m) i = m;
+// one column: `start` / `end` = a k-mer of the mask has its first / last column here. Returns the bound after the column.
+ZSW_SEED_HD int seed_col_step(SeedColDP* s, int maxw, int lam, bool start, bool end, bool fresh = true) {
+    s->vch += maxw;
+    s->vfr += maxw;
+    if (start && fresh) s->vfr = s->vfr > 0 ? s->vfr : 0;  // a path that starts behind the k-mer's first column does not span it
+    if (end) {
+        s->vch -= lam;
+        s->vch = s->vfr > s->vch ? s->vfr : s->vch;
+        s->vfr = SEED_COL_NONE;
     }
-    const int ci = i < m ? c0 + i * stride : len;
-    const int via_kmers = uk + p.maxw * (ci - 1 - xl) + (int)q_fa[i];
-    const int via_gap = (wu + 1 - p.Dn >= 1 ? ug : uk) + p.maxw * (len - 1 - xl) - seed_gap_up(p, wu);
-    return via_gap > via_kmers ? via_gap : via_kmers;
+    return s->vch > s->vfr ? s->vch : s->vfr;
 }
-// Lower exits of a strip of C columns ending in column xl (last row; e = C - 1 - c for the strip's column c): with
-// he(c) = max(H, E of the next row) of the exit cell, mk = max [he(c) + maxw * e], mg = max [he(c) - ge * max(e - 1, 0) +
-// (e >= 1 ? maxw : 0)] (the first term floored at 0). Columns at or beyond the read's end only raise the two maxima.
-template <typename Q>
-ZSW_SEED_HD int seed_band_lower(const SeedParams& p, int mk, int mg, int xl, int len, int wd, int t_all, int m, int c0, int stride, const Q* q_fb) {
-    if (xl >= len - 1) {  // the read's last strip: nothing beyond column len - 1 (he(c) + maxw * (len - 1 - c) <= mk - maxw * (xl - (len - 1)))
-        const int v = mk - p.maxw * (xl - (len - 1));
-        return v > 0 ? v : 0;
-    }
-    int i = 0;
-    if (m > 0 && xl >= c0) {
-        i = (xl - c0) / stride + 1;
-        if (i > m) i = m;
-    }
-    const int ci = i < m ? c0 + i * stride : len;
-    int via_kmers = p.maxw * (ci - 1 - xl) + (int)q_fb[i];
-    via_kmers = mk + (via_kmers > 0 ? via_kmers : 0);
-    const int need = wd + 1 - p.Dm;
-    const int via_gap = (need >= 1 ? mg + seed_gap_down_slack(p, wd, len, t_all) : mk) + p.maxw * (len - 1 - xl) - seed_gap_down(p, wd, len, t_all);
-    return via_gap > via_kmers ? via_gap : via_kmers;
+// a value leaving the band joins the paths outside
+ZSW_SEED_HD void seed_col_join(SeedColDP* s, int v, bool free_track) {
+    if (free_track) s->vfr = v > s->vfr ? v : s->vfr;
+    else s->vch = v > s->vch ? v : s->vch;
 }
+// the events of a strip's columns [kC, kC + C), C <= 32: bit i = a k-mer of `mask` starts / ends in column kC + i
+struct SeedStripEvents {
+    uint32_t start, end;
+    uint32_t inside;  // bit i: column kC + i lies in a k-mer of the mask, but is not its last column
+};
+ZSW_SEED_HD SeedStripEvents seed_strip_events(int kC, int C, int m, int c0, int stride, int K, uint32_t magic, uint32_t mask) {
+    SeedStripEvents e;
+    e.start = e.end = e.inside = 0;
+    for (int j = seed_started(kC - 1, m, c0, magic); j < m; ++j) {
+        const int cj = c0 + j * stride;
+        if (cj >= kC + C) break;
+        if ((mask >> j) & 1u) e.start |= 1u << (cj - kC);
+    }
+    for (int j = seed_started(kC - K, m, c0, magic); j < m; ++j) {  // the first k-mer whose last column is not left of the strip
+        const int cj = c0 + j * stride, ej = cj + K - 1;
+        if (cj >= kC + C) break;
+        if (!((mask >> j) & 1u)) continue;
+        if (ej < kC + C) e.end |= 1u << (ej - kC);
+        const int lo = cj > kC ? cj - kC : 0, hi = ej < kC + C ? ej - kC : C;  // columns [lo, hi) of the strip
+        if (hi > lo) e.inside |= (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+    }
+    return e;
+}
+// A value leaves the band above it after column x, possibly as an open insertion run: it does not pay for a k-mer of the mask
+// whose territory (the `spacer` columns before it and all but its last column) holds column x.
+ZSW_SEED_HD bool seed_exit_is_free(int x, int m, int c0, int stride, int K, int spacer, uint32_t magic, uint32_t mask) {
+    const int j = seed_started(x - K + 1, m, c0, magic);  // the first k-mer whose last column lies behind x
+    if (j >= m || !((mask >> j) & 1u)) return false;
+    return c0 + j * stride - spacer <= x;
+}
+
+// Doubled scores with the mark of a path that touched a cell outside the band: TAG = -1 (score only: such a path must score
+// MORE than the band's own to matter) or +1 (ends: as much). A bound of 0 stays the plain zero floor.
+ZSW_SEED_HD uint32_t seed_tag(int v, int tag) { return v > 0 ? (uint32_t)(2 * v + tag) : 0u; }
+// the plain bound a doubled value stands for
+ZSW_SEED_HD int seed_untag(uint32_t v2, int tag) { return (int)((v2 + (tag < 0 ? 1u : 0u)) >> 1); }
 
 // Certificate for the late start of the alignment's second pass (sw_simd_align's flags, striped.rs:449-598, recomputed for the
 // rows the traceback can visit). Every quantity of the striped recurrence at a cell (H, the E entering it, the F of a lazy-F
