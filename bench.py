@@ -37,15 +37,23 @@ sys.path.insert(0, ROOT)
 READ_LEN = 150
 REF_LEN = 2000
 ALGO_BYTES_PER_READ = READ_LEN + 4  # read bytes in + u32 score out
-# seed_band_kernel<32,3> on the 10 M-read headline batch — TWO launches per step: the narrow band over every read, then the full
-# band over the ~11 % of reads whose bounds fail in it (a hipCUB selection in between) — from committed rocprofv3 --pmc passes
-# (separate runs; the gfx950 x2 correction for wide streaming reads is NOT applied to FETCH_SIZE: the kernel's loads are 8-byte
-# strip-boundary rows and 4-byte code words, the raw counter is reported). CONSTANTS from that profile, not measurements of this
-# run (the bench line says so). Nearly all of the traffic is the strip boundary (H and outgoing F of a strip's last column,
-# 8 bytes per row and read pair, written once and read once by the same lane: ~70 MB in flight, beyond the 32 MB of L2).
-PMC_PROFILE = "profiles/r03_band_summary.txt"
-WINDOW_HBM_BYTES_PER_READ = 1946.7  # FETCH_SIZE 948.6 + 131.9, WRITE_SIZE 733.4 + 132.8 B per read of the batch (narrow + full band launch)
-WINDOW_VALU_PER_READ = 789          # SQ_INSTS_VALU per read of the batch: 684 (narrow band, 6.841e9 per launch) + 105 (full band over the rest)
+# Per-read instruction counts and HBM counters of the kernels below are CONSTANTS from committed rocprofv3 --pmc passes (separate
+# runs; the gfx950 x2 correction for wide streaming reads is NOT applied to FETCH_SIZE: the loads are 8-byte strip-boundary rows and
+# 4-byte code words, the raw counter is reported), not measurements of this run — the bench line says so. They live in
+# profiles/constants.json together with the sha256 of the .hip_fatbin section of the library they were measured on
+# (tools/refresh_constants.py); a bench run on a library with another hash marks every figure derived from them "stale".
+CONSTANTS_FILE = "profiles/constants.json"
+
+
+def load_constants():
+    with open(os.path.join(ROOT, CONSTANTS_FILE)) as f:
+        return json.load(f)
+
+
+PC = load_constants()
+PMC_PROFILE = PC["band"]["source"]
+WINDOW_HBM_BYTES_PER_READ = PC["band"]["hbm_bytes_per_read"]   # FETCH_SIZE + WRITE_SIZE per read of the batch, both launches of seed_band_kernel<32,3,0>
+WINDOW_VALU_PER_READ = PC["band"]["valu_per_read"]            # SQ_INSTS_VALU per read of the batch, both launches
 VALU_PEAK_SOURCE = "profiles/r01_valu_issue_rates_ubench.txt"  # this repo's micro-benchmark (tools/ubench.hip), not a figure of the guide
 TOTAL_READS_MULTI_GPU = 500_000_000  # BASELINE.json configs[3]
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
@@ -168,20 +176,47 @@ WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4  # wave64 VALU instructions/s: 1,024 SIMDs
 # VALU wave-instructions per read of the pass-2 / score kernels, from committed rocprofv3 --pmc SQ_INSTS_VALU passes
 # (constants from those profiles, not measured in the bench run): tools/pmc_entry.py, one entry point per run, every kernel of
 # the call summed (profiles/r03_secondary_valu.txt; per-phase budget of the packed alignment kernel: profiles/r02_align_pk_pmc.txt)
-SECONDARY_VALU_PROFILE = "profiles/r03_secondary_valu.txt"
-ALIGN_PK_VALU_PER_READ = 15_464   # align_kernel_pk<16,10> 14,789 + <32,5> 675 (pass 2 alone: what pass2_kernel_ms times)
+SECONDARY_VALU_PROFILE = PC["secondary"]["source"]
+ALIGN_PK_VALU_PER_READ = PC["secondary"]["align_pass2_valu_per_read"]   # align_kernel_pk<16,10> + <32,5> (pass 2 alone: what pass2_kernel_ms times)
 ALIGN_PK_PROFILE = SECONDARY_VALU_PROFILE
-RANGES_VALU_PER_READ = 4_393      # banded kernel (MODE 2, two launches) 939 + reverse pass 2,830 + handed-back reads 528 + seed kernel 81
-THREEPASS_VALU_PER_READ = 4_648   # the same + threepass_kernel 252
+RANGES_VALU_PER_READ = PC["secondary"]["ranges_valu_per_read"]          # banded kernel (MODE 2) + reverse pass + handed-back reads + seed kernel
+THREEPASS_VALU_PER_READ = PC["secondary"]["threepass_valu_per_read"]    # the same + threepass_kernel
 # FETCH_SIZE + WRITE_SIZE per read of the same calls (separate --pmc passes, raw counters), same file
-RANGES_HBM_PER_READ = 1_046 + 1_546
-THREEPASS_HBM_PER_READ = 2_244 + 4_722     # the third pass's DP rows and traceback cells in global memory (13.6 + 18.7 kB before the slots were interleaved)
-MIXED_HBM_PER_READ = 2_700 + 3_745
-ALIGN_HBM_PER_READ = 11_512 + 33_470       # the flag ring of pass 2 (30 kB per read) and its read-back by the traceback
-PROTEIN_PROFILE = "profiles/r03_protein_prune_summary.txt"
-PROTEIN_VALU_PER_READ = 3_940 + 2_155 + 496   # prune_strip_kernel<24,WIDE> + prune_window_kernel<24,4,32,0,WIDE> + score_kernel_v2<..,WIDE> over the 2.1 % handed back
-PROTEIN_HBM_PER_READ = 10_900 + 1_200 + 360 + 1_500   # the strip's boundary stream written, read back by the window kernel
-MIXED_VALU_PER_READ = 16_114      # 75-400 bp vs 30 kb: 13,800 of them are the full pass over the 3 % of reads handed back
+RANGES_HBM_PER_READ = PC["secondary"]["ranges_hbm_per_read"]
+THREEPASS_HBM_PER_READ = PC["secondary"]["threepass_hbm_per_read"]
+MIXED_HBM_PER_READ = PC["secondary"]["mixed_hbm_per_read"]
+ALIGN_HBM_PER_READ = PC["secondary"]["align_hbm_per_read"]              # the flag ring of pass 2 (30 kB per read) and its read-back by the traceback
+PROTEIN_PROFILE = PC["protein"]["source"]
+PROTEIN_VALU_PER_READ = PC["protein"]["valu_per_read"]   # prune_strip_kernel<24,WIDE> + prune_window_kernel<24,4,32,0,WIDE> + score_kernel_v2<..,WIDE> over the reads handed back
+PROTEIN_HBM_PER_READ = PC["protein"]["hbm_per_read"]     # the strip's boundary stream written, read back by the window kernel
+MIXED_VALU_PER_READ = PC["secondary"]["mixed_valu_per_read"]            # 75-400 bp vs 30 kb
+
+
+def library_hash():
+    from zoe_amd import build
+
+    try:
+        return build.fatbin_sha256()
+    except (OSError, RuntimeError):
+        return None
+
+
+LIB_HASH = library_hash()
+
+
+def constants_state(section: str):
+    """where a constant comes from and whether it was measured on the library this run loads"""
+    src = PC[section]
+    return {"source": file_tag(src["source"]), "measured_on_fatbin_sha256": src.get("fatbin_sha256"), "running_fatbin_sha256": LIB_HASH,
+            "stale": src.get("fatbin_sha256") != LIB_HASH}
+
+
+def _stale_of(source):
+    """True if the profile file `source` was taken from another library build than the one loaded (profiles/constants.json)"""
+    for sec in PC.values():
+        if isinstance(sec, dict) and sec.get("source") == source:
+            return sec.get("fatbin_sha256") != LIB_HASH
+    return True
 
 
 def rooflines(algo_bytes: float, kernel_s: float, valu_instr: float = None, source: str = None, traffic_bytes: float = None):
@@ -193,12 +228,13 @@ def rooflines(algo_bytes: float, kernel_s: float, valu_instr: float = None, sour
                         "traffic": traffic_bytes / kernel_s / 1e9 if traffic_bytes else None,
                         "traffic_bytes_per_launch": traffic_bytes, "traffic_measured_in_this_run": False if traffic_bytes else None,
                         "traffic_source": file_tag(source) if (traffic_bytes and source) else None,
+                        "traffic_stale": _stale_of(source) if (traffic_bytes and source) else None,
                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_s * 1e3}}
     if valu_instr:
         out["valu_roofline"] = {"bound": "valu", "achieved": valu_instr / kernel_s / 1e9, "peak": WAVE_INSTR_PEAK / 1e9,
                                 "unit": "G wave64 VALU instructions/s", "frac": valu_instr / kernel_s / WAVE_INSTR_PEAK,
                                 "instruction_count_source": file_tag(source) if source else None,
-                                "instruction_count_measured_in_this_run": False, "valu_peak_source": VALU_PEAK_SOURCE}
+                                "instruction_count_measured_in_this_run": False, "stale": _stale_of(source), "valu_peak_source": VALU_PEAK_SOURCE}
     return out
 
 
@@ -360,8 +396,22 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     out["score_mixed_1M_x_75_400bp_vs_30kb"] = entry
     del rr, pm, got, seeded_mixed
     torch.cuda.empty_cache()
+    out["score_divergence_sweep"] = divergence_sweep(ctx)
     out.update(protein_and_shared(zoe_amd, synth, ctx, matrix, timed, with_full_first_pass))
     return out
+
+
+def divergence_sweep(ctx):
+    """The default score path against read divergence (tools/bench_divergence.py): 1 M reads of 150 bases per rate — pieces of the
+    2 kb reference with x % substitutions, x / 10 % single-base indels and 2 % unrelated reads; every result compared with the full pass."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_divergence
+
+    rows = bench_divergence.sweep(ctx, 1_000_000, [1, 2, 3, 5, 8, 12])
+    if not all(r["identical"] for r in rows):
+        raise SystemExit("PARITY FAILURE: the default (seeded) pass differs from the full pass on diverged reads")
+    return {"reads": 1_000_000, "read_len": READ_LEN, "ref_len": REF_LEN, "rows": rows,
+            "note": "handed_back_fraction includes the 2 % unrelated reads of every set; a 1 M-read batch runs at about 0.6 of the 10 M-read batch's rate"}
 
 
 def protein_and_shared(zoe_amd, synth, ctx, matrix, timed, with_full_first_pass):
@@ -591,6 +641,10 @@ def main():
                 "handed_back_fraction": handed_back / max(n_local, 1),
                 "first_pass_ms": pass_s * 1e3,
                 "gcups_equivalent": value * READ_LEN * REF_LEN / 1e9,
+                "data_dependence": "`value` holds for reads within a few per cent of the reference (the synthetic set: 1 % substitutions, 2 % unrelated reads = "
+                                   "the handed-back fraction). The proof rests on k-mers the read shares with the reference: beyond about one substitution per "
+                                   "ten bases a read is scored over all its cells. Data-independent floor: full_pass_every_cell.reads_per_s; the curve between: "
+                                   "secondary.score_divergence_sweep",
             },
             "roofline": {
                 "bound": "hbm",
@@ -601,6 +655,7 @@ def main():
                 "traffic": traffic / kern / 1e9 if (traffic and kern > 0) else None,
                 "traffic_bytes_per_launch": traffic,
                 "traffic_measured_in_this_run": False,
+                "traffic_stale": constants_state("band")["stale"] if traffic else None,
                 "traffic_source": ("constant from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of the same kernel and workload: " + file_tag(PMC_PROFILE))
                                   if traffic else None,
                 "kernel": kernel_name,
@@ -616,6 +671,7 @@ def main():
             out["valu_roofline"] = {"bound": "valu", "achieved": instr / kern / 1e9, "peak": WAVE_INSTR_PEAK / 1e9,
                                     "unit": "G wave64 VALU instructions/s", "frac": instr / kern / WAVE_INSTR_PEAK, "kernel": kernel_name,
                                     "instruction_count_source": file_tag(PMC_PROFILE), "instruction_count_measured_in_this_run": False,
+                                    "library_fatbin_sha256": LIB_HASH, "stale": constants_state("band")["stale"],
                                     "valu_peak_source": "one wave64 packed/perm/max3 instruction per 4 cycles per SIMD: " + file_tag(VALU_PEAK_SOURCE)}
         if world == 1 and not args.no_full_pass:
             out["full_pass_every_cell"] = full_pass_headline(zoe_amd, ctx, profiles, reference, last, n_local, args.steps)

@@ -291,3 +291,41 @@ def test_banded_pass_work_queue_on_tiny_batches(za, oracle, n):
         assert int(got_r.status[i]) == st, i
         if st == 0:
             assert (int(got_r.score[i]), (int(got_r.ref_start[i]), int(got_r.ref_end[i])), (int(got_r.query_start[i]), int(got_r.query_end[i]))) == (s, rr, qr), i
+
+
+@pytest.mark.parametrize("rate", [30, 50, 80, 120])
+def test_diverged_reads_score_ranges_and_alignments_vs_oracle(za, oracle, rate):
+    """Reads 3 / 5 / 8 / 12 % away from the reference (+ a tenth of that in indels): the seeded pass proves fewer and fewer of
+    them (the k-mer bound's slope is one substitution per ten bases) and hands the rest to the full pass — every entry point that
+    starts with it must equal the oracle on all of them: score cascade, ranges cascade, exact alignment, 3-pass alignment."""
+    import torch
+
+    from test_gpu_bounds import diverged_reads
+    from zoe_amd import _lib, synth
+
+    ctx = za.SwContext.get(0)
+    ref = synth.reference_host(2000)
+    n = 1500
+    reads = diverged_reads(ref, n, 150, rate, stable_seed("diverged", rate))
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    sc = oracle.Scoring(dna.signed_weights(), dna.mapping.index_map, -10, -1)
+    ctx.debug_set(_lib.DEBUG_SCORE_PRUNE_ANY_SIZE)
+    try:
+        back = _oracle_check(za, oracle, reads, dna, -10, -1, ref)
+        assert (back < 0.2 * n) if rate <= 30 else (back > 0.5 * n if rate >= 120 else True), back
+        prof = za.LocalProfilesBatch.new_with_w256(_batch(za, reads), dna, -10, -1)
+        rg = prof.sw_score_ranges_from_i8(za.SeqSrc.Reference(ref))
+        al = prof.sw_align_from_i8(za.SeqSrc.Reference(ref))
+        a3 = prof.sw_align_from_i8_3pass(za.SeqSrc.Reference(ref))
+        torch.cuda.synchronize()
+    finally:
+        ctx.debug_set(0)
+    for i in range(0, n, 3):
+        o_st, o_s, o_rr, o_qr, o_t = oracle.cascade_score_ranges(8, 256, sc, reads[i], ref)
+        assert int(rg.status[i]) == o_st, i
+        if o_st == 0:
+            assert (int(rg.score[i]), (int(rg.ref_start[i]), int(rg.ref_end[i])), (int(rg.query_start[i]), int(rg.query_end[i])), int(rg.tier[i])) == (o_s, o_rr, o_qr, o_t), i
+        want, tier = oracle.cascade_align(8, 256, sc, reads[i], ref)
+        assert al.key(i) == (want.key() if want.status == 0 else (want.status, 0, (0, 0), (0, 0), "", 0, 0)), i
+        want3, tier3, _how = oracle.cascade_align_3pass(8, 256, sc, reads[i], ref)
+        assert a3.key(i) == (want3.key() if want3.status == 0 else (want3.status, 0, (0, 0), (0, 0), "", 0, 0)), i

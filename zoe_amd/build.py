@@ -67,6 +67,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def fatbin_sha256(path: str = LIB) -> str:
+    """sha256 of the library's .hip_fatbin section (the gfx950 code objects): what a rocprofv3 summary under profiles/ was taken
+    from, and what bench.py compares with the library it runs (a kernel change that was not re-profiled shows as "stale")."""
+    import hashlib
+    import struct
+
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        raise RuntimeError("not a 64-bit ELF file: " + path)
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+
+    def section(i):
+        name, _type, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
+        return name, off, size
+
+    _, stroff, strsize = section(shstrndx)
+    names = data[stroff:stroff + strsize]
+    for i in range(shnum):
+        name, off, size = section(i)
+        if names[name:names.index(b"\0", name)] == b".hip_fatbin":
+            return hashlib.sha256(data[off:off + size]).hexdigest()
+    raise RuntimeError("no .hip_fatbin section in " + path)
+
+
 def build_driver(name: str = "zsw_driver") -> str:
     """A C++ host program over include/zoe_sw.hpp (examples/zsw_driver.cpp: FASTQ -> SAM; examples/zsw_selftest.cpp: the
     reference's known-answer vectors), linked against the in-tree library."""
