@@ -113,6 +113,8 @@ unsafe extern "C" {
     fn zsw_score_ranges_shared_batch_from(ctx: *mut ZswContext, reads: *const ZswBatch, from_width: i32, preset_bits: i32, out_score: *mut u32, out_ref_start: *mut u32, out_ref_end: *mut u32, out_query_start: *mut u32, out_query_end: *mut u32, out_status: *mut u8, out_tier: *mut u8, stream: *mut c_void) -> i32;
     fn zsw_align_shared_batch(ctx: *mut ZswContext, reads: *const ZswBatch, int_type: i32, lanes: i32, invert: i32, out_aln: *mut ZswAlignment, out_status: *mut u8, out_inc: *mut u32, out_op: *mut u8, ciglet_cap: u64, out_n_ciglets: *mut u64, stream: *mut c_void) -> i32;
     fn zsw_align_shared_batch_from(ctx: *mut ZswContext, reads: *const ZswBatch, from_width: i32, preset_bits: i32, invert: i32, out_aln: *mut ZswAlignment, out_status: *mut u8, out_tier: *mut u8, out_inc: *mut u32, out_op: *mut u8, ciglet_cap: u64, out_n_ciglets: *mut u64, stream: *mut c_void) -> i32;
+    fn zsw_align_3pass_shared_batch(ctx: *mut ZswContext, reads: *const ZswBatch, int_type: i32, lanes: i32, invert: i32, out_aln: *mut ZswAlignment, out_status: *mut u8, out_inc: *mut u32, out_op: *mut u8, ciglet_cap: u64, out_n_ciglets: *mut u64, stream: *mut c_void) -> i32;
+    fn zsw_align_3pass_shared_batch_from(ctx: *mut ZswContext, reads: *const ZswBatch, from_width: i32, preset_bits: i32, invert: i32, out_aln: *mut ZswAlignment, out_status: *mut u8, out_tier: *mut u8, out_inc: *mut u32, out_op: *mut u8, ciglet_cap: u64, out_n_ciglets: *mut u64, stream: *mut c_void) -> i32;
     fn zsw_sneaky_snake_batch(ctx: *mut ZswContext, reads: *const ZswBatch, ref_start: *const u32, ref_len: *const u32, threshold: f32, out_pass: *mut u8, stream: *mut c_void) -> i32;
     fn zsw_group_create(device_ids: *const i32, n_devices: i32, out: *mut *mut ZswGroup) -> i32;
     fn zsw_group_destroy(group: *mut ZswGroup);
@@ -576,6 +578,37 @@ impl GpuContext {
         self.align_with(reads.len(), scoring.gap_open, scoring.gap_extend, |aln, st, tier, inc, op, cap, need| {
             // SAFETY: as above
             unsafe { zsw_align_shared_batch_from(self.raw, &c, cascade.from_width, cascade.preset_bits, invert, aln, st, tier, inc, op, cap, need, ptr::null_mut()) }
+        })
+    }
+
+    /// Per read: `StripedProfile::<T, N, S>::new(sequence, ..)?.sw_align_3pass(SeqSrc::Query(read), sequence, ..)` (profile.rs:536-552 ->
+    /// three_pass.rs:21-104) with ONE profile for the whole batch.
+    pub fn sw_align_3pass_shared_batch<const S: usize, Q: AsRef<[u8]>>(
+        &self, sequence: &[u8], reads: &[Q], scoring: &Scoring<'_, S>, int_type: IntType, lanes: i32, other: OtherSeq,
+    ) -> Result<Vec<Result<MaybeAligned<Alignment<u32>>, ProfileError>>, GpuError> {
+        self.configure_shared(scoring, sequence)?;
+        let batch = HostBatch::new(reads);
+        let c = batch.as_c();
+        let invert = i32::from(other == OtherSeq::Query);
+        let (out, _) = self.align_with(reads.len(), scoring.gap_open, scoring.gap_extend, |aln, st, _tier, inc, op, cap, need| {
+            // SAFETY: all arrays were sized by align_with
+            unsafe { zsw_align_3pass_shared_batch(self.raw, &c, int_type as i32, lanes, invert, aln, st, inc, op, cap, need, ptr::null_mut()) }
+        })?;
+        Ok(out)
+    }
+
+    /// Per read: `sequence.into_shared_profile(..)?.sw_align_from_i{from_width}_3pass(SeqSrc::Query(read))` (profile_set.rs:212-283,
+    /// 552-560); the second vector is the width that answered.
+    pub fn sw_align_3pass_shared_from_batch<const S: usize, Q: AsRef<[u8]>>(
+        &self, sequence: &[u8], reads: &[Q], scoring: &Scoring<'_, S>, cascade: Cascade, other: OtherSeq,
+    ) -> Result<(Vec<Result<MaybeAligned<Alignment<u32>>, ProfileError>>, Vec<u8>), GpuError> {
+        self.configure_shared(scoring, sequence)?;
+        let batch = HostBatch::new(reads);
+        let c = batch.as_c();
+        let invert = i32::from(other == OtherSeq::Query);
+        self.align_with(reads.len(), scoring.gap_open, scoring.gap_extend, |aln, st, tier, inc, op, cap, need| {
+            // SAFETY: as above
+            unsafe { zsw_align_3pass_shared_batch_from(self.raw, &c, cascade.from_width, cascade.preset_bits, invert, aln, st, tier, inc, op, cap, need, ptr::null_mut()) }
         })
     }
 

@@ -13,10 +13,10 @@ int main(void) {
         (fn)zsw_align_batch, (fn)zsw_align_batch_from, (fn)zsw_align_3pass_batch,
         (fn)zsw_align_3pass_batch_from, (fn)zsw_sneaky_snake_batch, (fn)zsw_set_profile_sequence,
         (fn)zsw_score_shared_batch, (fn)zsw_score_shared_batch_from, (fn)zsw_score_ends_shared_batch, (fn)zsw_score_ranges_shared_batch,
-        (fn)zsw_score_ranges_shared_batch_from, (fn)zsw_align_shared_batch, (fn)zsw_align_shared_batch_from, (fn)zsw_synth_reads,
+        (fn)zsw_score_ranges_shared_batch_from, (fn)zsw_align_shared_batch, (fn)zsw_align_shared_batch_from, (fn)zsw_align_3pass_shared_batch, (fn)zsw_align_3pass_shared_batch_from, (fn)zsw_synth_reads,
         (fn)zsw_synth_reads_ragged, (fn)zsw_synth_length, (fn)zsw_synth_reference_host,
         (fn)zsw_synth_reads_host, (fn)zsw_synth_reads_ragged_host, (fn)zsw_selftest,
-        (fn)zsw_timing_enable, (fn)zsw_timing_read, (fn)zsw_timing_read_window, (fn)zsw_debug_set, (fn)zsw_prune_rescored, (fn)zsw_set_option,
+        (fn)zsw_timing_enable, (fn)zsw_timing_read, (fn)zsw_timing_read_window, (fn)zsw_debug_set, (fn)zsw_debug_band_records, (fn)zsw_prune_rescored, (fn)zsw_set_option,
         (fn)zsw_group_create, (fn)zsw_group_destroy, (fn)zsw_group_size, (fn)zsw_group_context,
         (fn)zsw_group_last_error_string, (fn)zsw_group_set_scoring, (fn)zsw_group_set_reference,
         (fn)zsw_group_score_batch_from, (fn)zsw_group_score_batch_from_device,

@@ -210,6 +210,17 @@ zsw_error zsw_align_shared_batch(zsw_context* ctx, const zsw_batch* reads, zsw_i
 zsw_error zsw_align_shared_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, int invert,
                                       zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op,
                                       uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream);
+/* StripedProfile::sw_align_3pass / ProfileSets::sw_align_from_i{from_width}_3pass with the shared profile (profile.rs:536-552,
+ * profile_set.rs:212-283, 552-560 -> three_pass.rs:21-104): the shared role's ranges, then sw_banded_align / sw_scalar_align over
+ * the bounding box with the roles of three_pass.rs (`reference` = read i, ScalarProfile over the profile sequence's sub-range) —
+ * the form the reference documents for a large reference and small queries. Like the reference's, the CIGAR may differ from
+ * zsw_align_shared_batch's where several optimal alignments exist. invert = 1: SeqSrc::Query(read_i). Outputs as zsw_align_batch(_from). */
+zsw_error zsw_align_3pass_shared_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, int invert, zsw_alignment* out_aln,
+                                       uint8_t* out_status, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets,
+                                       void* stream);
+zsw_error zsw_align_3pass_shared_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, int invert,
+                                            zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op,
+                                            uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream);
 
 /* ---- pre-alignment filter ------------------------------------------------------------------ */
 /* out_pass[i] = sneaky_snake(&reference[ref_start[i] .. ref_start[i]+ref_len[i]], read_i, threshold)

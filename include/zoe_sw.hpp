@@ -502,6 +502,10 @@ class SharedProfilesBatch : public SharedProfileBase {
     std::vector<MaybeAligned<Alignment>> sw_align_from_i8(const std::vector<std::string>& reads, bool seq_is_query = true) { return align_from(reads, seq_is_query, 8); }
     std::vector<MaybeAligned<Alignment>> sw_align_from_i16(const std::vector<std::string>& reads, bool seq_is_query = true) { return align_from(reads, seq_is_query, 16); }
     std::vector<MaybeAligned<Alignment>> sw_align_from_i32(const std::vector<std::string>& reads, bool seq_is_query = true) { return align_from(reads, seq_is_query, 32); }
+    // ProfileSets::sw_align_from_i*_3pass (profile_set.rs:212-283) of SharedProfiles (:552-560)
+    std::vector<MaybeAligned<Alignment>> sw_align_from_i8_3pass(const std::vector<std::string>& reads, bool seq_is_query = true) { return align_from(reads, seq_is_query, 8, true); }
+    std::vector<MaybeAligned<Alignment>> sw_align_from_i16_3pass(const std::vector<std::string>& reads, bool seq_is_query = true) { return align_from(reads, seq_is_query, 16, true); }
+    std::vector<MaybeAligned<Alignment>> sw_align_from_i32_3pass(const std::vector<std::string>& reads, bool seq_is_query = true) { return align_from(reads, seq_is_query, 32, true); }
     const std::vector<uint8_t>& last_tiers() const { return tier_; }
 
   private:
@@ -517,12 +521,13 @@ class SharedProfilesBatch : public SharedProfileBase {
         for (size_t i = 0; i < n; ++i) out[i] = {(Status)status[i], score[i]};
         return out;
     }
-    std::vector<MaybeAligned<Alignment>> align_from(const std::vector<std::string>& reads, bool seq_is_query, int width) {
+    std::vector<MaybeAligned<Alignment>> align_from(const std::vector<std::string>& reads, bool seq_is_query, int width, bool three_pass = false) {
         const HostReads h = pack(reads);
         const zsw_batch b = h.batch();
         tier_.assign(reads.size(), 0);
         return collect(reads.size(), [&](zsw_alignment* aln, uint8_t* st, uint32_t* inc, uint8_t* op, uint64_t cap, uint64_t* total) {
-            return zsw_align_shared_batch_from(ctx_.raw(), &b, width, preset_, seq_is_query, aln, st, tier_.data(), inc, op, cap, total, nullptr);
+            return (three_pass ? zsw_align_3pass_shared_batch_from : zsw_align_shared_batch_from)(ctx_.raw(), &b, width, preset_, seq_is_query, aln, st,
+                                                                                                 tier_.data(), inc, op, cap, total, nullptr);
         });
     }
     int preset_;

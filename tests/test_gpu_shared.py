@@ -54,6 +54,8 @@ def test_shared_striped_profile_vs_oracle(za, oracle, T, N):
     rq = prof.sw_score_ranges(za.SeqBatchSrc.Query(reads))
     a = prof.sw_align(za.SeqBatchSrc.Query(reads))
     ar = prof.sw_align(za.SeqBatchSrc.Reference(reads[:300]))
+    a3 = prof.sw_align_3pass(za.SeqBatchSrc.Query(reads))
+    a3r = prof.sw_align_3pass(za.SeqBatchSrc.Reference(reads[:300]))
     for i, rd in enumerate(reads):
         st, sv = oracle.score(T, N, sc, ref, rd)
         assert (int(s.status[i]), int(s.score[i]) if st == S_ else 0) == (st, sv if st == S_ else 0), i
@@ -70,6 +72,9 @@ def test_shared_striped_profile_vs_oracle(za, oracle, T, N):
             assert a.key(i) == okey(oracle.align(T, N, sc, ref, rd, other_is_query=True)), i
         if i < 300 and i % 3 == 0:
             assert ar.key(i) == okey(oracle.align(T, N, sc, ref, rd, other_is_query=False)), i
+            assert a3r.key(i) == okey(oracle.align_3pass(T, N, sc, ref, rd, other_is_query=False)[0]), i
+        if i % 4 == 0:  # profile.rs:536-552 with the shared profile: ranges, then banded / scalar alignment in the box
+            assert a3.key(i) == okey(oracle.align_3pass(T, N, sc, ref, rd, other_is_query=True)[0]), i
 
 
 @pytest.mark.parametrize("preset", [128, 256, 512])
@@ -86,6 +91,7 @@ def test_shared_profiles_cascade_vs_oracle(za, oracle, preset):
     s = prof.sw_score_from_i8(reads)
     r = prof.sw_score_ranges_from_i8(za.SeqBatchSrc.Reference(reads))
     a = prof.sw_align_from_i8(za.SeqBatchSrc.Query(reads))
+    a3 = prof.sw_align_from_i8_3pass(za.SeqBatchSrc.Query(reads))
     tiers = set()
     for i, rd in enumerate(reads):
         st, sv, tier = oracle.cascade_score(8, preset, sc, ref, rd)
@@ -101,6 +107,10 @@ def test_shared_profiles_cascade_vs_oracle(za, oracle, preset):
             want, wt = oracle.cascade_align(8, preset, sc, ref, rd, other_is_query=True)
             assert a.key(i) == okey(want), i
             assert int(a.tier[i]) == wt, i
+            want3, wt3, _how = oracle.cascade_align_3pass(8, preset, sc, ref, rd, other_is_query=True)  # profile_set.rs:212-283 of SharedProfiles
+            assert a3.key(i) == okey(want3), i
+            if want3.status == S_:
+                assert int(a3.tier[i]) == wt3, i
     assert {8, 16} <= tiers
 
 
@@ -174,6 +184,7 @@ def test_random_pairs_ragged_reads_ties_and_low_complexity(za, oracle, scheme, s
         e = prof.sw_score_ends(za.SeqBatchSrc.Reference(reads))
         r = prof.sw_score_ranges(za.SeqBatchSrc.Reference(reads))
         a = prof.sw_align(za.SeqBatchSrc.Query(reads))
+        a3 = prof.sw_align_3pass(za.SeqBatchSrc.Query(reads))
         for i, rd in enumerate(reads):
             st, (sv, re_, qe) = oracle.score_ends("i16", N, sc, seq, rd)
             assert int(e.status[i]) == st, (N, i)
@@ -184,6 +195,7 @@ def test_random_pairs_ragged_reads_ties_and_low_complexity(za, oracle, scheme, s
             if st == S_:
                 assert (int(r.score[i]), (int(r.ref_start[i]), int(r.ref_end[i])), (int(r.query_start[i]), int(r.query_end[i]))) == (sv, rr, qr), (N, i)
             assert a.key(i) == okey(oracle.align("i16", N, sc, seq, rd, other_is_query=True)), (N, i)
+            assert a3.key(i) == okey(oracle.align_3pass("i16", N, sc, seq, rd, other_is_query=True)[0]), (N, i)
 
 
 def _tie_rich_reads(rng, seq, n, L):
@@ -318,9 +330,12 @@ def test_empty_inputs_and_errors(za, oracle):
     s = prof.sw_score(rb)
     e = prof.sw_score_ends(za.SeqBatchSrc.Reference(rb))
     a = prof.sw_align(za.SeqBatchSrc.Query(rb))
-    assert [int(x) for x in s.status] == [0, 2, 2] or [int(x) for x in s.status][1] == 2
-    assert int(e.status[1]) == 2 and int(a.status[1]) == 2
     sc = osc(oracle, dna, -10, -1)
+    want = [2 if not rd else oracle.score("i16", 16, sc, b"ACGTACGTTTGACA", rd)[0] for rd in reads]
+    assert want == [0, 2, 0] and [int(x) for x in s.status] == want
+    assert int(e.status[1]) == 2 and int(a.status[1]) == 2
+    a3 = prof.sw_align_3pass(za.SeqBatchSrc.Query(rb))
+    assert [int(x) for x in a3.status] == want
     assert a.key(0) == okey(oracle.align("i16", 16, sc, b"ACGTACGTTTGACA", reads[0], other_is_query=True))
     ctx = za.SwContext.get(0)
     fresh = _lib.load()
@@ -335,3 +350,34 @@ def test_empty_inputs_and_errors(za, oracle):
         assert fresh.zsw_score_shared_batch(h, C.byref(b), 1, 16, sc_t.data_ptr(), st_t.data_ptr(), None) == -5  # ZSW_ERR_NOT_CONFIGURED
     finally:
         fresh.zsw_destroy(h)
+
+
+@pytest.mark.parametrize("T,N", [("i16", 16), ("i8", 32)])
+def test_three_pass_with_the_shared_profile_on_tie_rich_and_diverged_reads(za, oracle, T, N, any_size):
+    """SharedProfiles::sw_align_from_i*_3pass / StripedProfile::sw_align_3pass with ONE profile (profile_set.rs:212-283, 552-560;
+    profile.rs:536-552 -> three_pass.rs:21-104): the shared ranges (seeded passes, forward and reversed), then the third pass with
+    `reference` = the read and a ScalarProfile over the profile sequence's sub-range. Tie-rich reads (several optimal alignments: the
+    band / scalar tie-breaking of banded.rs / scalar.rs decides) and reads 5-12 % away from the sequence, both SeqSrc directions."""
+    from test_gpu_bounds import diverged_reads
+    from zoe_amd import synth
+
+    rng = np.random.default_rng(stable_seed("shared3", T, N))
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seq = bytearray(rng.choice(alpha, 1500).tobytes())
+    seq[300:340] = bytes(rng.choice(alpha[:2], 40))
+    for i in range(700 + 3, 760):
+        seq[i] = seq[i - 3]
+    seq = bytes(seq)
+    reads = np.concatenate([_tie_rich_reads(rng, seq, 900, 100), diverged_reads(seq, 300, 100, 50, 1), diverged_reads(seq, 300, 100, 120, 2)])
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    sc = osc(oracle, dna, -10, -1)
+    prof = za.SharedStripedProfile(seq, dna, -10, -1, T, N)
+    import torch
+
+    rb = za.ReadBatch.from_fixed(torch.from_numpy(np.ascontiguousarray(reads).reshape(-1)).cuda(), 100)
+    aq = prof.sw_align_3pass(za.SeqBatchSrc.Query(rb))
+    ar = prof.sw_align_3pass(za.SeqBatchSrc.Reference(rb))
+    for i in range(len(reads)):
+        assert aq.key(i) == okey(oracle.align_3pass(T, N, sc, seq, reads[i], other_is_query=True)[0]), i
+        if i % 3 == 0:
+            assert ar.key(i) == okey(oracle.align_3pass(T, N, sc, seq, reads[i], other_is_query=False)[0]), i

@@ -41,3 +41,5 @@ m = max(n // 10, 1)
 rb2 = synth.reads_device(ctx, ref, 0, m, 150)
 a, t = timed(lambda: prof.sw_align_from_i8(zoe_amd.SeqBatchSrc.Query(rb2)), reps=2)
 print(f"sw_align_from_i8 (shared, {m} reads): {m / t / 1e6:.2f} M reads/s ({t * 1e3:.2f} ms)", flush=True)
+a3, t = timed(lambda: prof.sw_align_from_i8_3pass(zoe_amd.SeqBatchSrc.Query(rb)), reps=2)
+print(f"sw_align_from_i8_3pass (shared, {n} reads, end to end incl. D2H of records and CIGARs): {n / t / 1e6:.2f} M reads/s ({t * 1e3:.2f} ms)", flush=True)

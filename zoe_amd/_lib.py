@@ -35,7 +35,7 @@ SYMBOLS = [
     "zsw_create", "zsw_destroy", "zsw_last_error_string", "zsw_device_count", "zsw_set_scoring", "zsw_set_reference",
     "zsw_score_batch", "zsw_score_batch_from", "zsw_score_ends_batch", "zsw_score_ranges_batch", "zsw_score_ranges_batch_from", "zsw_align_batch", "zsw_align_batch_from", "zsw_align_3pass_batch", "zsw_align_3pass_batch_from", "zsw_sneaky_snake_batch",
     "zsw_set_profile_sequence", "zsw_score_shared_batch", "zsw_score_shared_batch_from", "zsw_score_ends_shared_batch", "zsw_score_ranges_shared_batch",
-    "zsw_score_ranges_shared_batch_from", "zsw_align_shared_batch", "zsw_align_shared_batch_from",
+    "zsw_score_ranges_shared_batch_from", "zsw_align_shared_batch", "zsw_align_shared_batch_from", "zsw_align_3pass_shared_batch", "zsw_align_3pass_shared_batch_from",
     "zsw_synth_reads", "zsw_synth_reads_ragged", "zsw_synth_length", "zsw_synth_reference_host", "zsw_synth_reads_host",
     "zsw_synth_reads_ragged_host", "zsw_selftest", "zsw_timing_enable", "zsw_timing_read", "zsw_timing_read_window", "zsw_debug_set", "zsw_debug_band_records", "zsw_prune_rescored", "zsw_set_option",
     "zsw_group_create", "zsw_group_destroy", "zsw_group_size", "zsw_group_context", "zsw_group_last_error_string", "zsw_group_set_scoring",
@@ -116,6 +116,8 @@ def load() -> C.CDLL:
     lib.zsw_score_ranges_shared_batch_from.argtypes = lib.zsw_score_ranges_batch_from.argtypes
     lib.zsw_align_shared_batch.argtypes = lib.zsw_align_batch.argtypes
     lib.zsw_align_shared_batch_from.argtypes = lib.zsw_align_batch_from.argtypes
+    lib.zsw_align_3pass_shared_batch.argtypes = lib.zsw_align_shared_batch.argtypes
+    lib.zsw_align_3pass_shared_batch_from.argtypes = lib.zsw_align_batch_from.argtypes
     lib.zsw_sneaky_snake_batch.argtypes = [vp, C.POINTER(ZswBatch), u32p, u32p, C.c_float, u8p, vp]
     lib.zsw_synth_reads.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp]
     lib.zsw_synth_reads_ragged.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u64p, vp, vp]

@@ -263,13 +263,11 @@ class SwContext:
         self.check(self.lib.zsw_debug_band_records(self.h, C.c_void_p(records.data_ptr() if records is not None else None)))
 
     def set_profile_sequence(self, sequence: bytes):
-        """zsw_set_profile_sequence: the sequence the shared profile is built from (skipped when it is the one already set)"""
+        """zsw_set_profile_sequence: the sequence the shared profile is built from (the library itself skips the work when it is the
+        one already set: no copy of it is kept on this side, which another binding of the same context could leave stale)"""
         sequence = bytes(sequence)
-        if getattr(self, "_pseq", None) == sequence:
-            return
         buf = (C.c_uint8 * max(len(sequence), 1)).from_buffer_copy(sequence if sequence else b"\0")
         self.check(self.lib.zsw_set_profile_sequence(self.h, buf, len(sequence), _lib.MEM_HOST))
-        self._pseq = sequence
 
     def set_option(self, option: int, value: int):
         """zsw_set_option, e.g. set_option(_lib.OPTION_EXACT_PRUNING, 0): every cell of every read instead of the seeded exact pass."""
@@ -758,6 +756,9 @@ class _SharedBase:
     reads are passed as `SeqSrc.Query(reads)`, which swaps the roles back (alignment/mod.rs:176-190)."""
 
     def __init__(self, sequence, matrix: WeightMatrix, gap_open: int, gap_extend: int, device: int = 0):
+        if not isinstance(sequence, (bytes, bytearray, memoryview, np.ndarray)):
+            # (this class once took the READS here; bytes(ReadBatch) or bytes(list) would be accepted and mean nothing)
+            raise TypeError("the shared profile is built from ONE sequence (bytes); the reads are the arguments of its methods")
         sequence = bytes(sequence)
         validate_profile_args(len(sequence), gap_open, gap_extend)
         self.sequence = sequence
@@ -818,8 +819,11 @@ class _SharedBase:
             rs, re_, qs, qe = qs, qe, rs, re_
         return ScoreBatch(o[0][:n], status[:n], tier=tier[:n] if direct is None else None, ref_start=rs, ref_end=re_, query_start=qs, query_end=qe)
 
-    def _align(self, seq, direct=None, from_width=None, preset=None) -> AlignmentBatch:
+    def _align(self, seq, direct=None, from_width=None, preset=None, threepass=False) -> AlignmentBatch:
         torch = _torch()
+        lib = self.ctx.lib
+        f_direct = lib.zsw_align_3pass_shared_batch if threepass else lib.zsw_align_shared_batch
+        f_from = lib.zsw_align_3pass_shared_batch_from if threepass else lib.zsw_align_shared_batch_from
         reads, is_query = self._reads_of(seq)
         rb = _as_batch(reads, self.device)
         self._prep()
@@ -834,11 +838,11 @@ class _SharedBase:
             inc = torch.empty(cap, dtype=torch.int32, device=dev)
             op = torch.empty(cap, dtype=torch.uint8, device=dev)
             if direct is not None:
-                rc = self.ctx.lib.zsw_align_shared_batch(self.ctx.h, C.byref(b), direct[0], direct[1], int(is_query), aln.data_ptr(), status.data_ptr(),
-                                                         inc.data_ptr(), op.data_ptr(), cap, C.byref(total), self.ctx.stream())
+                rc = f_direct(self.ctx.h, C.byref(b), direct[0], direct[1], int(is_query), aln.data_ptr(), status.data_ptr(),
+                              inc.data_ptr(), op.data_ptr(), cap, C.byref(total), self.ctx.stream())
             else:
-                rc = self.ctx.lib.zsw_align_shared_batch_from(self.ctx.h, C.byref(b), from_width, preset, int(is_query), aln.data_ptr(), status.data_ptr(),
-                                                              tier.data_ptr(), inc.data_ptr(), op.data_ptr(), cap, C.byref(total), self.ctx.stream())
+                rc = f_from(self.ctx.h, C.byref(b), from_width, preset, int(is_query), aln.data_ptr(), status.data_ptr(),
+                            tier.data_ptr(), inc.data_ptr(), op.data_ptr(), cap, C.byref(total), self.ctx.stream())
             if rc == -1 and total.value > cap:
                 cap = int(total.value)
                 continue
@@ -901,6 +905,10 @@ class SharedStripedProfile(_SharedBase):
 
     def sw_align(self, seq) -> AlignmentBatch:
         return self._align(seq, direct=(_lib.INT_TYPES[self.T], self.N))
+
+    def sw_align_3pass(self, seq) -> AlignmentBatch:
+        """profile.rs:536-552 (three_pass.rs:21-104) with the shared profile: ranges, then banded / scalar alignment in the box"""
+        return self._align(seq, direct=(_lib.INT_TYPES[self.T], self.N), threepass=True)
 
 
 class SharedProfilesBatch(_SharedBase):
@@ -966,6 +974,16 @@ class SharedProfilesBatch(_SharedBase):
 
     def sw_align_from_i32(self, seq) -> AlignmentBatch:
         return self._align(seq, from_width=32, preset=self.preset)
+
+    def sw_align_from_i8_3pass(self, seq) -> AlignmentBatch:
+        """ProfileSets::sw_align_from_i8_3pass (profile_set.rs:212-283) of SharedProfiles (:552-560)"""
+        return self._align(seq, from_width=8, preset=self.preset, threepass=True)
+
+    def sw_align_from_i16_3pass(self, seq) -> AlignmentBatch:
+        return self._align(seq, from_width=16, preset=self.preset, threepass=True)
+
+    def sw_align_from_i32_3pass(self, seq) -> AlignmentBatch:
+        return self._align(seq, from_width=32, preset=self.preset, threepass=True)
 
 
 def into_shared_profile(sequence, matrix: WeightMatrix, gap_open: int, gap_extend: int, device: int = 0) -> SharedProfilesBatch:

@@ -63,6 +63,11 @@ struct ThreePassArgs {
     uint32_t* fb_list;      // ciglet overflow / slot too small -> rerun with larger resources
     uint32_t* fb_count;
     int invert;
+    // The shared-profile role (profile_set.rs:552-560: one profile, built from `pseq`, reused for every sequence of the batch):
+    // non-null = the roles of three_pass.rs:21-26 are `reference` = read i, `query` = pseq for every i (ranges from
+    // zsw_score_ranges_shared_batch: rs/re index the read, qs/qe the profile sequence); `ref` / `ref_len` are then unused.
+    const uint8_t* pseq = nullptr;
+    uint32_t pseq_len = 0;
 };
 
 hipError_t launch_threepass(const ThreePassArgs& a, uint32_t grid, hipStream_t stream);

@@ -348,11 +348,6 @@ __global__ void ranges_combine_kernel(uint32_t n, const uint32_t* fscore, const 
 }
 
 
-struct RangesDev {  // device arrays of sw_simd_score_ranges for every read (library workspace)
-    uint32_t *score, *rs, *re, *qs, *qe;
-    uint8_t *status, *tier;
-};
-
 // forward score+ends (MODE 2), reverse pass on the prefixes, combine; everything stays on the device
 zsw_error ranges_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, hipStream_t stream, RangesDev* out) {
     const uint32_t n = st.b.n_reads;
@@ -704,11 +699,21 @@ zsw_error run_threepass(zsw_context* ctx, const zsw_batch* reads, const ResultRu
     }
     *out_n_ciglets = 0;
     if (n == 0) return ZSW_OK;
-    const bool host = reads->mem == ZSW_MEM_HOST;
     RangesDev rd;
     ctx->timer.begin(stream);
     zsw_error ze = ranges_device(ctx, st, rule, stream, &rd);
     if (ze != ZSW_OK) return ze;
+    return threepass_third_pass(ctx, st, rd, nullptr, 0, reads->mem == ZSW_MEM_HOST, invert, out_aln, out_status, out_tier, out_inc, out_op, ciglet_cap,
+                                out_n_ciglets, stream);
+}
+
+// The third pass over ranges that are already on the device (the caller opened ctx->timer's interval). pseq: non-null = the
+// shared-profile role (ThreePassArgs::pseq).
+zsw_error threepass_third_pass(zsw_context* ctx, const Staged& st, const RangesDev& rd, const uint8_t* pseq, uint32_t pseq_len, bool host, int invert,
+                               zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap,
+                               uint64_t* out_n_ciglets, hipStream_t stream) {
+    const uint32_t n = st.b.n_reads;
+    zsw_error ze = ZSW_OK;
     DevBuf* ws = ctx->a_ws;
     const uint32_t MAXC = 32;
     ZSW_HIP(ctx, ws[WS_ALN].ensure((size_t)n * sizeof(zsw_alignment)));
@@ -749,6 +754,8 @@ zsw_error run_threepass(zsw_context* ctx, const zsw_batch* reads, const ResultRu
     a.fb_list = ws[WS_FBLIST].as<uint32_t>();
     a.fb_count = counters;
     a.invert = invert;
+    a.pseq = pseq;
+    a.pseq_len = pseq_len;
     hipError_t e = launch_threepass(a, std::min<uint32_t>((n + 63) / 64, 65536u), stream);  // classify + no-gaps shortcut
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "3-pass classify", e);
     uint32_t h_cnt[3] = {0, 0, 0};
@@ -792,7 +799,7 @@ zsw_error run_threepass(zsw_context* ctx, const zsw_batch* reads, const ResultRu
         ZSW_HIP(ctx, ws[WS_FBMETA].ensure(8));
         ZSW_HIP(ctx, hipMemcpyAsync(ws[WS_FBMETA].p, &n_fb, 4, hipMemcpyHostToDevice, stream));
         ZSW_HIP(ctx, hipMemsetAsync(counters, 0, 4, stream));
-        const uint32_t maxc_fb = st.max_len + (uint32_t)ctx->ref_len + 4;
+        const uint32_t maxc_fb = st.max_len + (pseq ? pseq_len : (uint32_t)ctx->ref_len) + 4;
         ze = dp_pass(ws[WS_ITEMS2].as<uint32_t>(), ws[WS_FBMETA].as<uint32_t>(), n_fb, std::max<uint32_t>(h_cnt[2], 64), maxc_fb, 1,
                      ws[WS_CIG2], ws[WS_RING2]);
         if (ze != ZSW_OK) return ze;

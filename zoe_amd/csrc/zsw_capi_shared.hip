@@ -225,6 +225,10 @@ zsw_error run_ends_shared(zsw_context* ctx, const zsw_batch* reads, const Result
     return unstage(ctx, reads, stream, st, out_score, out_status, nullptr, out_rend, out_qend);
 }
 
+// sw_simd_score_ranges of the shared role for every read, on the device (rs / re: positions in the read, qs / qe: in the profile
+// sequence); opens ctx->timer's interval and leaves it open.
+zsw_error ranges_shared_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, hipStream_t stream, RangesDev* out);
+
 zsw_error run_ranges_shared(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, uint32_t* out_score, uint32_t* out_rs,
                             uint32_t* out_re, uint32_t* out_qs, uint32_t* out_qe, uint8_t* out_status, uint8_t* out_tier, void* stream_) {
     zsw_error ze = check_shared(ctx);
@@ -242,6 +246,23 @@ zsw_error run_ranges_shared(zsw_context* ctx, const zsw_batch* reads, const Resu
     }
     const uint32_t n = (uint32_t)reads->n_reads;
     if (n == 0) return ZSW_OK;
+    RangesDev rd;
+    ze = ranges_shared_device(ctx, st, rule, stream, &rd);
+    if (ze != ZSW_OK) return ze;
+    ctx->timer.end(stream);
+    const hipMemcpyKind kind = reads->mem == ZSW_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    uint32_t* outs[5] = {out_score, out_rs, out_re, out_qs, out_qe};
+    const uint32_t* devs[5] = {rd.score, rd.rs, rd.re, rd.qs, rd.qe};
+    for (int k = 0; k < 5; ++k) ZSW_HIP(ctx, hipMemcpyAsync(outs[k], devs[k], (size_t)n * 4, kind, stream));
+    ZSW_HIP(ctx, hipMemcpyAsync(out_status, rd.status, n, kind, stream));
+    if (out_tier) ZSW_HIP(ctx, hipMemcpyAsync(out_tier, rd.tier, n, kind, stream));
+    if (reads->mem == ZSW_MEM_HOST) ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    return ZSW_OK;
+}
+
+zsw_error ranges_shared_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, hipStream_t stream, RangesDev* out) {
+    zsw_error ze = ZSW_OK;
+    const uint32_t n = st.b.n_reads;
     DevBuf* ws = ctx->sh_ws;
     DevBuf* rw = ctx->r_ws;  // the output arrays of the ordinary ranges path
     for (int k : {SH_SCORE, SH_REND, SH_QEND, SH_QEM, SH_RSCORE, SH_RRS, SH_RQS}) ZSW_HIP(ctx, ws[k].ensure((size_t)n * 4 + 4));
@@ -331,15 +352,41 @@ zsw_error run_ranges_shared(zsw_context* ctx, const zsw_batch* reads, const Resu
     ZSW_HIP(ctx, launch_ranges_combine(n, fo.score, fo.status, fo.ref_end, fo.query_end, ro.score, ro.status, ro.ref_end, ro.query_end,
                                        rw[RW_O0].as<uint32_t>(), rw[RW_O1].as<uint32_t>(), rw[RW_O2].as<uint32_t>(), rw[RW_O3].as<uint32_t>(),
                                        rw[RW_O4].as<uint32_t>(), rw[RW_O5].as<uint8_t>(), ws[SH_MIS].as<uint32_t>(), stream));
-    ctx->timer.end(stream);
-    const hipMemcpyKind kind = reads->mem == ZSW_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    uint32_t* outs[5] = {out_score, out_rs, out_re, out_qs, out_qe};
-    const int devs[5] = {RW_O0, RW_O1, RW_O2, RW_O3, RW_O4};
-    for (int k = 0; k < 5; ++k) ZSW_HIP(ctx, hipMemcpyAsync(outs[k], rw[devs[k]].p, (size_t)n * 4, kind, stream));
-    ZSW_HIP(ctx, hipMemcpyAsync(out_status, rw[RW_O5].p, n, kind, stream));
-    if (out_tier) ZSW_HIP(ctx, hipMemcpyAsync(out_tier, fo.tier, n, kind, stream));
-    if (reads->mem == ZSW_MEM_HOST) ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    out->score = rw[RW_O0].as<uint32_t>();
+    out->rs = rw[RW_O1].as<uint32_t>();
+    out->re = rw[RW_O2].as<uint32_t>();
+    out->qs = rw[RW_O3].as<uint32_t>();
+    out->qe = rw[RW_O4].as<uint32_t>();
+    out->status = rw[RW_O5].as<uint8_t>();
+    out->tier = fo.tier;
     return ZSW_OK;
+}
+
+// SharedProfiles::sw_align_from_i*_3pass (profile_set.rs:212-283, 552-560; profile.rs:536-552 -> three_pass.rs:21-104): the shared
+// role's ranges, then the third pass with `reference` = read i and `query` = the profile sequence (ScalarProfile over its sub-range).
+zsw_error run_threepass_shared(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, int invert, zsw_alignment* out_aln, uint8_t* out_status,
+                               uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream_) {
+    zsw_error ze = check_shared(ctx);
+    if (ze != ZSW_OK) return ze;
+    if (!reads || !out_aln || !out_status || !out_n_ciglets || (ciglet_cap && (!out_inc || !out_op)))
+        return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard device_guard(ctx);
+    hipStream_t stream = (hipStream_t)stream_;
+    SharedStage guard(ctx, true);
+    Staged st;
+    {
+        uint32_t dummy_score = 0;
+        uint8_t dummy_status = 0;
+        ze = stage(ctx, reads, stream, false, false, &dummy_score, &dummy_status, nullptr, nullptr, nullptr, &st);
+        if (ze != ZSW_OK) return ze;
+    }
+    *out_n_ciglets = 0;
+    if (reads->n_reads == 0) return ZSW_OK;
+    RangesDev rd;
+    ze = ranges_shared_device(ctx, st, rule, stream, &rd);
+    if (ze != ZSW_OK) return ze;
+    return threepass_third_pass(ctx, st, rd, ctx->d_pseq.as<uint8_t>(), (uint32_t)ctx->pseq_len, reads->mem == ZSW_MEM_HOST, invert, out_aln, out_status, out_tier,
+                                out_inc, out_op, ciglet_cap, out_n_ciglets, stream);
 }
 
 zsw_error run_align_shared(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, int lanes_w8, int lanes_w16, int lanes_w32, int invert,
@@ -473,6 +520,8 @@ zsw_error zsw_set_profile_sequence(zsw_context* ctx, const uint8_t* sequence, si
     if (!ctx || (!sequence && len)) return ZSW_ERR_INVALID_ARGUMENT;
     if (len == 0) return ZSW_ERR_EMPTY_SEQUENCE;  // StripedProfile::new -> Err(ProfileError::EmptySequence) (profile.rs:32-44)
     if (len > 0x7fffffffull) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "profile sequence too long");
+    // the sequence already set (callers set it before every call): nothing to do, and no device-wide synchronisation
+    if (ctx->pseq_set && mem == ZSW_MEM_HOST && ctx->pseq_len == len && memcmp(ctx->h_pseq.data(), sequence, len) == 0) return ZSW_OK;
     ZSW_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->pseq_set) ZSW_HIP(ctx, hipDeviceSynchronize());  // queued kernels may still read the previous sequence
     ZSW_HIP(ctx, ctx->d_pseq.ensure(len + 16));
@@ -553,6 +602,25 @@ zsw_error zsw_align_shared_batch_from(zsw_context* ctx, const zsw_batch* reads, 
     if (!rule_cascade(from_width, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "from_width");
     return run_align_shared(ctx, reads, rule, preset_bits / 8, preset_bits / 16, preset_bits / 32, invert, out_aln, out_status, out_tier, out_inc,
                             out_op, ciglet_cap, out_n_ciglets, stream);
+}
+
+zsw_error zsw_align_3pass_shared_batch(zsw_context* ctx, const zsw_batch* reads, zsw_int_type int_type, int lanes, int invert, zsw_alignment* out_aln,
+                                       uint8_t* out_status, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap, uint64_t* out_n_ciglets, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!valid_lanes(lanes)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "lanes must be a power of two in 2..64");
+    ResultRule rule;
+    if (!rule_direct(int_type, ctx->bias, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "bad int_type");
+    return run_threepass_shared(ctx, reads, rule, invert, out_aln, out_status, nullptr, out_inc, out_op, ciglet_cap, out_n_ciglets, stream);
+}
+
+zsw_error zsw_align_3pass_shared_batch_from(zsw_context* ctx, const zsw_batch* reads, int from_width, int preset_bits, int invert, zsw_alignment* out_aln,
+                                            uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap,
+                                            uint64_t* out_n_ciglets, void* stream) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (preset_bits != 128 && preset_bits != 256 && preset_bits != 512) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "preset_bits");
+    ResultRule rule;
+    if (!rule_cascade(from_width, &rule)) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "from_width");
+    return run_threepass_shared(ctx, reads, rule, invert, out_aln, out_status, out_tier, out_inc, out_op, ciglet_cap, out_n_ciglets, stream);
 }
 
 }  // extern "C"

@@ -189,6 +189,15 @@ enum { RW_FSCORE = 0, RW_FSTATUS, RW_FREND, RW_FQEND, RW_RSCORE, RW_RSTATUS, RW_
 zsw_error finish_alignments(zsw_context* ctx, DevBuf* ws, uint32_t n, bool host, const uint8_t* d_status, const uint8_t* d_tier, int invert,
                             zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op,
                             uint64_t ciglet_cap, uint64_t* out_n_ciglets, hipStream_t stream);
+struct RangesDev {  // device arrays of sw_simd_score_ranges for every read (library workspace)
+    uint32_t *score, *rs, *re, *qs, *qe;
+    uint8_t *status, *tier;
+};
+// sw_align_3pass's third pass (zsw_threepass.hip) over ranges that are already on the device, results to the caller's arrays; the
+// caller has opened ctx->timer's interval. pseq: non-null = the shared-profile role (ThreePassArgs::pseq).
+zsw_error threepass_third_pass(zsw_context* ctx, const Staged& st, const RangesDev& rd, const uint8_t* pseq, uint32_t pseq_len, bool host, int invert,
+                               zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap,
+                               uint64_t* out_n_ciglets, hipStream_t stream);
 // the and_then / map chain of sw_simd_score_ranges on device arrays (kernels of zsw_capi.hip)
 hipError_t launch_ranges_prep(uint32_t n, const uint8_t* fstatus, const uint32_t* fqend, uint32_t* qe_masked, hipStream_t stream);
 hipError_t launch_ranges_combine(uint32_t n, const uint32_t* fscore, const uint8_t* fstatus, const uint32_t* frend, const uint32_t* fqend,

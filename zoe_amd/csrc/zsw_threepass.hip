@@ -107,8 +107,12 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
         const uint32_t id = a.list ? a.list[item] : item;
         if (a.status[id] != ZSW_STATUS_SOME) continue;
         uint64_t off = 0;
-        const uint32_t query_len = tp_read_len(a.b, id, &off);
-        const uint8_t* query = a.b.bases + off;
+        const uint32_t read_len = tp_read_len(a.b, id, &off);
+        // three_pass.rs:21-26: `reference` is the sequence the profile walks, `query` the sequence the profile was built from
+        const uint32_t query_len = a.pseq ? a.pseq_len : read_len;
+        const uint8_t* query = a.pseq ? a.pseq : a.b.bases + off;
+        const uint8_t* reference = a.pseq ? a.b.bases + off : a.ref;
+        const uint32_t reference_len = a.pseq ? read_len : a.ref_len;
         const uint32_t score = a.score[id];
         const uint32_t rs = a.rs[id], re = a.re[id], qs = a.qs[id], qe = a.qe[id];
         const uint32_t rlen = re - rs, qlen = qe - qs;
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
         w.maxc = a.maxc;
         zsw_alignment out;
         out.score = score;
-        out.ref_len = a.ref_len;
+        out.ref_len = reference_len;
         out.query_len = query_len;
         out.ciglet_offset = 0;
         bool done = false;
@@ -129,12 +133,12 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                 uint32_t k = 0;
                 for (; k + 4 <= qlen; k += 4) {  // four residues per (unaligned) load
                     uint32_t rw, qw;
-                    __builtin_memcpy(&rw, a.ref + rs + k, 4);
+                    __builtin_memcpy(&rw, reference + rs + k, 4);
                     __builtin_memcpy(&qw, query + qs + k, 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) sum += wt((uint8_t)(rw >> (8 * j)), (uint8_t)(qw >> (8 * j)));
                 }
-                for (; k < qlen; ++k) sum += wt(a.ref[rs + k], query[qs + k]);
+                for (; k < qlen; ++k) sum += wt(reference[rs + k], query[qs + k]);
                 if ((sum < 0 ? 0u : (uint32_t)sum) == score) {
                     w.push(query_len - qe, 'S');
                     w.push(qe - qs, 'M');
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
             auto h_row = [&](uint32_t c) -> int32_t& { return reinterpret_cast<int32_t*>(region)[(uint64_t)c * 64]; };
             auto e_row = [&](uint32_t c) -> int32_t& { return reinterpret_cast<int32_t*>(region)[(uint64_t)(e_off + c) * 64]; };
             auto bt = [&](uint64_t k) -> uint8_t& { return reinterpret_cast<uint8_t*>(region + (bt_off + (k >> 2)) * 64)[k & 3]; };
-            const uint8_t* refb = a.ref + rs;
+            const uint8_t* refb = reference + rs;
             const uint8_t* qb = query + qs;
             int r_fin = 0, c_fin = 0, r_end = 0, c_end = 0;
             bool have = false;
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
             a.fb_list[k] = id;
             continue;
         }
-        out.n_ciglets = a.invert ? w.n_nons + (out.ref_start > 0 ? 1u : 0u) + (a.ref_len > out.ref_end ? 1u : 0u) : w.ncig;
+        out.n_ciglets = a.invert ? w.n_nons + (out.ref_start > 0 ? 1u : 0u) + (reference_len > out.ref_end ? 1u : 0u) : w.ncig;
         a.aln[id] = out;
         a.cig_start[id] = (uint64_t)(uintptr_t)cig;
         a.cig_raw[id] = w.ncig;
