@@ -355,7 +355,10 @@ typedef enum zsw_debug_flag {
      * seed_band_kernel (zsw_score_band.hip) */
     ZSW_DEBUG_SEED_NO_BAND = 2048,
     /* score: the banded kernel walks every read in the full band at once (no narrow first band for short reads) */
-    ZSW_DEBUG_SEED_WIDE_BAND = 4096
+    ZSW_DEBUG_SEED_WIDE_BAND = 4096,
+    /* score: reads the seeded pass hands back walk every row of a long reference as one item each (by default they are cut
+     * into chunks of rows that run as independent items, zsw_score_v2.hpp: ScoreArgsV2::chunk_rows) */
+    ZSW_DEBUG_NO_ROW_CHUNKS = 8192
 } zsw_debug_flag;
 zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags);
 

@@ -329,3 +329,50 @@ def test_diverged_reads_score_ranges_and_alignments_vs_oracle(za, oracle, rate):
         assert al.key(i) == (want.key() if want.status == 0 else (want.status, 0, (0, 0), (0, 0), "", 0, 0)), i
         want3, tier3, _how = oracle.cascade_align_3pass(8, 256, sc, reads[i], ref)
         assert a3.key(i) == (want3.key() if want3.status == 0 else (want3.status, 0, (0, 0), (0, 0), "", 0, 0)), i
+
+
+def test_handed_back_reads_against_a_long_reference_run_in_row_chunks(za, oracle):
+    """Reads the seeded pass hands back (no anchor, failed proof) are scored over all their cells; against a 30 kb reference that
+    pass runs in chunks of rows, each an item of its own, and the largest (score, earliest row, earliest column) over a read's
+    chunks is its result (tests/models/chunk_rows.cpp). Unrelated reads, reads from a duplicated stretch of the reference (the
+    maximum in several rows: the first must win, whichever chunk holds it) and heavily diverged reads: equal to the whole-row pass
+    (ZSW_DEBUG_NO_ROW_CHUNKS) on every read — score, ranges — and to the oracle on a sample."""
+    import torch
+
+    from test_gpu_bounds import diverged_reads
+    from zoe_amd import _lib, synth
+
+    ctx = za.SwContext.get(0)
+    rng = np.random.default_rng(stable_seed("chunks"))
+    ref = bytearray(synth.reference_host(30000))
+    ref[21000:21400] = ref[3000:3400]   # a second copy far below the first
+    ref[12000:12150] = ref[3100:3250]   # and a third
+    ref = bytes(ref)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    r = np.frombuffer(ref, dtype=np.uint8)
+    parts = [rng.choice(alpha, (3000, 150)).astype(np.uint8), diverged_reads(ref, 1500, 150, 150, 5)]
+    dup = np.stack([r[3000 + int(s):3150 + int(s)] for s in rng.integers(0, 250, 1500)])  # pieces of the duplicated stretch ...
+    dup = np.where(rng.random(dup.shape) < 0.12, rng.choice(alpha, dup.shape), dup).astype(np.uint8)  # ... too diverged for the proof
+    reads = np.concatenate(parts + [dup])
+    n = len(reads)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    prof = za.LocalProfilesBatch.new_with_w256(_batch(za, reads), dna, -10, -1)
+    got = prof.sw_score_from_i8(ref)
+    assert ctx.prune_rescored() > 0.6 * n
+    rg = prof.sw_score_ranges_from_i8(za.SeqSrc.Reference(ref))
+    ctx.debug_set(_lib.DEBUG_NO_ROW_CHUNKS)
+    try:
+        want = prof.sw_score_from_i8(ref)
+        wrg = prof.sw_score_ranges_from_i8(za.SeqSrc.Reference(ref))
+    finally:
+        ctx.debug_set(0)
+    for f in ("score", "status", "tier"):
+        assert torch.equal(getattr(got, f), getattr(want, f)), f
+    for f in ("score", "status", "tier", "ref_start", "ref_end", "query_start", "query_end"):
+        assert torch.equal(getattr(rg, f), getattr(wrg, f)), f
+    sc = oracle.Scoring(dna.signed_weights(), dna.mapping.index_map, -10, -1)
+    for i in list(range(0, n, 61)) + list(range(4500, n, 37)):
+        o_st, o_s, o_rr, o_qr, o_t = oracle.cascade_score_ranges(8, 256, sc, reads[i], ref)
+        assert int(rg.status[i]) == o_st, i
+        if o_st == 0:
+            assert (int(rg.score[i]), (int(rg.ref_start[i]), int(rg.ref_end[i])), (int(rg.query_start[i]), int(rg.query_end[i])), int(rg.tier[i])) == (o_s, o_rr, o_qr, o_t), i

@@ -142,6 +142,7 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     ZSW_HIP(ctx, ctx->d_bucket_counts.ensure(64 * 4));
     ctx->prune_chunk = 0;
     ctx->seed_ready = false;
+    ctx->chunk_ready = false;
     const uint32_t flags = ctx->flags();
     const bool any_size = (flags & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE) != 0;
     // a shared-role call (zsw_capi_shared.hip) scores the reads against the profile sequence with the roles swapped and the matrix
@@ -173,6 +174,11 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
                 ctx->d_prune_count.ensure(64 * 4) == hipSuccess) {
                 ZSW_HIP(ctx, hipMemsetAsync(ctx->d_prune_count.p, 0, 64 * 4, stream));  // [1] the call's total, [0], [2..] lists in flight
                 ctx->seed_ready = true;
+                // long references: the reads handed back are scored in chunks of rows (one key per read collects the chunks' results)
+                if (seq_len >= 8192) {
+                    ctx->chunk_ready = ctx->d_chunk_keys.ensure((size_t)n * 8 + 8) == hipSuccess;
+                    if (!ctx->chunk_ready) (void)hipGetLastError();
+                }
             } else {
                 (void)hipGetLastError();
                 ctx->d_seed_work.release();
@@ -230,6 +236,7 @@ ScoreWorkspace score_ws(zsw_context* ctx) {
         w.seed_bytes = ctx->d_seed_work.cap;
         w.seed_gtab = ctx->d_seed_gtab.as<uint2>();
         w.band_dbg = ctx->band_dbg;
+        w.chunk_keys = ctx->chunk_ready ? ctx->d_chunk_keys.as<unsigned long long>() : nullptr;
         w.window_timer = &ctx->timer_window;
         w.prune_fail_list = ctx->d_prune_list.as<uint32_t>();
         w.prune_fail_count = ctx->d_prune_count.as<uint32_t>();
@@ -906,7 +913,7 @@ void zsw_destroy(zsw_context* ctx) {
     DeviceGuard device_guard(ctx);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state, &ctx->d_prune, &ctx->d_prune_list, &ctx->d_prune_count, &ctx->d_seed_work, &ctx->d_seed_gtab, &ctx->d_pseq, &ctx->d_pseq_rev, &ctx->d_sc_t,
+    DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state, &ctx->d_prune, &ctx->d_prune_list, &ctx->d_prune_count, &ctx->d_seed_work, &ctx->d_seed_gtab, &ctx->d_chunk_keys, &ctx->d_pseq, &ctx->d_pseq_rev, &ctx->d_sc_t,
                       &ctx->s_bases, &ctx->s_offsets, &ctx->s_score, &ctx->s_status, &ctx->s_tier, &ctx->s_rend, &ctx->s_qend};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->a_ws) b.release();

@@ -53,8 +53,9 @@ struct zsw_context {
     // that can use it, rebuilt after zsw_set_scoring / zsw_set_reference), a host copy of the reference to build it from
     zsw::SeedIndex seed;
     std::vector<uint8_t> h_ref;
-    zsw::DevBuf d_seed_work, d_seed_gtab;
+    zsw::DevBuf d_seed_work, d_seed_gtab, d_chunk_keys;
     bool seed_ready = false;  // this call's batch takes the seeded pass (workspace and worklist are in place)
+    bool chunk_ready = false;  // ... and d_chunk_keys holds a key per read (long references: the hand-back pass runs in chunks of rows)
     size_t ref_len = 0;
     uint32_t scratch_len = 0;
     size_t exact_slots = 0;

@@ -112,6 +112,7 @@ struct ScoreWorkspace {
     uint2* seed_gtab = nullptr;   // 2 x (ref_len + 2 * SEED_GTAB_PAD) entries: the per-row score table for blocks without an LDS table, then
                                   // the same with every score doubled (the banded kernel's domain, zsw_score_band.hip)
     int32_t* band_dbg = nullptr;  // zsw_debug_band_records
+    unsigned long long* chunk_keys = nullptr;  // one per read: row-chunked full pass over the reads the seeded pass hands back (long references)
     uint32_t debug = 0;           // ZSW_DEBUG_* bits of the context (zsw_debug_set) | its options: kernel-selection overrides
 };
 

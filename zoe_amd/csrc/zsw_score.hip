@@ -226,10 +226,46 @@ static hipError_t launch_cfg_v2(const ScoreArgsV2& a, int mode, hipStream_t stre
     const uint32_t reads_per_block = 2 * (BLOCK / G);
     const uint32_t grid = (a.b.n_items + reads_per_block - 1) / reads_per_block;
     if (grid == 0) return hipSuccess;
-    if (mode == 0) hipLaunchKernelGGL((score_kernel_v2<G, C, 0>), dim3(grid), dim3(BLOCK), 0, stream, a);
-    else if (mode == 1) hipLaunchKernelGGL((score_kernel_v2<G, C, 1>), dim3(grid), dim3(BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL((score_kernel_v2<G, C, 2>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    const dim3 g(grid, a.chunk_rows ? (a.ref_len + a.chunk_rows - 1) / a.chunk_rows : 1u);  // row-chunked launches: one grid row per chunk
+    if (mode == 0) hipLaunchKernelGGL((score_kernel_v2<G, C, 0>), g, dim3(BLOCK), 0, stream, a);
+    else if (mode == 1) hipLaunchKernelGGL((score_kernel_v2<G, C, 1>), g, dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((score_kernel_v2<G, C, 2>), g, dim3(BLOCK), 0, stream, a);
     return hipGetLastError();
+}
+
+// Row-chunked launches (ScoreArgsV2::chunk_rows): the keys of the listed reads before, their results after.
+__global__ void chunk_zero_kernel(const uint32_t* items, const uint32_t* n_dev, uint32_t n_max, unsigned long long* keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < min(*n_dev, n_max)) keys[items[i]] = 0ull;
+}
+__global__ void chunk_finalize_kernel(BatchDev b, const uint32_t* n_dev, const unsigned long long* keys, uint32_t limit, ResultRule rule, ScoreOut out, int mode) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= min(*n_dev, b.n_items)) return;
+    const uint32_t id = b.items[i];
+    const uint32_t len = b.offsets ? (uint32_t)(b.offsets[id + 1] - b.offsets[id]) : b.fixed_len;
+    const unsigned long long key = keys[id];
+    const uint32_t s = (uint32_t)(key >> (CHUNK_ROW_BITS + CHUNK_COL_BITS));
+    const uint32_t row1 = ((1u << CHUNK_ROW_BITS) - 1u) - (uint32_t)((key >> CHUNK_COL_BITS) & ((1u << CHUNK_ROW_BITS) - 1u));
+    const uint32_t col1 = ((1u << CHUNK_COL_BITS) - 1u) - (uint32_t)(key & ((1u << CHUNK_COL_BITS) - 1u));
+    if (len == 0) {
+        out.score[id] = 0;
+        out.status[id] = ZSW_STATUS_EMPTY;
+        if (out.tier) out.tier[id] = 0;
+        if (mode != 0 && out.ref_end) out.ref_end[id] = 0;
+        if (mode == 2 && out.query_end) out.query_end[id] = 0;
+    } else if (s >= limit) {  // near the representable limit: recompute exactly in 32 bits
+        out.fb_list[atomicAdd(out.fb_count, 1u)] = id;
+    } else {
+        uint32_t score;
+        uint8_t status, tier;
+        apply_rule(rule, (uint64_t)s, &score, &status, &tier);
+        out.score[id] = score;
+        out.status[id] = status;
+        if (out.tier) out.tier[id] = tier;
+        const bool some = status == ZSW_STATUS_SOME;
+        if (mode != 0 && out.ref_end) out.ref_end[id] = some ? row1 : 0;
+        if (mode == 2 && out.query_end) out.query_end[id] = some ? col1 : 0;
+    }
 }
 
 static hipError_t launch_table_cfg_v2(const ScoreArgsV2& a, int G, int C, int mode, hipStream_t stream) {
@@ -572,7 +608,29 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         ap.n_items_dev = counter;
         // mode 3 (out.unique, the shared-profile role's first pass): the caller recomputes every read without the flag under its
         // own tie rule, the handed-back reads among them — scoring them here would be thrown away
-        if (!out.unique) pe = launch_table_cfg_v2(ap, g, c, mode, stream);
+        if (!out.unique) {
+            // Against a long reference the few reads handed back are cut into chunks of rows, each an item of its own (a class of
+            // 2,000 reads walking 30,000 rows each is a dozen blocks on 256 CUs): chunks of at least four times the rows a
+            // positive path can span, so that the overlap costs a quarter more cells at most.
+            int maxw = 0;
+            for (int i = 0; i < h_sc.S * h_sc.S; ++i) maxw = std::max(maxw, (int)h_sc.w[i]);
+            const uint64_t overlap = h_sc.gap_extend > 0 ? (uint64_t)longest + (uint64_t)longest * (uint64_t)maxw / (uint64_t)h_sc.gap_extend + 2 : ~0ull;
+            const uint64_t rows = std::max<uint64_t>(4 * overlap, 2048);
+            if (ws.chunk_keys && !(ws.debug & ZSW_DEBUG_NO_ROW_CHUNKS) && h_sc.gap_extend > 0 && rows * 2 <= ref_len && longest < (1u << CHUNK_COL_BITS) &&
+                ref_len < (1u << CHUNK_ROW_BITS) - 2) {
+                ap.chunk_rows = (uint32_t)rows;
+                ap.chunk_overlap = (uint32_t)overlap;
+                ap.chunk_keys = ws.chunk_keys;
+                const uint32_t zgrid = (bb.n_items + 255) / 256;
+                hipLaunchKernelGGL(chunk_zero_kernel, dim3(zgrid), dim3(256), 0, stream, ap.b.items, counter, bb.n_items, ws.chunk_keys);
+                pe = launch_table_cfg_v2(ap, g, c, mode, stream);
+                if (pe != hipSuccess) return pe;
+                hipLaunchKernelGGL(chunk_finalize_kernel, dim3(zgrid), dim3(256), 0, stream, ap.b, counter, ws.chunk_keys, ap.limit, rule, out, mode);
+                pe = hipGetLastError();
+            } else {
+                pe = launch_table_cfg_v2(ap, g, c, mode, stream);
+            }
+        }
         if (pe != hipSuccess) return pe;
         hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, stream, counter, ws.prune_fail_count + 1);
         return hipGetLastError();

@@ -89,7 +89,21 @@ struct ScoreArgsV2 {
     // non-null: the number of items is read from the device (a worklist filled by an earlier kernel of the stream); the grid
     // is sized for b.n_items, blocks past the list return at once
     const uint32_t* n_items_dev = nullptr;
+    // Row-chunked launch (reads handed back by the seeded pass against a long reference: a few thousand reads walking 30,000 rows
+    // each fill a fraction of the chip): chunk_rows > 0 = blockIdx.y is a chunk of reference rows, rows [y * chunk_rows -
+    // chunk_overlap, (y + 1) * chunk_rows) from a zero state; a path that spans more than chunk_overlap rows cannot be positive
+    // (zsw_align_dev.hpp: warmup_rows), so the largest (score, then earliest row, then earliest column) over a read's chunks is
+    // the read's result (host model: tests/models/chunk_rows.cpp). Every chunk folds its result into chunk_keys[read] with one
+    // atomicMax (score << 36 | ~row << 12 | ~column); chunk_finalize_kernel turns the keys into the outputs.
+    uint32_t chunk_rows = 0, chunk_overlap = 0;
+    unsigned long long* chunk_keys = nullptr;
 };
+
+constexpr uint32_t CHUNK_ROW_BITS = 24, CHUNK_COL_BITS = 12;  // references below 2^24 rows (the seeded pass's limit), reads of up to 4,095 bases
+__host__ __device__ inline unsigned long long chunk_key(uint32_t score, uint32_t row1, uint32_t col1) {  // row1 / col1: 1-based, 0 = none
+    return ((unsigned long long)score << (CHUNK_ROW_BITS + CHUNK_COL_BITS)) | ((unsigned long long)(((1u << CHUNK_ROW_BITS) - 1u) - row1) << CHUNK_COL_BITS) |
+           (unsigned long long)(((1u << CHUNK_COL_BITS) - 1u) - col1);
+}
 
 template <int G, int C, int MODE, bool WIDE = false, bool TILED = false>
 __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(ScoreArgsV2 a) {
@@ -177,7 +191,14 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
     uint32_t best = 0;  // true scores (no offset)
     uint32_t Fout = Dr, Hlast = Dr, Hin_prev = Dr;
     int rA = 0, rB = 0;
-    const int R = (int)a.ref_len;
+    // a row-chunked launch sees rows [row_off, row_off + R) as its reference
+    int row_off = 0, R = (int)a.ref_len;
+    if (!TILED && a.chunk_rows) {
+        const int lo = max(0, (int)(blockIdx.y * a.chunk_rows) - (int)a.chunk_overlap), hi = min(R, (int)((blockIdx.y + 1) * a.chunk_rows));
+        row_off = lo;
+        R = max(hi - lo, 0);
+    }
+    const uint8_t* const refp = a.ref + row_off;
     const int T = R + G - 1;
     uint2 bd = make_uint2(0u, 0u);  // TILED: the boundary of the row lane 0 reaches next
     if (TILED) {
@@ -190,11 +211,11 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
             const int row = base - (G - 1) + j;
             if (WIDE) {
                 int idx = WIDE_NEUTRAL;
-                if (row >= 0 && row < R) idx = lut[a.ref[row]];
+                if (row >= 0 && row < R) idx = lut[refp[row]];
                 rpw[WIDE ? j : 0] = (uint16_t)(idx * WIDE_STRIDE);
             } else {
                 int idx = NEUTRAL;
-                if (row >= 0 && row < R) idx = lut[a.ref[row]];
+                if (row >= 0 && row < R) idx = lut[refp[row]];
                 rp[WIDE ? 0 : j] = swt[idx];
             }
         }
@@ -355,6 +376,11 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
             o_true = best_u == 0xffffffffu ? 0x7fffffff : (int)best_u;
         }
         if (a.tile_out != nullptr) return;  // results are written by the last tile
+    }
+    if (!TILED && a.chunk_rows) {  // one chunk of the read's rows: fold (score, first row, first column) into the read's key
+        if (lane < RW && o_valid && o_len != 0 && o_true > 0)
+            atomicMax(&a.chunk_keys[o_id], chunk_key((uint32_t)min(o_true, 0xffff), MODE != 0 ? o_re + (uint32_t)row_off : 0u, MODE == 2 ? o_qe : 0u));
+        return;
     }
     if (lane < RW && o_valid) {
         if (o_len == 0) {
