@@ -51,6 +51,7 @@ pub struct ZswBatch {
     pub fixed_len: u32,
     pub n_reads:   u64,
     pub mem:       i32,
+    pub encoding:  i32,
 }
 
 /// `zsw_alignment`
@@ -70,6 +71,8 @@ pub struct ZswAlignment {
 
 pub const ZSW_OK: i32 = 0;
 pub const ZSW_MEM_HOST: i32 = 0;
+pub const ZSW_ENCODING_BYTES: i32 = 0;
+pub const ZSW_ENCODING_PACKED4: i32 = 1;
 pub const ZSW_MEM_DEVICE: i32 = 1;
 pub const ZSW_STATUS_SOME: u8 = 0;
 pub const ZSW_STATUS_OVERFLOWED: u8 = 1;
@@ -90,6 +93,7 @@ pub enum ZswIntType {
 
 #[link(name = "zoe_sw_hip")]
 unsafe extern "C" {
+    fn zsw_pack4_host(ctx: *mut ZswContext, bases: *const u8, n_reads: u64, len: u32, out_packed: *mut u8) -> i32;
     fn zsw_create(device_id: i32, out: *mut *mut ZswContext) -> i32;
     fn zsw_destroy(ctx: *mut ZswContext);
     fn zsw_last_error_string(ctx: *const ZswContext) -> *const c_char;
@@ -239,6 +243,7 @@ impl HostBatch {
             fixed_len: 0,
             n_reads:   (self.offsets.len() - 1) as u64,
             mem:       ZSW_MEM_HOST,
+            encoding:  ZSW_ENCODING_BYTES,
         }
     }
 }
@@ -740,6 +745,25 @@ impl GpuContext {
     pub fn debug_set(&self, flags: u32) -> Result<(), GpuError> {
         // SAFETY: live context
         self.check(unsafe { zsw_debug_set(self.raw, flags) }, 0, 0)
+    }
+
+    /// `zsw_pack4_host` + a score call on the packed batch (`ZSW_ENCODING_PACKED4`): `reads` are `n` contiguous reads of `len` bytes;
+    /// they cross PCIe as two residue indices per byte. Same results as `sw_score_from_batch`.
+    pub fn sw_score_from_packed_batch<const S: usize>(
+        &self, reference: &[u8], reads: &[u8], len: u32, scoring: &Scoring<'_, S>, cascade: Cascade,
+    ) -> Result<(Vec<Result<MaybeAligned<u32>, ProfileError>>, Vec<u8>), GpuError> {
+        self.configure(scoring, reference)?;
+        let n = if len == 0 { 0 } else { reads.len() / len as usize };
+        let mut packed = vec![0u8; n * ((len as usize + 1) / 2)];
+        // SAFETY: both buffers are sized as the library expects
+        self.check(unsafe { zsw_pack4_host(self.raw, reads.as_ptr(), n as u64, len, packed.as_mut_ptr()) }, scoring.gap_open, scoring.gap_extend)?;
+        let c = ZswBatch { bases: packed.as_ptr(), offsets: ptr::null(), fixed_len: len, n_reads: n as u64, mem: ZSW_MEM_HOST, encoding: ZSW_ENCODING_PACKED4 };
+        let (mut score, mut status, mut tier) = (vec![0u32; n.max(1)], vec![0u8; n.max(1)], vec![0u8; n.max(1)]);
+        // SAFETY: output arrays hold n entries
+        self.check(unsafe { zsw_score_batch_from(self.raw, &c, cascade.from_width, cascade.preset_bits, score.as_mut_ptr(), status.as_mut_ptr(), tier.as_mut_ptr(), ptr::null_mut()) },
+                   scoring.gap_open, scoring.gap_extend)?;
+        tier.truncate(n);
+        Ok(((0..n).map(|i| maybe(status[i], || score[i])).collect(), tier))
     }
 
     /// `zsw_debug_band_records`: tests only — the banded seeded pass reports, per read, the values its decision rests on

@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
         b.fixed_len = L;
         b.n_reads = n;
         b.mem = ZSW_MEM_HOST;
+        b.encoding = ZSW_ENCODING_BYTES;
         std::vector<uint32_t> score(n), rs(n), re(n), qs(n), qe(n), inc(8 * n + 64);
         std::vector<uint8_t> status(n), tier(n), op(inc.size());
         std::vector<zsw_alignment> aln(n);

@@ -67,12 +67,19 @@ typedef struct zsw_context zsw_context;
 /* A batch of profile sequences (reads). Either fixed-length (offsets == NULL, read i occupies
  * bases[i*fixed_len, (i+1)*fixed_len)) or ragged (offsets[n_reads+1], read i = bases[offsets[i], offsets[i+1])).
  * `mem` says where bases/offsets AND the output arrays of the call live. */
+/* How `bases` spells the reads. ZSW_ENCODING_BYTES (0, the default): one byte per base, as in a Nucleotides buffer.
+ * ZSW_ENCODING_PACKED4: two bases per byte as residue indices of the context's ByteIndexMap (index_map[byte], < 16), the first
+ * base of a pair in the low nibble; read i occupies bases[i * ((fixed_len + 1) / 2) ...]. Fixed-length host batches only: a shard
+ * that crosses PCIe at half the bytes (zsw_pack4_host packs a byte batch; the library unpacks on the device). */
+typedef enum zsw_encoding { ZSW_ENCODING_BYTES = 0, ZSW_ENCODING_PACKED4 = 1 } zsw_encoding;
+
 typedef struct zsw_batch {
     const uint8_t* bases;
     const uint64_t* offsets;
     uint32_t fixed_len;
     uint64_t n_reads;
     zsw_mem mem;
+    zsw_encoding encoding;
 } zsw_batch;
 
 /* Per-read alignment record: Alignment<u32> (src/alignment/types/output.rs:264-279) with
@@ -87,6 +94,10 @@ typedef struct zsw_alignment {
 } zsw_alignment;
 
 /* ---- context ------------------------------------------------------------------------------- */
+/* Host utility: packs n_reads reads of `len` bytes each (contiguous) into ZSW_ENCODING_PACKED4 with the context's ByteIndexMap
+ * (zsw_set_scoring first; alphabets of up to 16 letters); out_packed: n_reads * ((len + 1) / 2) bytes. No GPU work. */
+zsw_error zsw_pack4_host(zsw_context* ctx, const uint8_t* bases, uint64_t n_reads, uint32_t len, uint8_t* out_packed);
+
 zsw_error zsw_create(int device_id, zsw_context** out);
 void zsw_destroy(zsw_context* ctx);
 /* The message of the context's last failing call. ctx == NULL: why the last zsw_create of the CALLING THREAD failed

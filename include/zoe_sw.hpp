@@ -177,6 +177,7 @@ class ProfileBatchBase {
         b.fixed_len = 0;
         b.n_reads = offsets_.size() - 1;
         b.mem = ZSW_MEM_HOST;
+        b.encoding = ZSW_ENCODING_BYTES;
         return b;
     }
     void set_reference(const std::string& reference) {
@@ -389,6 +390,7 @@ class SharedProfileBase {
             b.fixed_len = 0;
             b.n_reads = offsets.size() - 1;
             b.mem = ZSW_MEM_HOST;
+            b.encoding = ZSW_ENCODING_BYTES;
             return b;
         }
     };

@@ -527,7 +527,7 @@ def test_host_batch_pipeline_matches_device_batch(za, oracle, dna):
 
     from zoe_amd import _lib, synth
 
-    n, L = 5_300_000, 150  # three chunks, the last one partial
+    n, L = 5_300_000, 150  # three chunks (0.5 M, 4 M, 0.8 M: zsw_capi.hip PIPE_FIRST / PIPE_CHUNK)
     ref = synth.reference_host(2000)
     ctx = za.SwContext.get(0)
     rb = synth.reads_device(ctx, ref, 0, n, L)
@@ -543,9 +543,40 @@ def test_host_batch_pipeline_matches_device_batch(za, oracle, dna):
     assert lib.zsw_score_batch_from(ctx.h, C.byref(b), 8, 256, score.ctypes.data, status.ctypes.data, tier.ctypes.data, None) == 0
     assert np.array_equal(score, dscore) and np.array_equal(status, dstatus) and np.array_equal(tier, dtier)
     sc = osc(oracle, dna, -10, -1)
-    for i in list(range(0, 200)) + list(range(2_499_900, 2_500_100)) + list(range(n - 100, n)):
+    for i in list(range(0, 200)) + list(range(499_900, 500_100)) + list(range(4_499_900, 4_500_100)) + list(range(n - 100, n)):
         o_st, o_s, o_t = oracle.cascade_score(8, 256, sc, host[i * L:(i + 1) * L], ref)
         assert (int(status[i]), int(score[i]) if o_st == S_ else 0) == (o_st, o_s if o_st == S_ else 0), i
+    # the same batch as ZSW_ENCODING_PACKED4 (two residue indices per byte, zsw_pack4_host): half the bytes cross PCIe, the device
+    # spells them out again; lower case, U and N among the reads (index_map sends them to the indices the bytes would have)
+    host2 = host.copy()
+    host2[5:40:7] = np.frombuffer(b"acgtuNnRy"[:5], dtype=np.uint8)[:5]
+    packed = np.zeros(n * ((L + 1) // 2), dtype=np.uint8)
+    assert lib.zsw_pack4_host(ctx.h, host2.ctypes.data, n, L, packed.ctypes.data) == 0
+    bp = _lib.ZswBatch()
+    bp.bases, bp.offsets, bp.fixed_len, bp.n_reads, bp.mem, bp.encoding = packed.ctypes.data, None, L, n, _lib.MEM_HOST, 1
+    b.bases = host2.ctypes.data
+    assert lib.zsw_score_batch_from(ctx.h, C.byref(b), 8, 256, score.ctypes.data, status.ctypes.data, tier.ctypes.data, None) == 0
+    score2, status2, tier2 = np.zeros(n, dtype=np.uint32), np.full(n, 9, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    assert lib.zsw_score_batch_from(ctx.h, C.byref(bp), 8, 256, score2.ctypes.data, status2.ctypes.data, tier2.ctypes.data, None) == 0
+    assert np.array_equal(score2, score) and np.array_equal(status2, status) and np.array_equal(tier2, tier)
+    # a small (single-chunk) packed batch with an odd read length, through the ends call; and the misuse cases
+    Lo, no = 151, 3000
+    small = synth.reads_host(ref, 3, no, Lo)
+    pk = np.zeros(no * ((Lo + 1) // 2), dtype=np.uint8)
+    assert lib.zsw_pack4_host(ctx.h, small.ctypes.data, no, Lo, pk.ctypes.data) == 0
+    outs = [np.zeros(no, dtype=np.uint32) for _ in range(6)]
+    sts = [np.zeros(no, dtype=np.uint8) for _ in range(2)]
+    for enc, base, o, st in ((0, small, outs[:3], sts[0]), (1, pk, outs[3:], sts[1])):
+        bb = _lib.ZswBatch()
+        bb.bases, bb.offsets, bb.fixed_len, bb.n_reads, bb.mem, bb.encoding = base.ctypes.data, None, Lo, no, _lib.MEM_HOST, enc
+        assert lib.zsw_score_ends_batch(ctx.h, C.byref(bb), 1, 16, o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data, st.ctypes.data, None) == 0
+    assert all(np.array_equal(outs[k], outs[k + 3]) for k in range(3)) and np.array_equal(sts[0], sts[1])
+    bad = _lib.ZswBatch()
+    bad.bases, bad.offsets, bad.fixed_len, bad.n_reads, bad.mem, bad.encoding = rb.bases.data_ptr(), None, L, 10, _lib.MEM_DEVICE, 1
+    assert lib.zsw_score_batch_from(ctx.h, C.byref(bad), 8, 256, dev.score.data_ptr(), dev.status.data_ptr(), dev.tier.data_ptr(), None) == -1  # device memory: not packed
+    bad.mem, bad.encoding = _lib.MEM_HOST, 7
+    bad.bases = host.ctypes.data
+    assert lib.zsw_score_batch_from(ctx.h, C.byref(bad), 8, 256, score2.ctypes.data, status2.ctypes.data, tier2.ctypes.data, None) == -1
     del dev, rb
     torch.cuda.empty_cache()
 

@@ -33,3 +33,21 @@ for kind in ("pageable", "pinned"):
         dt = time.perf_counter() - t0
         assert rc == 0
         print(f"{kind} rep {rep}: {n / dt / 1e6:.2f} M reads/s ({dt * 1e3:.0f} ms per {n} reads, host in -> host out)", flush=True)
+
+# ZSW_ENCODING_PACKED4: two residue indices per byte (zsw_pack4_host), pinned host memory: half the bytes cross PCIe
+tb = dev_reads.bases.cpu()
+packed = torch.zeros(n * ((L + 1) // 2), dtype=torch.uint8).pin_memory()
+t0 = time.perf_counter()
+assert lib.zsw_pack4_host(ctx.h, tb.data_ptr(), n, L, packed.data_ptr()) == 0
+print(f"zsw_pack4_host: {time.perf_counter() - t0:.2f} s for {n} reads (one host core)", flush=True)
+ts2 = torch.zeros(n, dtype=torch.int32).pin_memory(); tst2 = torch.zeros(n, dtype=torch.uint8).pin_memory(); tt2 = torch.zeros(n, dtype=torch.uint8).pin_memory()
+b = _lib.ZswBatch()
+b.bases, b.offsets, b.fixed_len, b.n_reads, b.mem, b.encoding = packed.data_ptr(), None, L, n, _lib.MEM_HOST, 1
+for rep in range(3):
+    t0 = time.perf_counter()
+    rc = lib.zsw_score_batch_from(ctx.h, C.byref(b), 8, 256, ts2.data_ptr(), tst2.data_ptr(), tt2.data_ptr(), None)
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    print(f"packed4 pinned rep {rep}: {n / dt / 1e6:.2f} M reads/s ({dt * 1e3:.0f} ms per {n} reads, host in -> host out)", flush=True)
+assert torch.equal(ts2, ts) and torch.equal(tst2, tst) and torch.equal(tt2, tt), "packed input: results differ from the byte form"
+print("packed4 results identical to the byte form", flush=True)

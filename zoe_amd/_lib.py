@@ -33,7 +33,7 @@ INT_TYPES = {"i8": 0, "i16": 1, "i32": 2, "u8": 3, "u16": 4, "u32": 5}
 
 # every symbol include/zoe_sw.h declares (tests/test_capi_symbols.py checks the two lists agree)
 SYMBOLS = [
-    "zsw_create", "zsw_destroy", "zsw_last_error_string", "zsw_device_count", "zsw_set_scoring", "zsw_set_reference",
+    "zsw_pack4_host", "zsw_create", "zsw_destroy", "zsw_last_error_string", "zsw_device_count", "zsw_set_scoring", "zsw_set_reference",
     "zsw_score_batch", "zsw_score_batch_from", "zsw_score_ends_batch", "zsw_score_ranges_batch", "zsw_score_ranges_batch_from", "zsw_align_batch", "zsw_align_batch_from", "zsw_align_3pass_batch", "zsw_align_3pass_batch_from", "zsw_sneaky_snake_batch",
     "zsw_set_profile_sequence", "zsw_score_shared_batch", "zsw_score_shared_batch_from", "zsw_score_ends_shared_batch", "zsw_score_ranges_shared_batch",
     "zsw_score_ranges_shared_batch_from", "zsw_align_shared_batch", "zsw_align_shared_batch_from", "zsw_align_3pass_shared_batch", "zsw_align_3pass_shared_batch_from",
@@ -52,6 +52,7 @@ class ZswBatch(C.Structure):
         ("fixed_len", C.c_uint32),
         ("n_reads", C.c_uint64),
         ("mem", C.c_int),
+        ("encoding", C.c_int),
     ]
 
 
@@ -136,6 +137,7 @@ def load() -> C.CDLL:
     lib.zsw_timing_read_window.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.zsw_debug_set.argtypes = [vp, C.c_uint32]
     lib.zsw_debug_band_records.argtypes = [vp, vp]
+    lib.zsw_pack4_host.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp]
     lib.zsw_prune_rescored.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.zsw_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.zsw_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]

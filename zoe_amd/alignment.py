@@ -436,6 +436,7 @@ class ReadBatch:
         b.fixed_len = self.fixed_len
         b.n_reads = self.n_reads
         b.mem = _lib.MEM_DEVICE
+        b.encoding = 0
         return b
 
     @property

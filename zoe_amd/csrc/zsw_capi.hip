@@ -51,6 +51,44 @@ __global__ void selftest_kernel(uint32_t* out) {
 
 
 // Brings a batch to the device (or validates device pointers), finds the longest read and sizes the workspace.
+// ZSW_ENCODING_PACKED4: two residue indices per byte -> one byte per base (byte_of[index]: a byte the context's map sends to it)
+struct Unpack4 {
+    uint8_t byte_of[16];
+};
+__global__ void unpack4_kernel(const uint8_t* packed, uint64_t n, uint32_t len, Unpack4 u, uint8_t* out) {
+    const uint32_t stride = (len + 1) / 2;
+    const uint64_t total = n * stride;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t read = k / stride;
+        const uint32_t c = 2 * (uint32_t)(k - read * stride);
+        const uint8_t p = packed[k];
+        out[read * len + c] = u.byte_of[p & 15u];
+        if (c + 1 < len) out[read * len + c + 1] = u.byte_of[p >> 4];
+    }
+}
+// reads [first, first + cnt) of a packed host batch: H2D copy of the packed bytes and their expansion into s_bases, on `stream`
+hipError_t copy_packed_chunk(zsw_context* ctx, const zsw_batch* reads, size_t first, size_t cnt, hipStream_t stream) {
+    const uint32_t L = reads->fixed_len;
+    const size_t stride = (L + 1) / 2;
+    hipError_t e = hipMemcpyAsync(ctx->s_packed.as<uint8_t>() + first * stride, reads->bases + first * stride, cnt * stride, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess || cnt == 0) return e;
+    Unpack4 u;
+    for (int k = 0; k < 16; ++k) u.byte_of[k] = 0;
+    bool seen[16] = {false};
+    for (int b = 255; b >= 0; --b) {  // the smallest byte of each index (upper case before lower case)
+        const int idx = ctx->h_sc.index_map[b];
+        if (idx < 16) {
+            u.byte_of[idx] = (uint8_t)b;
+            seen[idx] = true;
+        }
+    }
+    (void)seen;
+    const uint64_t total = (uint64_t)cnt * stride;
+    hipLaunchKernelGGL(unpack4_kernel, dim3((unsigned)std::min<uint64_t>((total + 255) / 256, 65536)), dim3(256), 0, stream,
+                       ctx->s_packed.as<uint8_t>() + first * stride, (uint64_t)cnt, L, u, ctx->s_bases.as<uint8_t>() + first * L);
+    return hipGetLastError();
+}
+
 zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bool want_tier, bool want_ends,
                 uint32_t* out_score, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_rend, uint32_t* out_qend,
                 Staged* st, bool defer_bases_copy) {
@@ -60,6 +98,10 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     if (reads->n_reads > 0x7fffffffull) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "n_reads > 2^31-1 per call");
     if (reads->n_reads && !reads->bases) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "null bases");
     if (!reads->offsets && reads->fixed_len == 0 && reads->n_reads) return ZSW_ERR_EMPTY_SEQUENCE;
+    const bool packed = reads->encoding == ZSW_ENCODING_PACKED4;
+    if (reads->encoding != ZSW_ENCODING_BYTES && !packed) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "unknown zsw_batch.encoding");
+    if (packed && (reads->mem != ZSW_MEM_HOST || reads->offsets || ctx->h_sc.S > 16))
+        return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "ZSW_ENCODING_PACKED4: fixed-length host batches, alphabets of up to 16 letters");
     const uint32_t n = (uint32_t)reads->n_reads;
     ZSW_HIP(ctx, hipSetDevice(ctx->device));
     st->b.n_reads = n;
@@ -69,7 +111,10 @@ zsw_error stage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, bo
     if (reads->mem == ZSW_MEM_HOST) {
         size_t total = reads->offsets ? (size_t)reads->offsets[n] : (size_t)n * reads->fixed_len;
         ZSW_HIP(ctx, ctx->s_bases.ensure(total + 16));
-        if (!defer_bases_copy) ZSW_HIP(ctx, hipMemcpyAsync(ctx->s_bases.p, reads->bases, total, hipMemcpyHostToDevice, stream));
+        if (packed) {  // half the bytes cross PCIe; the device spells them out as bytes again (one representative byte per residue index)
+            ZSW_HIP(ctx, ctx->s_packed.ensure((size_t)n * ((reads->fixed_len + 1) / 2) + 16));
+            if (!defer_bases_copy) ZSW_HIP(ctx, copy_packed_chunk(ctx, reads, 0, n, stream));
+        } else if (!defer_bases_copy) ZSW_HIP(ctx, hipMemcpyAsync(ctx->s_bases.p, reads->bases, total, hipMemcpyHostToDevice, stream));
         st->b.bases = ctx->s_bases.as<uint8_t>();
         st->b.offsets = nullptr;
         st->max_len = reads->fixed_len;
@@ -264,7 +309,8 @@ zsw_error unstage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, 
     return ZSW_OK;
 }
 
-constexpr uint32_t PIPE_CHUNK = 2'500'000;  // reads per chunk of the host-batch pipeline (375 MB at 150 bp)
+constexpr uint32_t PIPE_CHUNK = 4'000'000;  // reads per chunk of the host-batch pipeline (600 MB at 150 bp; fewer, larger chunks keep the kernels near their large-batch rate)
+constexpr uint32_t PIPE_FIRST = 500'000;    // ... and of its first chunk, whose copy nothing hides
 
 zsw_error run_score(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, bool want_ends, uint32_t* out_score,
                     uint8_t* out_status, uint8_t* out_tier, uint32_t* out_rend, uint32_t* out_qend, void* stream_) {
@@ -292,24 +338,41 @@ zsw_error run_score(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
         if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "score launch", e);
         return unstage(ctx, reads, stream, st, out_score, out_status, out_tier, out_rend, out_qend);
     }
+    // chunks: a small first one (its copy is the only one nothing hides), then PIPE_CHUNK reads each
     const uint32_t n = (uint32_t)reads->n_reads, L = reads->fixed_len;
-    const uint32_t n_chunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
+    std::vector<uint32_t> starts;
+    for (uint32_t first = 0; first < n; first += first == 0 ? PIPE_FIRST : PIPE_CHUNK) starts.push_back(first);
+    starts.push_back(n);
+    const uint32_t n_chunks = (uint32_t)starts.size() - 1;
     if (!ctx->copy_stream) ZSW_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    while (ctx->copy_events.size() < n_chunks) {
+    while (ctx->copy_events.size() < 2 * (size_t)n_chunks) {
         hipEvent_t ev;
         ZSW_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         ctx->copy_events.push_back(ev);
     }
     auto copy_chunk = [&](uint32_t k) -> hipError_t {
-        const size_t first = (size_t)k * PIPE_CHUNK, cnt = std::min<size_t>(PIPE_CHUNK, n - first);
-        hipError_t e = hipMemcpyAsync(ctx->s_bases.as<uint8_t>() + first * L, reads->bases + first * L, cnt * L, hipMemcpyHostToDevice,
-                                      ctx->copy_stream);
+        const size_t first = starts[k], cnt = starts[k + 1] - starts[k];
+        hipError_t e = reads->encoding == ZSW_ENCODING_PACKED4
+                           ? copy_packed_chunk(ctx, reads, first, cnt, ctx->copy_stream)
+                           : hipMemcpyAsync(ctx->s_bases.as<uint8_t>() + first * L, reads->bases + first * L, cnt * L, hipMemcpyHostToDevice, ctx->copy_stream);
         if (e != hipSuccess) return e;
         return hipEventRecord(ctx->copy_events[k], ctx->copy_stream);
     };
+    // the results of chunk k go back on the copy stream once its kernels are done (under the kernels of chunk k + 1)
+    auto results_back = [&](uint32_t k) -> hipError_t {
+        const size_t first = starts[k], cnt = starts[k + 1] - starts[k];
+        hipError_t e = hipEventRecord(ctx->copy_events[n_chunks + k], stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->copy_events[n_chunks + k], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_score + first, st.d_score + first, cnt * 4, hipMemcpyDeviceToHost, ctx->copy_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_status + first, st.d_status + first, cnt, hipMemcpyDeviceToHost, ctx->copy_stream);
+        if (e == hipSuccess && st.d_tier && out_tier) e = hipMemcpyAsync(out_tier + first, st.d_tier + first, cnt, hipMemcpyDeviceToHost, ctx->copy_stream);
+        if (e == hipSuccess && st.d_rend && out_rend) e = hipMemcpyAsync(out_rend + first, st.d_rend + first, cnt * 4, hipMemcpyDeviceToHost, ctx->copy_stream);
+        if (e == hipSuccess && st.d_qend && out_qend) e = hipMemcpyAsync(out_qend + first, st.d_qend + first, cnt * 4, hipMemcpyDeviceToHost, ctx->copy_stream);
+        return e;
+    };
     ZSW_HIP(ctx, copy_chunk(0));
     for (uint32_t k = 0; k < n_chunks; ++k) {
-        const uint32_t first = k * PIPE_CHUNK, cnt = std::min<uint32_t>(PIPE_CHUNK, n - first);
+        const uint32_t first = starts[k], cnt = starts[k + 1] - starts[k];
         ZSW_HIP(ctx, hipStreamWaitEvent(stream, ctx->copy_events[k], 0));
         BatchDev bk = st.b;
         bk.bases = st.b.bases + (size_t)first * L;
@@ -324,8 +387,11 @@ zsw_error run_score(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
                                     (uint32_t)ctx->ref_len, rule, ok, score_ws(ctx), stream, &ctx->timer, want_ends ? 2 : 0);
         if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "score launch", e);
         if (k + 1 < n_chunks) ZSW_HIP(ctx, copy_chunk(k + 1));  // issued after the launch: it runs under chunk k's kernel
+        ZSW_HIP(ctx, results_back(k));
     }
-    return unstage(ctx, reads, stream, st, out_score, out_status, out_tier, out_rend, out_qend);
+    ZSW_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    ZSW_HIP(ctx, hipStreamSynchronize(stream));
+    return ZSW_OK;
 }
 
 
@@ -914,7 +980,7 @@ void zsw_destroy(zsw_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     DevBuf* bufs[] = {&ctx->d_sc, &ctx->d_ref, &ctx->d_fb_list, &ctx->d_fb_count, &ctx->d_scratch, &ctx->d_maxlen, &ctx->d_bucket_items, &ctx->d_bucket_counts, &ctx->d_tile_buf, &ctx->d_tile_state, &ctx->d_prune, &ctx->d_prune_list, &ctx->d_prune_count, &ctx->d_seed_work, &ctx->d_seed_gtab, &ctx->d_chunk_keys, &ctx->d_pseq, &ctx->d_pseq_rev, &ctx->d_sc_t,
-                      &ctx->s_bases, &ctx->s_offsets, &ctx->s_score, &ctx->s_status, &ctx->s_tier, &ctx->s_rend, &ctx->s_qend};
+                      &ctx->s_bases, &ctx->s_packed, &ctx->s_offsets, &ctx->s_score, &ctx->s_status, &ctx->s_tier, &ctx->s_rend, &ctx->s_qend};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->a_ws) b.release();
     for (DevBuf& b : ctx->r_ws) b.release();
@@ -1195,6 +1261,22 @@ zsw_error zsw_selftest(zsw_context* ctx) {
 zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags) {
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     ctx->debug = flags;
+    return ZSW_OK;
+}
+
+zsw_error zsw_pack4_host(zsw_context* ctx, const uint8_t* bases, uint64_t n_reads, uint32_t len, uint8_t* out_packed) {
+    if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
+    if (!ctx->scoring_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "scoring not set");
+    if ((n_reads && len && (!bases || !out_packed)) || ctx->h_sc.S > 16) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "zsw_pack4_host: null argument, or an alphabet above 16 letters");
+    const uint8_t* map = ctx->h_sc.index_map;
+    const uint32_t stride = (len + 1) / 2;
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        const uint8_t* r = bases + i * len;
+        uint8_t* o = out_packed + i * stride;
+        uint32_t c = 0;
+        for (; c + 1 < len; c += 2) o[c / 2] = (uint8_t)(map[r[c]] | (map[r[c + 1]] << 4));
+        if (c < len) o[c / 2] = map[r[c]];
+    }
     return ZSW_OK;
 }
 

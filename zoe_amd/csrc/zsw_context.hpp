@@ -60,7 +60,7 @@ struct zsw_context {
     uint32_t scratch_len = 0;
     size_t exact_slots = 0;
     // staging for host-memory batches
-    zsw::DevBuf s_bases, s_offsets, s_score, s_status, s_tier, s_rend, s_qend;
+    zsw::DevBuf s_bases, s_packed, s_offsets, s_score, s_status, s_tier, s_rend, s_qend;
     // alignment workspace (zsw_align.hip)
     zsw::DevBuf a_ws[30];
     // score_ranges workspace

@@ -256,7 +256,7 @@ zsw_error zsw_group_score_batch_from(zsw_group* g, const zsw_batch* reads, int f
             b.bases = reads->bases + base;
             b.offsets = rebased.data();
         } else {
-            b.bases = reads->bases + first * reads->fixed_len;
+            b.bases = reads->bases + first * (reads->encoding == ZSW_ENCODING_PACKED4 ? (uint64_t)(reads->fixed_len + 1) / 2 : (uint64_t)reads->fixed_len);
         }
         return zsw_score_batch_from(g->ctx[(size_t)i], &b, from_width, preset_bits, out_score + first, out_status + first,
                                     out_tier ? out_tier + first : nullptr, nullptr);
@@ -299,7 +299,7 @@ zsw_error group_align(zsw_group* g, const zsw_batch* reads, zsw_alignment* out_a
             b.bases = reads->bases + base;
             b.offsets = rebased.data();
         } else {
-            b.bases = reads->bases + first * reads->fixed_len;
+            b.bases = reads->bases + first * (reads->encoding == ZSW_ENCODING_PACKED4 ? (uint64_t)(reads->fixed_len + 1) / 2 : (uint64_t)reads->fixed_len);
         }
         ShardAlign& s = sh[(size_t)i];
         s.aln.resize(count);
