@@ -369,7 +369,10 @@ typedef enum zsw_debug_flag {
     ZSW_DEBUG_SEED_WIDE_BAND = 4096,
     /* score: reads the seeded pass hands back walk every row of a long reference as one item each (by default they are cut
      * into chunks of rows that run as independent items, zsw_score_v2.hpp: ScoreArgsV2::chunk_rows) */
-    ZSW_DEBUG_NO_ROW_CHUNKS = 8192
+    ZSW_DEBUG_NO_ROW_CHUNKS = 8192,
+    /* score + ranges: the reverse pass of sw_simd_score_ranges by the exact prefix kernel for every read (by default a second seeded
+     * pass over the reversed sequences settles the reads whose maximum sits in one cell, forward and reversed) */
+    ZSW_DEBUG_RANGES_EXACT_REVERSE = 16384
 } zsw_debug_flag;
 zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags);
 

@@ -376,3 +376,64 @@ def test_handed_back_reads_against_a_long_reference_run_in_row_chunks(za, oracle
         assert int(rg.status[i]) == o_st, i
         if o_st == 0:
             assert (int(rg.score[i]), (int(rg.ref_start[i]), int(rg.ref_end[i])), (int(rg.query_start[i]), int(rg.query_end[i])), int(rg.tier[i])) == (o_s, o_rr, o_qr, o_t), i
+
+
+def test_ranges_reverse_pass_as_a_second_seeded_pass(za, oracle):
+    """sw_simd_score_ranges' second pass (striped.rs:355-388) runs, for the reads whose forward maximum sits in one cell, as a seeded
+    pass over the reversed reads and the reversed reference; a read is settled if the reversed maximum sits in one cell too, every
+    other read takes the exact prefix kernel. 400,000 reads — synthetic, tie-rich (tandem repeats, a duplicated stretch, two halves
+    from different places, low complexity) and diverged — must equal the all-exact reverse pass (ZSW_DEBUG_RANGES_EXACT_REVERSE) in
+    every field, the 3-pass alignments built on the ranges too, and the oracle on a sample."""
+    import torch
+
+    from test_gpu_bounds import diverged_reads
+    from zoe_amd import _lib, synth
+
+    ctx = za.SwContext.get(0)
+    rng = np.random.default_rng(stable_seed("rev-seeded"))
+    ref = bytearray(synth.reference_host(2500))
+    ref[900:1000] = ref[300:400]
+    for i in range(1500 + 2, 1580):
+        ref[i] = ref[i - 2]
+    ref = bytes(ref)
+    r = np.frombuffer(ref, dtype=np.uint8)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    L = 150
+    syn = synth.reads_host(ref, 17, 300_000, L)
+    ties = np.empty((60_000, L), dtype=np.uint8)
+    for i in range(len(ties)):
+        kind = i % 5
+        p = int(rng.integers(0, len(r) - L))
+        if kind == 0:
+            p = int(rng.integers(250, 320))          # inside the duplicated stretch
+        elif kind == 1:
+            p = int(rng.integers(1440, 1520))        # across the tandem repeat
+        q = r[p:p + L].copy()
+        if kind == 2:                                # two halves from different places
+            p2 = int(rng.integers(0, len(r) - L))
+            q[L // 2:] = r[p2:p2 + L - L // 2]
+        elif kind == 3:
+            q = rng.choice(alpha[:2], L).astype(np.uint8)
+        ties[i] = q
+    reads = np.concatenate([syn, ties, diverged_reads(ref, 20_000, L, 50, 3), diverged_reads(ref, 20_000, L, 100, 4)])
+    n = len(reads)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    prof = za.LocalProfilesBatch.new_with_w256(_batch(za, reads), dna, -10, -1)
+    got = prof.sw_score_ranges_from_i8(za.SeqSrc.Reference(ref))
+    got3 = prof.sw_align_from_i8_3pass(za.SeqSrc.Reference(ref))
+    ctx.debug_set(_lib.DEBUG_RANGES_EXACT_REVERSE)
+    try:
+        want = prof.sw_score_ranges_from_i8(za.SeqSrc.Reference(ref))
+        want3 = prof.sw_align_from_i8_3pass(za.SeqSrc.Reference(ref))
+    finally:
+        ctx.debug_set(0)
+    for f in ("score", "status", "tier", "ref_start", "ref_end", "query_start", "query_end"):
+        assert torch.equal(getattr(got, f), getattr(want, f)), f
+    assert np.array_equal(got3.status, want3.status) and np.array_equal(got3.records, want3.records)
+    assert np.array_equal(got3.inc, want3.inc) and np.array_equal(got3.op, want3.op)
+    sc = oracle.Scoring(dna.signed_weights(), dna.mapping.index_map, -10, -1)
+    for i in list(range(0, 300_000, 1511)) + list(range(300_000, n, 257)):
+        o_st, o_s, o_rr, o_qr, o_t = oracle.cascade_score_ranges(8, 256, sc, reads[i], ref)
+        assert int(got.status[i]) == o_st, i
+        if o_st == 0:
+            assert (int(got.score[i]), (int(got.ref_start[i]), int(got.ref_end[i])), (int(got.query_start[i]), int(got.query_end[i])), int(got.tier[i])) == (o_s, o_rr, o_qr, o_t), i

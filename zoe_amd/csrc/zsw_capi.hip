@@ -438,8 +438,21 @@ zsw_error ranges_device(zsw_context* ctx, const Staged& st, const ResultRule& ru
     fo.query_end = ws[RW_FQEND].as<uint32_t>();
     fo.fb_list = ctx->d_fb_list.as<uint32_t>();
     fo.fb_count = ctx->d_fb_count.as<uint32_t>();
+    // The reverse pass as a second seeded pass (as the shared role does it, zsw_capi_shared.hip): when this batch takes the seeded
+    // pass, the forward pass also reports whether a read's maximum sits in ONE cell (mode 3). Then every alignment that scores it
+    // ends there, i.e. lies inside the prefixes the reverse pass of striped.rs:355-388 is restricted to, and the cells of the
+    // reversed matrix that hold the score are the same with or without the restriction (tests/models/reverse_unique.cpp): a seeded
+    // pass over the reversed reads and the reversed reference, whole sequences, finds them; if that is one cell too, it is the
+    // start. Every other read goes to the exact reverse kernel below.
+    const bool seeded_reverse = ctx->seed_ready && !ctx->shared_call && !(ctx->flags() & ZSW_DEBUG_RANGES_EXACT_REVERSE) && ctx->ref_len > 0 &&
+                                ctx->seed.valid && ctx->seed.usable && st.max_len <= SEED_MAX_LEN;
+    if (seeded_reverse) {
+        ZSW_HIP(ctx, ws[RW_UNIQ_F].ensure((size_t)n + 4));
+        ZSW_HIP(ctx, hipMemsetAsync(ws[RW_UNIQ_F].p, 0, n, stream));
+        fo.unique = ws[RW_UNIQ_F].as<uint8_t>();
+    }
     hipError_t e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(),
-                                (uint32_t)ctx->ref_len, rule, fo, score_ws(ctx), stream, nullptr, 2);
+                                (uint32_t)ctx->ref_len, rule, fo, score_ws(ctx), stream, nullptr, seeded_reverse ? 3 : 2);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "ranges forward pass", e);
     const uint32_t g256 = (n + 255) / 256;
     hipLaunchKernelGGL(ranges_prep_kernel, dim3(g256), dim3(256), 0, stream, n, fo.status, fo.query_end, ws[RW_QEM].as<uint32_t>());
@@ -451,9 +464,56 @@ zsw_error ranges_device(zsw_context* ctx, const Staged& st, const ResultRule& ru
     ro.query_end = ws[RW_RQS].as<uint32_t>();
     ro.fb_list = ctx->d_fb_list.as<uint32_t>();
     ro.fb_count = ctx->d_fb_count.as<uint32_t>();
-    e = launch_score_rev(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len,
-                         rule, ro, score_ws(ctx), fo.ref_end, ws[RW_QEM].as<uint32_t>(), fo.score, ws[RW_GTAB].as<uint2>(), stream);
-    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "ranges reverse pass", e);
+    BatchDev rest = st.b;
+    bool run_exact = true;
+    if (seeded_reverse) {
+        const size_t R = ctx->ref_len;
+        if (!ctx->seed_rev.valid) {
+            std::vector<uint8_t> rev(ctx->h_ref.rbegin(), ctx->h_ref.rend());
+            ZSW_HIP(ctx, ctx->d_ref_rev.ensure(R + 16));
+            ZSW_HIP(ctx, hipMemcpyAsync(ctx->d_ref_rev.p, rev.data(), R, hipMemcpyHostToDevice, stream));
+            ZSW_HIP(ctx, hipStreamSynchronize(stream));  // `rev` goes out of scope
+            ZSW_HIP(ctx, seed_index_update(&ctx->seed_rev, ctx->h_sc, rev.data(), R));
+        }
+        if (ctx->seed_rev.usable) {
+            uint64_t bytes = (uint64_t)n * st.b.fixed_len;
+            if (st.b.offsets) {
+                ZSW_HIP(ctx, hipMemcpyAsync(&bytes, st.b.offsets + n, 8, hipMemcpyDeviceToHost, stream));
+                ZSW_HIP(ctx, hipStreamSynchronize(stream));
+            }
+            ZSW_HIP(ctx, ws[RW_RBASES].ensure(bytes + 16));
+            ZSW_HIP(ctx, ws[RW_UNIQ_R].ensure((size_t)n + 4));
+            ZSW_HIP(ctx, ws[RW_ULIST].ensure((size_t)n * 4 + 4));
+            ZSW_HIP(ctx, ws[RW_UCOUNT].ensure(4));
+            ZSW_HIP(ctx, hipMemsetAsync(ws[RW_UNIQ_R].p, 0, n, stream));
+            ZSW_HIP(ctx, launch_reverse_reads(st.b, bytes, ws[RW_RBASES].as<uint8_t>(), stream));
+            BatchDev brev = st.b;
+            brev.bases = ws[RW_RBASES].as<uint8_t>();
+            ScoreOut o3 = ro;  // rows: positions of the reversed reference; columns: positions of the reversed read
+            o3.unique = ws[RW_UNIQ_R].as<uint8_t>();
+            o3.skip_handed_back = true;
+            ScoreWorkspace w = score_ws(ctx);
+            w.seed = &ctx->seed_rev;
+            w.band_dbg = nullptr;
+            hipError_t e3 = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, brev, st.max_len, ctx->d_ref_rev.as<uint8_t>(), (uint32_t)R, rule, o3, w, stream,
+                                         nullptr, 3);
+            if (e3 != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "ranges: seeded reverse pass", e3);
+            ZSW_HIP(ctx, hipMemsetAsync(ws[RW_UCOUNT].p, 0, 4, stream));
+            ZSW_HIP(ctx, launch_settle_reverse(st.b, n, (uint32_t)R, ws[RW_UNIQ_F].as<uint8_t>(), ws[RW_UNIQ_R].as<uint8_t>(), fo.score, fo.status, ro.score,
+                                               ro.status, ro.query_end, ro.ref_end, ws[RW_ULIST].as<uint32_t>(), ws[RW_UCOUNT].as<uint32_t>(), stream));
+            uint32_t left = 0;
+            ZSW_HIP(ctx, hipMemcpyAsync(&left, ws[RW_UCOUNT].p, 4, hipMemcpyDeviceToHost, stream));
+            ZSW_HIP(ctx, hipStreamSynchronize(stream));
+            rest.items = ws[RW_ULIST].as<uint32_t>();
+            rest.n_items = left;
+            run_exact = left > 0;
+        }
+    }
+    if (run_exact) {
+        e = launch_score_rev(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, rest, st.max_len, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len,
+                             rule, ro, score_ws(ctx), fo.ref_end, ws[RW_QEM].as<uint32_t>(), fo.score, ws[RW_GTAB].as<uint2>(), stream);
+        if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "ranges reverse pass", e);
+    }
     out->score = ws[RW_O0].as<uint32_t>();
     out->rs = ws[RW_O1].as<uint32_t>();
     out->re = ws[RW_O2].as<uint32_t>();
@@ -986,6 +1046,8 @@ void zsw_destroy(zsw_context* ctx) {
     for (DevBuf& b : ctx->r_ws) b.release();
     for (DevBuf& b : ctx->sh_ws) b.release();
     seed_index_release(&ctx->seed);
+    seed_index_release(&ctx->seed_rev);
+    ctx->d_ref_rev.release();
     seed_index_release(&ctx->seed_shared);
     seed_index_release(&ctx->seed_shared_rev);
     ctx->timer.destroy();
@@ -1043,6 +1105,7 @@ zsw_error zsw_set_scoring(zsw_context* ctx, const int8_t* weights, int S, const 
     }
     ctx->scoring_set = true;
     ctx->seed.valid = false;  // the index spells k-mers with the matrix's good residues
+    ctx->seed_rev.valid = false;
     ctx->seed_shared.valid = false;
     ctx->seed_shared_rev.valid = false;
     return ZSW_OK;
@@ -1063,6 +1126,7 @@ zsw_error zsw_set_reference(zsw_context* ctx, const uint8_t* reference, size_t l
         else ZSW_HIP(ctx, hipMemcpy(ctx->h_ref.data(), reference, len, hipMemcpyDeviceToHost));
     }
     ctx->seed.valid = false;
+    ctx->seed_rev.valid = false;
     ctx->ref_len = len;
     ctx->reference_set = true;
     return ZSW_OK;

@@ -95,6 +95,30 @@ __global__ void settle_reverse_kernel(BatchDev b, uint32_t n, uint32_t plen, con
     }
 }
 
+}  // namespace
+
+namespace zsw {
+namespace capi {
+// (also used by the read-as-profile role's ranges, zsw_capi.hip: its reverse pass as a second seeded pass)
+hipError_t launch_reverse_reads(const BatchDev& b, uint64_t total_bases, uint8_t* out, hipStream_t stream) {
+    if (b.offsets) hipLaunchKernelGGL(reverse_reads_kernel, dim3((b.n_reads + 255) / 256), dim3(256), 0, stream, b, total_bases, out);
+    else if (total_bases) hipLaunchKernelGGL(reverse_reads_kernel, dim3((unsigned)((total_bases + 255) / 256)), dim3(256), 0, stream, b, total_bases, out);
+    return hipGetLastError();
+}
+// read_side / other_side: the reversed pass's ends in the reversed read / in the reversed other sequence (of other_len residues); on
+// return the inclusive starts in the sequences themselves for the settled reads
+hipError_t launch_settle_reverse(const BatchDev& b, uint32_t n, uint32_t other_len, const uint8_t* uf, const uint8_t* ur, const uint32_t* fscore,
+                                 const uint8_t* fstatus, const uint32_t* rscore, const uint8_t* rstatus, uint32_t* read_side, uint32_t* other_side,
+                                 uint32_t* list, uint32_t* count, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(settle_reverse_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, b, n, other_len, uf, ur, fscore, fstatus, rscore, rstatus,
+                              read_side, other_side, list, count);
+    return hipGetLastError();
+}
+}  // namespace capi
+}  // namespace zsw
+
+namespace {
+
 zsw_error check_shared(zsw_context* ctx) {
     if (!ctx) return ZSW_ERR_INVALID_ARGUMENT;
     if (!ctx->scoring_set) return fail(ctx, ZSW_ERR_NOT_CONFIGURED, "scoring not set");
@@ -152,6 +176,7 @@ zsw_error shared_ends_device(zsw_context* ctx, const Staged& st, const ResultRul
         o2.fb_list = ctx->d_fb_list.as<uint32_t>();
         o2.fb_count = ctx->d_fb_count.as<uint32_t>();
         o2.unique = ws[SH_UNIQUE].as<uint8_t>();
+        o2.skip_handed_back = true;
         hipError_t e = launch_score(ctx->d_sc_t.as<ScoringDev>(), h_t, st.b, st.max_len, ctx->d_pseq.as<uint8_t>(), (uint32_t)ctx->pseq_len, rule, o2,
                                     score_ws(ctx), stream, nullptr, 3);
         if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "shared ends: role-swapped seeded pass", e);
@@ -332,6 +357,7 @@ zsw_error ranges_shared_device(zsw_context* ctx, const Staged& st, const ResultR
             o3.fb_list = ctx->d_fb_list.as<uint32_t>();
             o3.fb_count = ctx->d_fb_count.as<uint32_t>();
             o3.unique = ws[SH_UNIQUE_R].as<uint8_t>();
+            o3.skip_handed_back = true;
             ScoreWorkspace w = score_ws(ctx);
             w.seed = &ctx->seed_shared_rev;
             hipError_t e3 = launch_score(ctx->d_sc_t.as<ScoringDev>(), h_t, brev, st.max_len, ctx->d_pseq_rev.as<uint8_t>(), (uint32_t)plen, rule, o3, w,

@@ -52,6 +52,10 @@ struct zsw_context {
     // seeded exact score pass (zsw_score_seed.hip): index of the reference under the current matrix (built with the first batch
     // that can use it, rebuilt after zsw_set_scoring / zsw_set_reference), a host copy of the reference to build it from
     zsw::SeedIndex seed;
+    // the same for the REVERSED reference (d_ref_rev): the reverse pass of sw_simd_score_ranges as a second seeded pass over the
+    // reversed reads (zsw_capi.hip, ranges_device); built with the first such call
+    zsw::SeedIndex seed_rev;
+    zsw::DevBuf d_ref_rev;
     std::vector<uint8_t> h_ref;
     zsw::DevBuf d_seed_work, d_seed_gtab, d_chunk_keys;
     bool seed_ready = false;  // this call's batch takes the seeded pass (workspace and worklist are in place)
@@ -64,7 +68,7 @@ struct zsw_context {
     // alignment workspace (zsw_align.hip)
     zsw::DevBuf a_ws[30];
     // score_ranges workspace
-    zsw::DevBuf r_ws[20];
+    zsw::DevBuf r_ws[24];
     zsw::KernelTimer timer;
     zsw::KernelTimer timer_window;  // seed_window_kernel launches alone
     std::string err;
@@ -186,7 +190,7 @@ enum { WS_SCORE = 0, WS_STATUS, WS_TIER, WS_REND, WS_ITEMS, WS_RING, WS_CIG, WS_
        WS_FBLIST, WS_FBCOUNT, WS_OINC, WS_OOP, WS_CIG2, WS_RING2, WS_KEYS_IN, WS_KEYS_OUT, WS_VALS_IN, WS_SORT_TMP, WS_GTABLE, WS_FBMETA,
        WS_ITEMS2, WS_SAFE };
 enum { RW_FSCORE = 0, RW_FSTATUS, RW_FREND, RW_FQEND, RW_RSCORE, RW_RSTATUS, RW_RRS, RW_RQS, RW_QEM, RW_GTAB, RW_MIS, RW_O0, RW_O1,
-       RW_O2, RW_O3, RW_O4, RW_O5, RW_FTIER };
+       RW_O2, RW_O3, RW_O4, RW_O5, RW_FTIER, RW_UNIQ_F, RW_UNIQ_R, RW_RBASES, RW_ULIST, RW_UCOUNT };
 zsw_error finish_alignments(zsw_context* ctx, DevBuf* ws, uint32_t n, bool host, const uint8_t* d_status, const uint8_t* d_tier, int invert,
                             zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op,
                             uint64_t ciglet_cap, uint64_t* out_n_ciglets, hipStream_t stream);
@@ -199,6 +203,12 @@ struct RangesDev {  // device arrays of sw_simd_score_ranges for every read (lib
 zsw_error threepass_third_pass(zsw_context* ctx, const Staged& st, const RangesDev& rd, const uint8_t* pseq, uint32_t pseq_len, bool host, int invert,
                                zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap,
                                uint64_t* out_n_ciglets, hipStream_t stream);
+// zsw_capi_shared.hip: every read reversed in place of a copy of the batch; and the settlement of a reversed seeded pass (a read is
+// done if both maxima sit in one cell each and the scores agree; the others are listed for the exact reverse kernel)
+hipError_t launch_reverse_reads(const BatchDev& b, uint64_t total_bases, uint8_t* out, hipStream_t stream);
+hipError_t launch_settle_reverse(const BatchDev& b, uint32_t n, uint32_t other_len, const uint8_t* uf, const uint8_t* ur, const uint32_t* fscore,
+                                 const uint8_t* fstatus, const uint32_t* rscore, const uint8_t* rstatus, uint32_t* read_side, uint32_t* other_side,
+                                 uint32_t* list, uint32_t* count, hipStream_t stream);
 // the and_then / map chain of sw_simd_score_ranges on device arrays (kernels of zsw_capi.hip)
 hipError_t launch_ranges_prep(uint32_t n, const uint8_t* fstatus, const uint32_t* fqend, uint32_t* qe_masked, hipStream_t stream);
 hipError_t launch_ranges_combine(uint32_t n, const uint32_t* fscore, const uint8_t* fstatus, const uint32_t* frend, const uint32_t* fqend,

@@ -68,10 +68,11 @@ struct ScoreOut {
     // (seed_safe_start, zsw_seed.hpp); the caller presets 0xffffffff = no certificate, the seeded window kernel fills the rest
     uint32_t* safe_row = nullptr;
     // optional (mode 3, the banded seeded pass only): 1 where the read's maximum sits in exactly one cell of its matrix — the ends
-    // then do not depend on the tie rule (zsw_capi_shared.hip). The caller presets 0; kernels that do not know leave it. With
-    // this pointer set the seeded pass does not score the reads it hands back (launch_score, seed_items): the caller recomputes
-    // every read without the flag under its own rule, those among them
+    // then do not depend on the tie rule (zsw_capi_shared.hip; the reverse pass of sw_simd_score_ranges as a second seeded pass).
+    // The caller presets 0; kernels that do not know leave it.
     uint8_t* unique = nullptr;
+    // the seeded pass does not score the reads it hands back (the caller computes every read without `unique` by other means)
+    bool skip_handed_back = false;
 };
 
 struct KernelTimer;

@@ -606,9 +606,9 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         if (pe != hipSuccess) return pe;
         ap.b.items = ws.prune_fail_list + list_off;
         ap.n_items_dev = counter;
-        // mode 3 (out.unique, the shared-profile role's first pass): the caller recomputes every read without the flag under its
-        // own tie rule, the handed-back reads among them — scoring them here would be thrown away
-        if (!out.unique) {
+        // out.skip_handed_back (the shared-profile role's passes, the seeded reverse pass of the ranges): the caller recomputes every
+        // read without the `unique` flag by other means, the handed-back reads among them — scoring them here would be thrown away
+        if (!out.skip_handed_back) {
             // Against a long reference the few reads handed back are cut into chunks of rows, each an item of its own (a class of
             // 2,000 reads walking 30,000 rows each is a dozen blocks on 256 CUs): chunks of at least four times the rows a
             // positive path can span, so that the overlap costs a quarter more cells at most.
@@ -625,7 +625,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
                 hipLaunchKernelGGL(chunk_zero_kernel, dim3(zgrid), dim3(256), 0, stream, ap.b.items, counter, bb.n_items, ws.chunk_keys);
                 pe = launch_table_cfg_v2(ap, g, c, mode, stream);
                 if (pe != hipSuccess) return pe;
-                hipLaunchKernelGGL(chunk_finalize_kernel, dim3(zgrid), dim3(256), 0, stream, ap.b, counter, ws.chunk_keys, ap.limit, rule, out, mode);
+                hipLaunchKernelGGL(chunk_finalize_kernel, dim3(zgrid), dim3(256), 0, stream, ap.b, counter, ws.chunk_keys, ap.limit, rule, out, std::min(mode, 2));
                 pe = hipGetLastError();
             } else {
                 pe = launch_table_cfg_v2(ap, g, c, mode, stream);
