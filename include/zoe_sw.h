@@ -380,7 +380,7 @@ zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags);
  * values its decision rests on into records[8 * read]: [0] the band's maximum (doubled; odd = held by a path through a cell
  * outside the band), [1] / [2] the most a path that ends above / below the band can score, [3] / [4] the smaller / larger anchor
  * diagonal of the lane's two reads, [5] strips | rows above the anchor << 8 | below << 20, [6] the read's own anchor diagonal,
- * [7] 1 = accepted by this walk. A later tier overwrites an earlier one. The host model (tests/models/seed_band.cpp) computes
+ * [7] 1 = accepted by this walk | columns per strip << 8. A later tier overwrites an earlier one. The host model (tests/models/seed_band.cpp) computes
  * the same quantities from the read and this geometry; the test requires equality. records: device memory for 8 int32 per read
  * of the following calls, NULL = off (the default). */
 zsw_error zsw_debug_band_records(zsw_context* ctx, int32_t* records);

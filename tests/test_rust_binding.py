@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 C_SCALARS = {
     "int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint8_t": "u8", "uint64_t": "u64", "int8_t": "i8", "size_t": "usize", "float": "f32", "double": "f64",
-    "zsw_error": "i32", "zsw_int_type": "i32", "zsw_mem": "i32", "zsw_option": "i32", "int64_t": "i64", "char": "c_char", "void": "c_void",
+    "zsw_error": "i32", "zsw_int_type": "i32", "zsw_mem": "i32", "zsw_encoding": "i32", "zsw_option": "i32", "int64_t": "i64", "char": "c_char", "void": "c_void",
     "zsw_context": "ZswContext", "zsw_group": "ZswGroup", "zsw_batch": "ZswBatch", "zsw_alignment": "ZswAlignment",
 }
 

@@ -26,7 +26,7 @@ namespace zsw {
 
 namespace {
 
-constexpr int BC = 32;  // columns per strip (a multiple of 8: a strip's residue codes are whole dwords of the packed reads; MODE 3 keeps
+constexpr int BC = 16;  // columns per strip (a multiple of 8: a strip's residue codes are whole dwords of the packed reads; MODE 3 keeps
                         // one bit per column in a 32-bit mask)
 
 // What the kernel keeps per lane between strips, in LDS ([field][lane]: the registers of the row loop hold nothing but the strip):
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                 rec[4] = dtmax;
                 rec[5] = n_strips | (wu << 8) | (wd << 20);
                 rec[6] = h ? dtB : dtA;
-                rec[7] = ((h ? lenB : lenA) == 0 || redo) ? 0 : 1;
+                rec[7] = (((h ? lenB : lenA) == 0 || redo) ? 0 : 1) | (C << 8);
             }
             if ((h ? lenB : lenA) == 0 || redo) {
                 if (a.retry) a.retry[h ? itemB : itemA] = 1;
@@ -492,11 +492,11 @@ bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase
 }
 
 hipError_t launch_seed_band(const SeedBandArgs& a, int mode, hipStream_t stream) {
-    // MODE 2 keeps a snapshot of the H row (32 more registers): two waves per SIMD
-    if (mode == 0) hipLaunchKernelGGL((seed_band_kernel<BC, 3, 0>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
-    else if (mode == 1) hipLaunchKernelGGL((seed_band_kernel<BC, 3, 1>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
-    else if (mode == 2) hipLaunchKernelGGL((seed_band_kernel<BC, 2, 2>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL((seed_band_kernel<BC, 2, 3>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+    // 16 columns per strip: H, E and the selectors are 48 registers (64 with the MODE 2 snapshot of the H row)
+    if (mode == 0) hipLaunchKernelGGL((seed_band_kernel<BC, 4, 0>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+    else if (mode == 1) hipLaunchKernelGGL((seed_band_kernel<BC, 4, 1>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+    else if (mode == 2) hipLaunchKernelGGL((seed_band_kernel<BC, 3, 2>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((seed_band_kernel<BC, 3, 3>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
     return hipGetLastError();
 }
 
