@@ -26,8 +26,14 @@ namespace zsw {
 
 namespace {
 
-constexpr int BC = 16;  // columns per strip (a multiple of 8: a strip's residue codes are whole dwords of the packed reads; MODE 3 keeps
-                        // one bit per column in a 32-bit mask)
+// Columns per strip (a multiple of 8: a strip's residue codes are whole dwords of the packed reads; MODE 3 keeps one bit per column
+// in a 32-bit mask). A strip computes a rectangle of C + Wu + Wd rows, the band itself is Wu + Wd + 1 diagonals: narrower strips
+// waste fewer cells (16 columns: 10 strips of 27 rows for a 150-base read in the narrow band; 32 columns: 5 strips of 43 rows),
+// but every strip boundary is a place where a bound that entered the strip's corner can leave it again inside a k-mer without paying
+// for it (zsw_seed.hpp) — about lambda / 3 of slack per boundary and side. So the narrow first tier, which nearly every read
+// within a few per cent of the reference passes, walks 16-column strips, and the reads that fail there are walked again in
+// 32-column strips (and the wide band), where half as many boundaries leave the proof of a diverged read that much more room.
+constexpr int BC_NARROW = 16, BC_WIDE = 32;
 
 // What the kernel keeps per lane between strips, in LDS ([field][lane]: the registers of the row loop hold nothing but the strip):
 // the k-mer layout and masks of the lane's two reads, and the two bound programmes of zsw_seed.hpp (SeedColDP) for BOTH reads at
@@ -482,6 +488,7 @@ size_t seed_band_buffer_bytes(const SeedParams& p, uint32_t n, uint32_t max_len,
     return n ? (size_t)seed_band_grid(n, grid_cap) * BLOCK * (size_t)seed_band_rows(p, max_len) * sizeof(uint2) : 0;
 }
 
+constexpr int BC = BC_WIDE;  // (sizes and limits below: the wider of the two)
 bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase_rows, uint32_t limit) {
     // a strip's rows must fit one drift period of the packed domain (no re-basing inside a strip); doubled scores (+ the mark)
     // must stay inside the packed range, the bound programmes' plain values below their bias; the masks are relative to Dn / Dm
@@ -491,12 +498,19 @@ bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase
     return (uint32_t)BC + seed_band_rows(p, max_len) + 2 <= rebase_rows;
 }
 
-hipError_t launch_seed_band(const SeedBandArgs& a, int mode, hipStream_t stream) {
-    // 16 columns per strip: H, E and the selectors are 48 registers (64 with the MODE 2 snapshot of the H row)
-    if (mode == 0) hipLaunchKernelGGL((seed_band_kernel<BC, 4, 0>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
-    else if (mode == 1) hipLaunchKernelGGL((seed_band_kernel<BC, 4, 1>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
-    else if (mode == 2) hipLaunchKernelGGL((seed_band_kernel<BC, 3, 2>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL((seed_band_kernel<BC, 3, 3>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+hipError_t launch_seed_band(const SeedBandArgs& a, int mode, bool narrow_strips, hipStream_t stream) {
+    // H, E and the selectors are 3 * C registers (4 * C with the MODE 2 snapshot of the H row)
+    if (narrow_strips) {
+        if (mode == 0) hipLaunchKernelGGL((seed_band_kernel<BC_NARROW, 4, 0>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+        else if (mode == 1) hipLaunchKernelGGL((seed_band_kernel<BC_NARROW, 4, 1>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+        else if (mode == 2) hipLaunchKernelGGL((seed_band_kernel<BC_NARROW, 3, 2>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((seed_band_kernel<BC_NARROW, 3, 3>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((seed_band_kernel<BC_WIDE, 3, 0>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+        else if (mode == 1) hipLaunchKernelGGL((seed_band_kernel<BC_WIDE, 3, 1>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+        else if (mode == 2) hipLaunchKernelGGL((seed_band_kernel<BC_WIDE, 2, 2>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((seed_band_kernel<BC_WIDE, 2, 3>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -303,14 +303,14 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
             b1.wd_per32 = SEED_NARROW_WD_PER32;
             b1.retry = retry;
             b1.next_pair = queue1;
-            e = launch_seed_band(b1, mode, stream);
+            e = launch_seed_band(b1, mode, true, stream);
             if (e != hipSuccess) return e;
             e = hipcub::DeviceSelect::Flagged(temp, temp_bytes, (const uint32_t*)order, (const uint8_t*)retry, order2, n2, (int)n, stream);
             if (e != hipSuccess) return e;
             b.order = order2;
             b.n_dev = n2;
         }
-        e = launch_seed_band(b, mode, stream);
+        e = launch_seed_band(b, mode, false, stream);
         if (window_timer) window_timer->end(stream);
         return e;
     }

@@ -93,7 +93,8 @@ uint32_t seed_band_grid(uint32_t n, uint32_t grid_cap);
 size_t seed_band_buffer_bytes(const SeedParams& p, uint32_t n, uint32_t max_len, uint32_t grid_cap);
 // rebase_rows / limit: of the doubled scoring's drift domain (a strip's rows must fit one drift period, twice the largest score the range)
 bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase_rows, uint32_t limit);
-hipError_t launch_seed_band(const SeedBandArgs& a, int mode, hipStream_t stream);
+// narrow_strips: 16 columns per strip (the first tier) instead of 32
+hipError_t launch_seed_band(const SeedBandArgs& a, int mode, bool narrow_strips, hipStream_t stream);
 
 struct ScoreArgsV2;
 
