@@ -372,7 +372,12 @@ typedef enum zsw_debug_flag {
     ZSW_DEBUG_NO_ROW_CHUNKS = 8192,
     /* score + ranges: the reverse pass of sw_simd_score_ranges by the exact prefix kernel for every read (by default a second seeded
      * pass over the reversed sequences settles the reads whose maximum sits in one cell, forward and reversed) */
-    ZSW_DEBUG_RANGES_EXACT_REVERSE = 16384
+    ZSW_DEBUG_RANGES_EXACT_REVERSE = 16384,
+    /* align: every read with an alignment goes through the second pass (the literal striped recurrence). By default a read with
+     * exactly one optimal alignment that is a gapless diagonal — both maxima in one cell each, the diagonal's weights add up to the
+     * score, the score beyond what any path with an insertion and a deletion between the same corners can reach — gets that
+     * alignment without it (tests/models/align_gapless_cert.cpp) */
+    ZSW_DEBUG_ALIGN_NO_CERTIFICATE = 32768
 } zsw_debug_flag;
 zsw_error zsw_debug_set(zsw_context* ctx, uint32_t flags);
 

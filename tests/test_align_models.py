@@ -105,3 +105,25 @@ def test_reversed_pass_over_whole_sequences_model(tmp_path, seed):
     out = subprocess.run([_build(tmp_path, "reverse_unique"), "4000", str(seed)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "reverse_unique OK" in out.stdout
+
+
+@pytest.mark.parametrize("seed", [20261005, 8])
+def test_gapless_alignment_certificate_model(tmp_path, seed):
+    """The certificate that lets sw_simd_align's second pass be skipped (zsw_capi.hip run_align, zsw_threepass.hip classify pass in
+    certificate mode): both maxima in one cell each, ranges of equal length whose diagonal adds up to the score, and the score beyond
+    maxw * (n - 1) - 2 * gap_open. The oracle's literal sw_simd_align (striped.rs:449-598 restated) must then return the gapless
+    diagonal at N = 2 .. 64 in 16-bit lanes and N = 16, 32 in 8-bit lanes; ten scoring schemes, repeats, homopolymer runs, N, junk
+    ends, reads with indels (never certified). (Dropping the score condition produces a counter-example within 3,000 iterations.)"""
+    out = subprocess.run([_build(tmp_path, "align_gapless_cert"), "500", str(seed)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "align_gapless_cert OK" in out.stdout
+
+
+@pytest.mark.parametrize("seed", [20261005, 4])
+def test_row_chunked_full_pass_model(tmp_path, seed):
+    """Reads the seeded pass hands back against a long reference are scored in chunks of rows, each from a zero state with an
+    overlap of L + L * maxw / gap_extend + 2 rows (zsw_score_v2.hpp, ScoreArgsV2::chunk_rows): the largest (score, earliest row,
+    earliest column) over the chunks is the whole matrix's, with repeats in the reference and long deletions in the reads."""
+    out = subprocess.run([_build(tmp_path, "chunk_rows"), "2500", str(seed)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "chunk_rows OK" in out.stdout

@@ -453,3 +453,80 @@ def test_scores_at_the_edge_of_the_packed_kernels_16_bit_lanes(za, oracle):
         got32 = za.StripedProfileBatch(reads, m, go, ge, "i32", 8).sw_align(za.SeqSrc.Reference(ref))
         for i, rd in enumerate(reads):
             assert got32.key(i) == okey(oracle.align("i32", 8, sc, rd, ref)), (ma, mi, go, ge, i)
+
+
+def test_reads_with_one_optimal_alignment_skip_the_second_pass(za, oracle):
+    """sw_simd_align's CIGAR depends on the striping only where several optimal alignments exist. A read whose maximum sits in one
+    cell, whose reversed maximum sits in one cell, whose ranges have equal lengths with the diagonal adding up to the score, and whose
+    score lies beyond what a path with an insertion and a deletion between the same corners can reach has exactly one optimal
+    alignment — the gapless diagonal — and gets it without the literal striped recurrence (tests/models/align_gapless_cert.cpp).
+    500,000 reads (synthetic; tie-rich: tandem repeats, a duplicated stretch, low complexity; diverged; with indels): every record
+    and every ciglet must equal the all-literal path (ZSW_DEBUG_ALIGN_NO_CERTIFICATE), both SeqSrc directions, and the oracle's
+    cascade on a sample; most synthetic reads must have been certified (the call must be much faster than the literal one)."""
+    import time
+
+    import torch
+
+    from test_gpu_bounds import diverged_reads
+    from zoe_amd import _lib, synth
+
+    ctx = za.SwContext.get(0)
+    rng = np.random.default_rng(stable_seed("gapless-cert"))
+    ref = bytearray(synth.reference_host(2500))
+    ref[900:1000] = ref[300:400]
+    for i in range(1500 + 2, 1580):
+        ref[i] = ref[i - 2]
+    ref = bytes(ref)
+    r = np.frombuffer(ref, dtype=np.uint8)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    L = 150
+    syn = synth.reads_host(ref, 29, 400_000, L)
+    ties = np.empty((50_000, L), dtype=np.uint8)
+    for i in range(len(ties)):
+        kind = i % 5
+        p = int(rng.integers(0, len(r) - L))
+        if kind == 0:
+            p = int(rng.integers(250, 320))
+        elif kind == 1:
+            p = int(rng.integers(1440, 1520))
+        q = r[p:p + L].copy()
+        if kind == 2:
+            p2 = int(rng.integers(0, len(r) - L))
+            q[L // 2:] = r[p2:p2 + L - L // 2]
+        elif kind == 3:
+            q = rng.choice(alpha[:2], L).astype(np.uint8)
+        elif kind == 4:  # three or four substitutions: around the threshold of the certificate
+            for k in rng.choice(L, int(rng.integers(3, 5)), replace=False):
+                q[k] = alpha[(int(np.where(alpha == q[k])[0][0]) + 1) % 4] if q[k] in alpha else q[k]
+        ties[i] = q
+    reads = np.concatenate([syn, ties, diverged_reads(ref, 25_000, L, 30, 7), diverged_reads(ref, 25_000, L, 80, 8)])
+    n = len(reads)
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    rb = za.ReadBatch.from_fixed(torch.from_numpy(np.ascontiguousarray(reads).reshape(-1)).cuda(), L)
+    prof = za.into_local_profile(rb, dna, -10, -1)
+
+    def timed(src):
+        prof.sw_align_from_i8(src)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        a = prof.sw_align_from_i8(src)
+        torch.cuda.synchronize()
+        return a, time.perf_counter() - t0
+
+    got, t_cert = timed(za.SeqSrc.Reference(ref))
+    gotq = prof.sw_align_from_i8(za.SeqSrc.Query(ref))
+    ctx.debug_set(_lib.DEBUG_ALIGN_NO_CERTIFICATE)
+    try:
+        want, t_lit = timed(za.SeqSrc.Reference(ref))
+        wantq = prof.sw_align_from_i8(za.SeqSrc.Query(ref))
+    finally:
+        ctx.debug_set(0)
+    for a, b in ((got, want), (gotq, wantq)):
+        assert np.array_equal(a.status, b.status) and np.array_equal(a.tier, b.tier)
+        assert np.array_equal(a.records, b.records)
+        assert np.array_equal(a.inc, b.inc) and np.array_equal(a.op, b.op)
+    assert t_cert < 0.9 * t_lit, (t_cert, t_lit)  # (a tie-rich set: the synthetic reads alone run at about 0.6)
+    sc = osc(oracle, dna, -10, -1)
+    for i in list(range(0, 400_000, 2003)) + list(range(400_000, n, 499)):
+        w, tier = oracle.cascade_align(8, 256, sc, reads[i], ref)
+        assert got.key(i) == okey(w), i

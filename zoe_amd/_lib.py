@@ -29,6 +29,7 @@ DEBUG_SCORE_V1, DEBUG_NO_TILES, DEBUG_NO_W32, DEBUG_NO_WIDE, DEBUG_NO_SIDE_STREA
 DEBUG_SCORE_PRUNE, DEBUG_SCORE_PRUNE_ANY_SIZE, DEBUG_PRUNE_STRIP, DEBUG_ALIGN_LONG_WARMUP, DEBUG_SEED_NO_BAND, DEBUG_SEED_WIDE_BAND = 128, 256, 512, 1024, 2048, 4096
 DEBUG_NO_ROW_CHUNKS = 8192
 DEBUG_RANGES_EXACT_REVERSE = 16384
+DEBUG_ALIGN_NO_CERTIFICATE = 32768
 OPTION_EXACT_PRUNING = 1
 INT_TYPES = {"i8": 0, "i16": 1, "i32": 2, "u8": 3, "u16": 4, "u32": 5}
 

@@ -68,6 +68,14 @@ struct ThreePassArgs {
     // zsw_score_ranges_shared_batch: rs/re index the read, qs/qe the profile sequence); `ref` / `ref_len` are then unused.
     const uint8_t* pseq = nullptr;
     uint32_t pseq_len = 0;
+    // Certificate mode of the classify pass (sw_simd_align's second pass skipped, zsw_capi.hip run_align; host model
+    // tests/models/align_gapless_cert.cpp): cert_ok[i] = both maxima of read i sit in one cell each (forward and reversed seeded
+    // pass, mode 3). A read whose ranges have equal lengths n, whose diagonal adds up to its score S and whose S exceeds
+    // cert_maxw * (n - 1) - 2 * cert_go has exactly one optimal alignment, the diagonal: it is written here (cert_done[i] = 1) and
+    // is what sw_simd_align returns at every <T, N>; every other read is left to the literal striped kernel (cert_done[i] = 0).
+    const uint8_t* cert_ok = nullptr;
+    uint8_t* cert_done = nullptr;
+    int cert_maxw = 0, cert_go = 0;
 };
 
 hipError_t launch_threepass(const ThreePassArgs& a, uint32_t grid, hipStream_t stream);

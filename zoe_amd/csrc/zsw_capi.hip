@@ -421,8 +421,22 @@ __global__ void ranges_combine_kernel(uint32_t n, const uint32_t* fscore, const 
 }
 
 
+// can this call's batch take the reverse pass of the ranges as a second seeded pass (stage() has run)?
+static bool seeded_reverse_possible(zsw_context* ctx, const Staged& st) {
+    return ctx->seed_ready && !ctx->shared_call && !(ctx->flags() & ZSW_DEBUG_RANGES_EXACT_REVERSE) && ctx->ref_len > 0 && ctx->seed.valid && ctx->seed.usable &&
+           st.max_len <= SEED_MAX_LEN;
+}
+
+// run_align's first pass in certificate mode: the forward and the reversed seeded pass only (no exact reverse pass, no combine)
+struct RangesCert {
+    uint32_t* safe_row;  // in: where the forward pass leaves the late-start rows of sw_simd_align's second pass
+    uint8_t* settled;    // in: n bytes; out: 1 = both maxima of the read sit in one cell each, rs / qs hold its starts
+    ScoreOut fwd;        // out: the forward pass's arrays (score, status, tier, ref_end, query_end)
+    uint32_t *rs, *qs;   // out
+};
+
 // forward score+ends (MODE 2), reverse pass on the prefixes, combine; everything stays on the device
-zsw_error ranges_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, hipStream_t stream, RangesDev* out) {
+zsw_error ranges_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, hipStream_t stream, RangesDev* out, RangesCert* cert = nullptr) {
     const uint32_t n = st.b.n_reads;
     DevBuf* ws = ctx->r_ws;
     for (int k : {RW_FSCORE, RW_FREND, RW_FQEND, RW_RSCORE, RW_RRS, RW_RQS, RW_QEM, RW_O0, RW_O1, RW_O2, RW_O3, RW_O4})
@@ -444,8 +458,9 @@ zsw_error ranges_device(zsw_context* ctx, const Staged& st, const ResultRule& ru
     // reversed matrix that hold the score are the same with or without the restriction (tests/models/reverse_unique.cpp): a seeded
     // pass over the reversed reads and the reversed reference, whole sequences, finds them; if that is one cell too, it is the
     // start. Every other read goes to the exact reverse kernel below.
-    const bool seeded_reverse = ctx->seed_ready && !ctx->shared_call && !(ctx->flags() & ZSW_DEBUG_RANGES_EXACT_REVERSE) && ctx->ref_len > 0 &&
-                                ctx->seed.valid && ctx->seed.usable && st.max_len <= SEED_MAX_LEN;
+    const bool seeded_reverse = seeded_reverse_possible(ctx, st);
+    if (cert && !seeded_reverse) return fail(ctx, ZSW_ERR_INVALID_ARGUMENT, "internal: certificate pass without the seeded reverse pass");
+    if (cert) fo.safe_row = cert->safe_row;
     if (seeded_reverse) {
         ZSW_HIP(ctx, ws[RW_UNIQ_F].ensure((size_t)n + 4));
         ZSW_HIP(ctx, hipMemsetAsync(ws[RW_UNIQ_F].p, 0, n, stream));
@@ -500,13 +515,26 @@ zsw_error ranges_device(zsw_context* ctx, const Staged& st, const ResultRule& ru
             if (e3 != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "ranges: seeded reverse pass", e3);
             ZSW_HIP(ctx, hipMemsetAsync(ws[RW_UCOUNT].p, 0, 4, stream));
             ZSW_HIP(ctx, launch_settle_reverse(st.b, n, (uint32_t)R, ws[RW_UNIQ_F].as<uint8_t>(), ws[RW_UNIQ_R].as<uint8_t>(), fo.score, fo.status, ro.score,
-                                               ro.status, ro.query_end, ro.ref_end, ws[RW_ULIST].as<uint32_t>(), ws[RW_UCOUNT].as<uint32_t>(), stream));
+                                               ro.status, ro.query_end, ro.ref_end, ws[RW_ULIST].as<uint32_t>(), ws[RW_UCOUNT].as<uint32_t>(), stream,
+                                               cert ? cert->settled : nullptr));
+            if (cert) {  // the caller takes it from here (the unsettled reads go to sw_simd_align's own second pass)
+                cert->fwd = fo;
+                cert->rs = ro.ref_end;
+                cert->qs = ro.query_end;
+                return ZSW_OK;
+            }
             uint32_t left = 0;
             ZSW_HIP(ctx, hipMemcpyAsync(&left, ws[RW_UCOUNT].p, 4, hipMemcpyDeviceToHost, stream));
             ZSW_HIP(ctx, hipStreamSynchronize(stream));
             rest.items = ws[RW_ULIST].as<uint32_t>();
             rest.n_items = left;
             run_exact = left > 0;
+        } else if (cert) {
+            ZSW_HIP(ctx, hipMemsetAsync(cert->settled, 0, n, stream));  // no index of the reversed reference: nothing is settled
+            cert->fwd = fo;
+            cert->rs = ro.ref_end;
+            cert->qs = ro.query_end;
+            return ZSW_OK;
         }
     }
     if (run_exact) {
@@ -560,6 +588,12 @@ zsw_error run_ranges(zsw_context* ctx, const zsw_batch* reads, const ResultRule&
     return ZSW_OK;
 }
 
+
+// statuses as sw_simd_align's second pass sees them: a read whose alignment the certificate pass wrote does not take part
+__global__ void cert_status_kernel(uint32_t n, const uint8_t* status, const uint8_t* done, uint8_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = done[i] ? (uint8_t)ZSW_STATUS_UNMAPPED : status[i];
+}
 
 __global__ void count_some_kernel(const uint8_t* status, uint32_t n, uint32_t* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -653,9 +687,78 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     ZSW_HIP(ctx, ws[WS_SAFE].ensure((size_t)n * 4 + 4));
     ZSW_HIP(ctx, hipMemsetAsync(ws[WS_SAFE].p, 0xff, (size_t)n * 4, stream));
     so.safe_row = (ctx->flags() & ZSW_DEBUG_ALIGN_LONG_WARMUP) ? nullptr : ws[WS_SAFE].as<uint32_t>();
-    hipError_t e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(),
-                                (uint32_t)ctx->ref_len, rule, so, score_ws(ctx), stream, nullptr, 1);
-    if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align pass 1", e);
+    // Certificate mode (tests/models/align_gapless_cert.cpp): the first pass is the forward and the reversed seeded pass of the
+    // ranges (mode 3: is the maximum in one cell?); a read with exactly one optimal alignment, a gapless diagonal, gets it from the
+    // classify pass of zsw_threepass.hip and never sees the literal striped recurrence below.
+    const uint8_t* pass2_status = nullptr;  // statuses as the grouping sees them: certified reads do not take part
+    hipError_t e = hipSuccess;
+    const bool certify = seeded_reverse_possible(ctx, st) && !(ctx->flags() & ZSW_DEBUG_ALIGN_NO_CERTIFICATE) && ctx->h_sc.gap_open > 0;
+    if (certify) {
+        const uint32_t MAXC0 = 32;
+        ZSW_HIP(ctx, ws[WS_CERT_OK].ensure((size_t)n + 4));
+        ZSW_HIP(ctx, ws[WS_CERT_DONE].ensure((size_t)n + 4));
+        ZSW_HIP(ctx, ws[WS_CERT_STATUS].ensure((size_t)n + 4));
+        ZSW_HIP(ctx, ws[WS_ALN].ensure((size_t)n * sizeof(zsw_alignment)));
+        ZSW_HIP(ctx, ws[WS_CIGSTART].ensure((size_t)n * 8));
+        ZSW_HIP(ctx, ws[WS_CIGRAW].ensure((size_t)n * 4));
+        ZSW_HIP(ctx, ws[WS_CIG].ensure((size_t)n * MAXC0 * 4));
+        ZSW_HIP(ctx, ws[WS_FBLIST].ensure((size_t)n * 4 + 4));
+        ZSW_HIP(ctx, ws[WS_FBCOUNT].ensure(16));
+        RangesCert cert;
+        cert.safe_row = so.safe_row;
+        cert.settled = ws[WS_CERT_OK].as<uint8_t>();
+        RangesDev unused;
+        zsw_error ze = ranges_device(ctx, st, rule, stream, &unused, &cert);
+        if (ze != ZSW_OK) return ze;
+        so.score = cert.fwd.score;
+        so.status = cert.fwd.status;
+        so.tier = cert.fwd.tier;
+        so.ref_end = cert.fwd.ref_end;
+        int maxw = 0;
+        for (int i = 0; i < ctx->h_sc.S * ctx->h_sc.S; ++i) maxw = std::max(maxw, (int)ctx->h_sc.w[i]);
+        ThreePassArgs a;
+        a.b = st.b;
+        a.ref = ctx->d_ref.as<uint8_t>();
+        a.ref_len = (uint32_t)ctx->ref_len;
+        a.sc = ctx->d_sc.as<ScoringDev>();
+        a.score = so.score;
+        a.rs = cert.rs;
+        a.re = cert.fwd.ref_end;
+        a.qs = cert.qs;
+        a.qe = cert.fwd.query_end;
+        a.status = so.status;
+        a.list = nullptr;
+        a.list_count = nullptr;
+        a.dp_list = nullptr;
+        a.dp_count = nullptr;
+        a.dp_need_max = nullptr;
+        a.scratch = nullptr;
+        a.slots = 0;
+        a.slot_bytes = 0;
+        a.cig = ws[WS_CIG].as<uint32_t>();
+        a.maxc = MAXC0;
+        a.pool_base = 0;
+        a.by_item = 0;
+        a.cig_start = ws[WS_CIGSTART].as<uint64_t>();
+        a.cig_raw = ws[WS_CIGRAW].as<uint32_t>();
+        a.aln = ws[WS_ALN].as<zsw_alignment>();
+        a.fb_list = ws[WS_FBLIST].as<uint32_t>();
+        a.fb_count = ws[WS_FBCOUNT].as<uint32_t>();
+        a.invert = invert;
+        a.cert_ok = cert.settled;
+        a.cert_done = ws[WS_CERT_DONE].as<uint8_t>();
+        a.cert_maxw = maxw;
+        a.cert_go = ctx->h_sc.gap_open;
+        e = launch_threepass(a, std::min<uint32_t>((n + 63) / 64, 65536u), stream);
+        if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align: certificate pass", e);
+        hipLaunchKernelGGL(cert_status_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, so.status, ws[WS_CERT_DONE].as<uint8_t>(), ws[WS_CERT_STATUS].as<uint8_t>());
+        pass2_status = ws[WS_CERT_STATUS].as<uint8_t>();
+    } else {
+        e = launch_score(ctx->d_sc.as<ScoringDev>(), ctx->h_sc, st.b, st.max_len, ctx->d_ref.as<uint8_t>(), (uint32_t)ctx->ref_len, rule, so, score_ws(ctx), stream,
+                         nullptr, 1);
+        if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align pass 1", e);
+        pass2_status = so.status;
+    }
 
     // Group the reads that have an alignment by the <N, nv> of the instantiation that answered and order each group by its
     // reference end row — on the device (zsw_group.hip); only the table of group starts comes back to the host.
@@ -674,7 +777,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
     const size_t sort_bytes = group_temp_bytes(n);
     ZSW_HIP(ctx, ws[WS_SORT_TMP].ensure(sort_bytes + 256));
     ZSW_HIP(ctx, ws[WS_GTABLE].ensure((size_t)TABLE_CAP * 8 + 8));
-    e = group_reads(st.b, so.status, so.tier, so.ref_end, so.score, so.safe_row, lanes_w8, lanes_w16, lanes_w32, ws[WS_KEYS_IN].as<uint64_t>(),
+    e = group_reads(st.b, pass2_status, so.tier, so.ref_end, so.score, so.safe_row, lanes_w8, lanes_w16, lanes_w32, ws[WS_KEYS_IN].as<uint64_t>(),
                     ws[WS_KEYS_OUT].as<uint64_t>(), ws[WS_VALS_IN].as<uint32_t>(), ws[WS_ITEMS].as<uint32_t>(), ws[WS_SORT_TMP].p,
                     sort_bytes, ws[WS_GTABLE].as<uint32_t>() + 2, ws[WS_GTABLE].as<uint32_t>(), TABLE_CAP - 1, stream);
     if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align grouping", e);
@@ -695,7 +798,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
         if (!t.empty()) {
             ZSW_HIP(ctx, ws[WS_FBCOUNT].ensure(8));  // fallback counter + the packed kernel's work counter
             ZSW_HIP(ctx, hipMemsetAsync(ws[WS_FBCOUNT].p, 0, 4, stream));
-            hipLaunchKernelGGL(count_some_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, so.status, n, ws[WS_FBCOUNT].as<uint32_t>());
+            hipLaunchKernelGGL(count_some_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pass2_status, n, ws[WS_FBCOUNT].as<uint32_t>());
             ZSW_HIP(ctx, hipMemcpyAsync(&n_some, ws[WS_FBCOUNT].p, 4, hipMemcpyDeviceToHost, stream));
             ZSW_HIP(ctx, hipStreamSynchronize(stream));
         }

@@ -73,7 +73,7 @@ __global__ void reverse_reads_kernel(BatchDev b, uint64_t total_bases, uint8_t* 
 // likewise in the profile sequence). Everything else joins the list of the exact reverse kernel.
 __global__ void settle_reverse_kernel(BatchDev b, uint32_t n, uint32_t plen, const uint8_t* uf, const uint8_t* ur, const uint32_t* fscore,
                                       const uint8_t* fstatus, const uint32_t* rscore, const uint8_t* rstatus, uint32_t* rs, uint32_t* qs,
-                                      uint32_t* list, uint32_t* count) {
+                                      uint32_t* list, uint32_t* count, uint8_t* settled_out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool settled = false;
     if (i < n && uf[i] && ur[i] && fstatus[i] == ZSW_STATUS_SOME && rstatus[i] == ZSW_STATUS_SOME && rscore[i] == fscore[i]) {
@@ -84,6 +84,7 @@ __global__ void settle_reverse_kernel(BatchDev b, uint32_t n, uint32_t plen, con
             settled = true;
         }
     }
+    if (settled_out && i < n) settled_out[i] = settled ? 1 : 0;
     const bool take = i < n && !settled;
     const unsigned long long m = __ballot(take);
     if (m) {
@@ -109,9 +110,9 @@ hipError_t launch_reverse_reads(const BatchDev& b, uint64_t total_bases, uint8_t
 // return the inclusive starts in the sequences themselves for the settled reads
 hipError_t launch_settle_reverse(const BatchDev& b, uint32_t n, uint32_t other_len, const uint8_t* uf, const uint8_t* ur, const uint32_t* fscore,
                                  const uint8_t* fstatus, const uint32_t* rscore, const uint8_t* rstatus, uint32_t* read_side, uint32_t* other_side,
-                                 uint32_t* list, uint32_t* count, hipStream_t stream) {
+                                 uint32_t* list, uint32_t* count, hipStream_t stream, uint8_t* settled) {
     if (n) hipLaunchKernelGGL(settle_reverse_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, b, n, other_len, uf, ur, fscore, fstatus, rscore, rstatus,
-                              read_side, other_side, list, count);
+                              read_side, other_side, list, count, settled);
     return hipGetLastError();
 }
 }  // namespace capi
@@ -366,7 +367,7 @@ zsw_error ranges_shared_device(zsw_context* ctx, const Staged& st, const ResultR
             ZSW_HIP(ctx, hipMemsetAsync(ws[SH_UCOUNT].p, 0, 4, stream));
             hipLaunchKernelGGL(settle_reverse_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, st.b, n, (uint32_t)plen, ws[SH_UNIQUE].as<uint8_t>(),
                                ws[SH_UNIQUE_R].as<uint8_t>(), fo.score, fo.status, ro.score, ro.status, ro.ref_end, ro.query_end,
-                               ws[SH_ULIST].as<uint32_t>(), ws[SH_UCOUNT].as<uint32_t>());
+                               ws[SH_ULIST].as<uint32_t>(), ws[SH_UCOUNT].as<uint32_t>(), (uint8_t*)nullptr);
             rest.items = ws[SH_ULIST].as<uint32_t>();
             rest_count = ws[SH_UCOUNT].as<uint32_t>();
         }

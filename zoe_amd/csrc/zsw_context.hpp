@@ -188,7 +188,7 @@ zsw_error unstage(zsw_context* ctx, const zsw_batch* reads, hipStream_t stream, 
                   uint8_t* out_tier, uint32_t* out_rend, uint32_t* out_qend);
 enum { WS_SCORE = 0, WS_STATUS, WS_TIER, WS_REND, WS_ITEMS, WS_RING, WS_CIG, WS_ALN, WS_CIGSTART, WS_CIGRAW, WS_BSUMS, WS_TOTAL,
        WS_FBLIST, WS_FBCOUNT, WS_OINC, WS_OOP, WS_CIG2, WS_RING2, WS_KEYS_IN, WS_KEYS_OUT, WS_VALS_IN, WS_SORT_TMP, WS_GTABLE, WS_FBMETA,
-       WS_ITEMS2, WS_SAFE };
+       WS_ITEMS2, WS_SAFE, WS_CERT_OK, WS_CERT_DONE, WS_CERT_STATUS };
 enum { RW_FSCORE = 0, RW_FSTATUS, RW_FREND, RW_FQEND, RW_RSCORE, RW_RSTATUS, RW_RRS, RW_RQS, RW_QEM, RW_GTAB, RW_MIS, RW_O0, RW_O1,
        RW_O2, RW_O3, RW_O4, RW_O5, RW_FTIER, RW_UNIQ_F, RW_UNIQ_R, RW_RBASES, RW_ULIST, RW_UCOUNT };
 zsw_error finish_alignments(zsw_context* ctx, DevBuf* ws, uint32_t n, bool host, const uint8_t* d_status, const uint8_t* d_tier, int invert,
@@ -208,7 +208,7 @@ zsw_error threepass_third_pass(zsw_context* ctx, const Staged& st, const RangesD
 hipError_t launch_reverse_reads(const BatchDev& b, uint64_t total_bases, uint8_t* out, hipStream_t stream);
 hipError_t launch_settle_reverse(const BatchDev& b, uint32_t n, uint32_t other_len, const uint8_t* uf, const uint8_t* ur, const uint32_t* fscore,
                                  const uint8_t* fstatus, const uint32_t* rscore, const uint8_t* rstatus, uint32_t* read_side, uint32_t* other_side,
-                                 uint32_t* list, uint32_t* count, hipStream_t stream);
+                                 uint32_t* list, uint32_t* count, hipStream_t stream, uint8_t* settled = nullptr);  // settled[i] = 1: read i is done
 // the and_then / map chain of sw_simd_score_ranges on device arrays (kernels of zsw_capi.hip)
 hipError_t launch_ranges_prep(uint32_t n, const uint8_t* fstatus, const uint32_t* fqend, uint32_t* qe_masked, hipStream_t stream);
 hipError_t launch_ranges_combine(uint32_t n, const uint32_t* fscore, const uint8_t* fstatus, const uint32_t* frend, const uint32_t* fqend,

@@ -128,7 +128,10 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
         bool done = false;
         if (!a.list) {
             // classify pass: the no-gaps shortcut (three_pass.rs:37-58) is resolved here, the rest is queued for the DP pass
-            if (qlen == rlen) {
+            // (certificate mode: only reads with one optimal alignment, which must be this diagonal; the rest is not touched)
+            const bool may = !a.cert_ok || (a.cert_ok[id] && re > rs && (long long)score > (long long)a.cert_maxw * ((long long)rlen - 1) - 2ll * a.cert_go);
+            if (a.cert_done) a.cert_done[id] = 0;
+            if (may && qlen == rlen) {
                 int64_t sum = 0;
                 uint32_t k = 0;
                 for (; k + 4 <= qlen; k += 4) {  // four residues per (unaligned) load
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                     done = true;
                 }
             }
+            if (!done && a.cert_ok) continue;
             if (!done) {
                 const uint32_t k = atomicAdd(a.dp_count, 1u);
                 a.dp_list[k] = id;
@@ -313,6 +317,7 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
         a.aln[id] = out;
         a.cig_start[id] = (uint64_t)(uintptr_t)cig;
         a.cig_raw[id] = w.ncig;
+        if (a.cert_done) a.cert_done[id] = 1;
     }
 }
 
