@@ -52,7 +52,7 @@ def load_constants():
 
 PC = load_constants()
 PMC_PROFILE = PC["band"]["source"]
-WINDOW_HBM_BYTES_PER_READ = PC["band"]["hbm_bytes_per_read"]   # FETCH_SIZE + WRITE_SIZE per read of the batch, both launches of seed_band_kernel<32,3,0>
+WINDOW_HBM_BYTES_PER_READ = PC["band"]["hbm_bytes_per_read"]   # FETCH_SIZE + WRITE_SIZE per read of the batch, both launches of the banded kernel (tier 1 seed_band_kernel<16,4,0>, tier 2 <32,3,0>)
 WINDOW_VALU_PER_READ = PC["band"]["valu_per_read"]            # SQ_INSTS_VALU per read of the batch, both launches
 VALU_PEAK_SOURCE = "profiles/r01_valu_issue_rates_ubench.txt"  # this repo's micro-benchmark (tools/ubench.hip), not a figure of the guide
 TOTAL_READS_MULTI_GPU = 500_000_000  # BASELINE.json configs[3]
@@ -322,7 +322,7 @@ def secondary_configs(zoe_amd, synth, ctx, matrix):
     entry = {"reads_per_s_end_to_end_incl_d2h": n_full / dt, "pass2_kernel_ms": ks * 1e3, "pass2_kernel_ms_per_1M_reads": ks * 1e3 / (n_full / 1e6),
              "ciglets": n_cig, "aligned_reads": n_some,
              "call": "into_local_profile(..).sw_align_from_i8(SeqSrc::Reference(ref)) (CIGAR of the i16x16 / i8x32 tier), 10 M reads (BASELINE.json configs[2] at full size)",
-             "kernel": "zsw::align_kernel_pk<16,10> (+ <32,5> for the reads that answer at i8x32); pass 1 = the seeded exact pass (seed_band_kernel<32,3,1>: 823 more VALU instructions per read)"}
+             "kernel": "zsw::align_kernel_pk<16,10> (+ <32,5> for the reads that answer at i8x32); pass 1 = the seeded exact pass (seed_band_kernel<16,4,3> forward + reversed: is there exactly one optimal alignment? DESIGN.md §4.2)"}
     # algorithmic bytes: read in, record out (score, 4 coordinates, 2 lengths, count, offset = 40 B), 5 B per ciglet
     entry.update(rooflines(n_full * (READ_LEN + 4.0) + n_some * 40.0 + n_cig * 5.0, ks, ALIGN_PK_VALU_PER_READ * n_full, ALIGN_PK_PROFILE,
                            ALIGN_HBM_PER_READ * n_full))
@@ -467,7 +467,7 @@ def protein_and_shared(zoe_amd, synth, ctx, matrix, timed, with_full_first_pass)
             "reads_per_s": n / dt_r0, "identical": all(bool(torch.equal(getattr(rg0, f), getattr(rg, f)))
                                                         for f in ("score", "status", "ref_start", "ref_end", "query_start", "query_end"))},
         "call": "StripedProfile::<i16,16,5>::new(reference) reused for every read: sw_score(read) / sw_score_ends / sw_score_ranges(SeqSrc::Reference(read))",
-        "kernel": "the seeded pass with the roles swapped (seed_band_kernel<32,.,3>: ends + 'the maximum sits in one cell'; ranges: again over the reversed sequences), shared_ends_kernel for every other read",
+        "kernel": "the seeded pass with the roles swapped (seed_band_kernel<16|32,.,3>: ends + 'the maximum sits in one cell'; ranges: again over the reversed sequences), shared_ends_kernel for every other read",
         "every_read_by_the_exact_shared_kernel": {"score_ends_reads_per_s": n / dt_e0,
                                                     "identical": all(bool(torch.equal(getattr(en0, f), getattr(en, f))) for f in ("score", "status", "ref_end", "query_end"))}}
     return out
@@ -609,7 +609,7 @@ def main():
         pass_s = kern_s / max(launches, 1)             # the whole first pass: seed + sort + window + full pass over the handed-back reads
         seeded = win_launches > 0
         kern = win_s / win_launches if seeded else pass_s  # the dominant kernel alone
-        kernel_name = "zsw::seed_band_kernel<32,3> (two launches per step: narrow band over every read + full band over the reads that fail in it)" if seeded else "zsw::score_kernel_v2<4,38,0>"
+        kernel_name = "zsw::seed_band_kernel<16,4,0> over every read (16-column strips, band 8/6) + <32,3,0> over the reads that fail in it (32-column strips, band 42/18): two launches per step" if seeded else "zsw::score_kernel_v2<4,38,0>"
         achieved = ALGO_BYTES_PER_READ * n_local / kern / 1e9 if kern > 0 else 0.0
         traffic = WINDOW_HBM_BYTES_PER_READ * n_local if (seeded and WINDOW_HBM_BYTES_PER_READ) else None
         out = {

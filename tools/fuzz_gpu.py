@@ -1,6 +1,6 @@
 """Randomised parity sweep: random scoring schemes, alphabets, lengths, lane counts and batch shapes through every GPU entry
 point (score, ends, ranges, cascades, exact and 3-pass alignment, SeqSrc inversion; the shared-profile role's score, ends, ranges
-and alignment with the reference as the profile sequence) against the oracle.
+exact and 3-pass alignment with the reference as the profile sequence) against the oracle.
 usage: python tools/fuzz_gpu.py [iterations] [seed]     (FUZZ_PRUNE=1: the seeded exact first pass for batches of every size, FUZZ_PRUNE=strip: the column-pruned one; FUZZ_LONG_P: share of long-read cases)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -110,6 +110,7 @@ for it in range(iters):
         s_sc, s_en = sp.sw_score(reads), sp.sw_score_ends(za.SeqBatchSrc.Reference(reads))
         s_rg = sp.sw_score_ranges(za.SeqBatchSrc.Reference(reads))
         s_al = sp.sw_align((za.SeqBatchSrc.Query if inv else za.SeqBatchSrc.Reference)(reads[:16]))
+        s_3p = sp.sw_align_3pass((za.SeqBatchSrc.Query if inv else za.SeqBatchSrc.Reference)(reads))  # profile.rs:536-552 with the shared profile
     # the same batch through HOST pointers (staging path of the C ABI) and the sneaky_snake filter on random windows
     import ctypes as C
     from zoe_amd import _lib
@@ -165,6 +166,7 @@ for it in range(iters):
                 assert (int(s_rg.score[i]), (int(s_rg.ref_start[i]), int(s_rg.ref_end[i])), (int(s_rg.query_start[i]), int(s_rg.query_end[i]))) == (s, rr, qr), ("shared ranges", ctxt)
             if i < 16:
                 assert s_al.key(i) == okey(oracle.align(T, N, sc, ref, rd, other_is_query=inv)), ("shared align", ctxt)
+            assert s_3p.key(i) == okey(oracle.align_3pass(T, N, sc, ref, rd, other_is_query=inv)[0]), ("shared 3pass", ctxt)
         n_checked += 1
     print(f"iteration {it}: ok ({len(reads)} reads, R={R}, T={T}x{N}, preset {preset} from i{width}, go={go} ge={ge}, {'protein S=%d' % len(m.mapping) if protein else 'dna'}, invert={inv}) [{time.time() - t_start:.0f} s]", flush=True)
-print(f"FUZZ OK: {n_checked} reads x 12 entry points + 4 of the shared-profile role")
+print(f"FUZZ OK: {n_checked} reads x 12 entry points + 5 of the shared-profile role")
