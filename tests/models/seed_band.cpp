@@ -113,8 +113,8 @@ Walk walk_band(const Scheme& s, const SeedParams& p, const zsw::SeedRead& sr, co
         const int next_top = g.top(k + 1);
         const int nr = std::max(0, std::min(C, L - k * C));  // real columns of the strip
         const int xl = (k + 1) * C - 1;
-        const zsw::SeedStripEvents ea = zsw::seed_strip_events(k * C, C, y.m, y.c0, y.stride, p.K, y.magic, sr.fa_mask);
-        const zsw::SeedStripEvents eb = zsw::seed_strip_events(k * C, C, y.m, y.c0, y.stride, p.K, y.magic, sr.fb_mask);
+        const zsw::SeedStripEventsT<uint64_t> ea = zsw::seed_strip_events_t<uint64_t>(k * C, C, y.m, y.c0, y.stride, p.K, y.magic, sr.fa_mask);
+        const zsw::SeedStripEventsT<uint64_t> eb = zsw::seed_strip_events_t<uint64_t>(k * C, C, y.m, y.c0, y.stride, p.K, y.magic, sr.fb_mask);
         out.yh[k] = yh;
         out.yf[k] = yf;
         // above the strip's columns: a(c); its first row receives it (E: less gap_open)
@@ -302,7 +302,7 @@ bool check_classes(const Scheme& s, const SeedParams& p, const zsw::SeedRead& sr
                 zsw::SeedColDP dp;
                 zsw::seed_col_init(&dp, src < 0);
                 for (int k = 0; k < n_real; ++k) {
-                    const zsw::SeedStripEvents e = zsw::seed_strip_events(k * C, C, y.m, y.c0, y.stride, p.K, y.magic, mask);
+                    const zsw::SeedStripEventsT<uint64_t> e = zsw::seed_strip_events_t<uint64_t>(k * C, C, y.m, y.c0, y.stride, p.K, y.magic, mask);
                     int ux = -1;
                     for (int c = k * C; c < std::min(L, (k + 1) * C); ++c) {
                         int v = zsw::seed_col_step(&dp, p.maxw, y.lam, (e.start >> (c - k * C)) & 1u, (e.end >> (c - k * C)) & 1u, src < 0);
@@ -532,14 +532,14 @@ extern "C" int zsw_model_band(const int32_t* w, int S, int go, int ge, const uin
     return 0;
 }
 #else
-// `report`: the production setting (150-base reads against a 2 kb reference, 2 / -5, -10 / -1, K = 8, strips of 32 columns) —
+// `report`: the production setting (150-base reads against a 2 kb reference, 2 / -5, -10 / -1, K = 8, strips of ZSW_REPORT_C columns, default 32) —
 // how many reads of each divergence the walk accepts in a band of (wu, wd), for choosing the kernel's tiers. Every accepted read is
 // compared with the full matrix.
 int report(uint64_t seed, int n_reads) {
     std::mt19937_64 rng(seed);
     auto rnd = [&](int lo, int hi) { return lo + (int)(rng() % (uint64_t)(hi - lo + 1)); };
     const Scheme s = dna(2, -5, 0, 10, 1);
-    const int R = 2000, L = 150, K = 8, C = 32;
+    const int R = 2000, L = 150, K = 8, C = std::getenv("ZSW_REPORT_C") ? atoi(std::getenv("ZSW_REPORT_C")) : 32;
     std::vector<uint8_t> ref(R);
     for (auto& x : ref) x = (uint8_t)rnd(0, 3);
     bool ref_has[32] = {false};
@@ -662,7 +662,7 @@ int main(int argc, char** argv) {
         std::vector<uint32_t> table((size_t)2 << (2 * K), 0);
         zsw::seed_index_build(p, ref.data(), (uint64_t)R, table.data());
         auto geometry = [&](int* C, int* wu, int* wd, int* slo, int* shi, int* extra) {
-            *C = rnd(5, 32);
+            *C = rnd(0, 3) ? rnd(5, 32) : rnd(33, 64);  // (the kernel: 16 and 48)
             *wu = p.Dn + rnd(0, 24);
             *wd = p.Dm + rnd(0, 16);
             *slo = rnd(0, 3) ? 0 : rnd(0, 32);

@@ -1,7 +1,7 @@
 """The default (seeded, banded) score pass against read divergence: reads/s, the share of reads handed back to the full pass,
 and equality of every result with the full pass, for reads that are x % substituted pieces of the reference (+ x / 10 % indels,
 + 2 % unrelated reads).
-usage: python tools/bench_divergence.py [n_reads] [rates, per cent, comma-separated] [--ends] [--json]
+usage: python tools/bench_divergence.py [n_reads] [rates, per cent, comma-separated] [--ends] [--noband] [--json]
 The seeded pass proves a read's score with the k-mers the read shares with the reference: a path elsewhere loses at least
 lambda (7 with 2 / -5, -10 / -1) per sampled 8-mer without an occurrence there, i.e. 0.7 per column. A read that is itself further
 than that from the reference (one substitution per ten bases) cannot be told from such a path and is scored over all its cells:
@@ -55,6 +55,8 @@ if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     n = int(args[0]) if args else 1_000_000
     rates = [float(x) for x in args[1].split(",")] if len(args) > 1 else [1, 2, 3, 5, 8, 12]
+    if "--noband" in sys.argv:  # whole rows around the anchor (seed_window_kernel) instead of the banded kernel
+        zoe_amd.SwContext.get(0).debug_set(_lib.DEBUG_SEED_NO_BAND)
     res = sweep(zoe_amd.SwContext.get(0), n, rates, ends="--ends" in sys.argv)
     if "--json" in sys.argv:
         print(json.dumps(res))

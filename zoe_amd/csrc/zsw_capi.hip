@@ -507,6 +507,9 @@ zsw_error ranges_device(zsw_context* ctx, const Staged& st, const ResultRule& ru
             ScoreOut o3 = ro;  // rows: positions of the reversed reference; columns: positions of the reversed read
             o3.unique = ws[RW_UNIQ_R].as<uint8_t>();
             o3.skip_handed_back = true;
+            // the exact reverse kernel walks a read's prefixes for what the second tier costs per read, and always answers; only the
+            // certificate of run_align, whose unsettled reads take the literal second pass, is worth the second tier
+            o3.narrow_only = cert == nullptr;
             ScoreWorkspace w = score_ws(ctx);
             w.seed = &ctx->seed_rev;
             w.band_dbg = nullptr;

@@ -73,6 +73,9 @@ struct ScoreOut {
     uint8_t* unique = nullptr;
     // the seeded pass does not score the reads it hands back (the caller computes every read without `unique` by other means)
     bool skip_handed_back = false;
+    // the banded seeded pass stops after its first (narrow) tier: what fails there is handed back at once — for a caller whose own
+    // way of computing those reads costs no more than the second tier would (the exact reverse kernel of sw_simd_score_ranges)
+    bool narrow_only = false;
 };
 
 struct KernelTimer;

@@ -14,7 +14,8 @@
 // outside may score, are flagged (`retry`: walked again in the launch's wider band, launch_score_seeded) or join the worklist
 // of reads scored over all their cells. Host model, cell by cell against the full Gotoh matrix: tests/models/seed_band.cpp; the
 // same model as a library checks this kernel's own values (maximum, oa, ob) on the GPU: tests/test_gpu_bounds.py.
-// 150 bp: 5 strips x 46 (narrow) or 92 (full) rows x 32 columns per pair in one lane instead of 4 lanes x 211 steps x 38 columns.
+// 150 bp: 10 strips x 30 rows x 16 columns (first tier) or 4 strips x 85 rows x 48 columns (second tier) per pair in one lane instead of
+// 4 lanes x 211 steps x 38 columns.
 #include <algorithm>
 #include <type_traits>
 
@@ -27,13 +28,16 @@ namespace zsw {
 namespace {
 
 // Columns per strip (a multiple of 8: a strip's residue codes are whole dwords of the packed reads; MODE 3 keeps one bit per column
-// in a 32-bit mask). A strip computes a rectangle of C + Wu + Wd rows, the band itself is Wu + Wd + 1 diagonals: narrower strips
-// waste fewer cells (16 columns: 10 strips of 27 rows for a 150-base read in the narrow band; 32 columns: 5 strips of 43 rows),
+// in a 32- or 64-bit mask). A strip computes a rectangle of C + Wu + Wd rows, the band itself is Wu + Wd + 1 diagonals: narrower strips
+// waste fewer cells (16 columns: 10 strips of 30 rows for a 150-base read in the narrow band),
 // but every strip boundary is a place where a bound that entered the strip's corner can leave it again inside a k-mer without paying
 // for it (zsw_seed.hpp) — about lambda / 3 of slack per boundary and side. So the narrow first tier, which nearly every read
 // within a few per cent of the reference passes, walks 16-column strips, and the reads that fail there are walked again in
-// 32-column strips (and the wide band), where half as many boundaries leave the proof of a diverged read that much more room.
-constexpr int BC_NARROW = 16, BC_WIDE = 32;
+// 48-column strips: two boundaries inside a 150-base read instead of nine (tests/models/seed_band.cpp `report`: of reads with 5 %
+// substitutions 60 % prove their score in 16-column strips, 86 % in 32-column strips, 91 % in 48-column strips, 94 % without any
+// boundary; at 8 %: 12 / 33 / 42 / 50 %). 48 columns are what the register file holds: H, E and the selectors are 144 VGPRs
+// (score only: two wavefronts per SIMD; with the MODE 2 snapshot of the H row one, the AGPRs as spill space).
+constexpr int BC_NARROW = 16, BC_WIDE = 48;
 
 // What the kernel keeps per lane between strips, in LDS ([field][lane]: the registers of the row loop hold nothing but the strip):
 // the k-mer layout and masks of the lane's two reads, and the two bound programmes of zsw_seed.hpp (SeedColDP) for BOTH reads at
@@ -93,6 +97,16 @@ __device__ __forceinline__ uint32_t half_mask(uint32_t bitsA, uint32_t bitsB, in
     const uint32_t mA = (uint32_t)__builtin_amdgcn_sbfe((int)bitsA, (uint32_t)c, 1u), mB = (uint32_t)__builtin_amdgcn_sbfe((int)bitsB, (uint32_t)c, 1u);
     return __builtin_amdgcn_perm(mB, mA, 0x05040100u);
 }
+// (strips of more than 32 columns keep their per-column bits in 64-bit masks; c is a constant after unrolling)
+__device__ __forceinline__ uint32_t half_mask(uint64_t bitsA, uint64_t bitsB, int c) {
+    return half_mask((uint32_t)(c < 32 ? bitsA : bitsA >> 32), (uint32_t)(c < 32 ? bitsB : bitsB >> 32), c & 31);
+}
+__device__ __forceinline__ int mask_popc(uint32_t x) { return __popc(x); }
+__device__ __forceinline__ int mask_popc(uint64_t x) { return __popcll(x); }
+template <class M>
+__device__ __forceinline__ M mask_first(int n) {  // bits [0, n)
+    return n >= (int)sizeof(M) * 8 ? ~(M)0 : (((M)1 << n) - 1u);
+}
 __device__ __forceinline__ uint32_t pk_subu_sat(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
 }
@@ -120,6 +134,8 @@ __device__ __forceinline__ void pk_events(BandPk* t, uint32_t sm, uint32_t em, u
 template <int C, int MINW, int MODE>
 __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) {
     constexpr int TAG = MODE == 0 ? -1 : 1;
+    using M = std::conditional_t<(C > 32), uint64_t, uint32_t>;  // one bit per column of a strip
+    static_assert(C % 8 == 0 && C <= 64, "a strip's residue codes are whole dwords; its column masks at most 64 bits");
     __shared__ uint16_t sel_lut[16];
     __shared__ int sst[BF_N * BLOCK];
     const int tid = threadIdx.x;
@@ -212,9 +228,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
             const uint32_t lam2 = (uint32_t)st[BF_LAM2 * BLOCK];
             {
                 const BandLayout yA = band_layout(st, false), yB = band_layout(st, true);
-                const SeedStripEvents eA = seed_strip_events(k * C, C, yA.m, yA.c0, yA.stride, a.sp.K, yA.magic, yA.fa);
-                const SeedStripEvents eB = seed_strip_events(k * C, C, yB.m, yB.c0, yB.stride, a.sp.K, yB.magic, yB.fa);
-                const uint32_t any = eA.start | eA.end | eB.start | eB.end;
+                const SeedStripEventsT<M> eA = seed_strip_events_t<M>(k * C, C, yA.m, yA.c0, yA.stride, a.sp.K, yA.magic, yA.fa);
+                const SeedStripEventsT<M> eB = seed_strip_events_t<M>(k * C, C, yB.m, yB.c0, yB.stride, a.sp.K, yB.magic, yB.fa);
+                const M any = eA.start | eA.end | eB.start | eB.end;
                 BandPk up;
                 up.ch = (uint32_t)st[BF_UP_CH * BLOCK];
                 up.fr = (uint32_t)st[BF_UP_FR * BLOCK];
@@ -223,12 +239,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                 const uint32_t DrE = pk_addu(Dr, ge2);
                 auto sweep = [&](auto full_tag) {
                     constexpr bool FULL = decltype(full_tag)::value;
-                    const uint32_t realA = nrA >= 32 ? 0xffffffffu : ((1u << nrA) - 1u), realB = nrB >= 32 ? 0xffffffffu : ((1u << nrB) - 1u);
+                    const M realA = mask_first<M>(nrA), realB = mask_first<M>(nrB);
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         up.ch += maxw2;
                         up.fr += maxw2;
-                        if (__ballot((any >> c) & 1u) != 0) pk_events(&up, half_mask(eA.start, eB.start, c), half_mask(eA.end, eB.end, c), lam2);
+                        if (__ballot((uint32_t)(any >> c) & 1u) != 0) pk_events(&up, half_mask(eA.start, eB.start, c), half_mask(eA.end, eB.end, c), lam2);
                         uint32_t v = pk_subu_sat(pk_maxu(up.ch, up.fr), PKB2) & above;
                         if (!FULL) v &= half_mask(realA, realB, c);
                         oa2 = pk_maxu(oa2, v);
@@ -263,7 +279,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
             // MODE 3: the strip's real columns per read as bit masks (a padding column copies the value of its upper left
             // neighbour: a copy of the maximum is not a second cell holding it), and whether a row after the strip's latest rise
             // reached the same value again in a real column
-            const uint32_t realA = nrA >= 32 ? 0xffffffffu : ((1u << nrA) - 1u), realB = nrB >= 32 ? 0xffffffffu : ((1u << nrB) - 1u);
+            const M realA = mask_first<M>(nrA), realB = mask_first<M>(nrB);
             bool smA = false, smB = false;
 #pragma unroll 1
             for (int r = top; r < bot; ++r) {
@@ -316,12 +332,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                         if (ch >> 16) smB = false;
                         if (tA || tB) {  // rare: which columns hold it
                             const uint32_t target = pk_addu(nsb, Dr);
-                            uint32_t hitA = 0, hitB = 0;
+                            M hitA = 0, hitB = 0;
 #pragma unroll
                             for (int c = 0; c < C; ++c) {
                                 const uint32_t x = H[c] ^ target;
-                                if (!(x & 0xffffu)) hitA |= 1u << c;
-                                if (!(x >> 16)) hitB |= 1u << c;
+                                if (!(x & 0xffffu)) hitA |= (M)1 << c;
+                                if (!(x >> 16)) hitB |= (M)1 << c;
                             }
                             if (tA && (hitA & realA)) smA = true;
                             if (tB && (hitB & realB)) smB = true;
@@ -348,25 +364,25 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                 }
                 if (MODE >= 2 && (upA || upB || (MODE == 3 && (eqA || eqB)))) {
                     int cA = 0x7fffffff, cB = 0x7fffffff;
-                    uint32_t hitA = 0, hitB = 0;
+                    M hitA = 0, hitB = 0;
                     const int sdA = (int)(snapD & 0xffffu), sdB = (int)(snapD >> 16);
 #pragma unroll
                     for (int c = C - 1; c >= 0; --c) {
                         const uint32_t sv = snap[MODE >= 2 ? c : 0];
                         if ((int)(sv & 0xffffu) - sdA == sA) {
                             cA = k * C + c;
-                            hitA |= 1u << c;
+                            hitA |= (M)1 << c;
                         }
                         if ((int)(sv >> 16) - sdB == sB) {
                             cB = k * C + c;
-                            hitB |= 1u << c;
+                            hitB |= (M)1 << c;
                         }
                     }
                     if (upA) colA = cA;
                     if (upB) colB = cB;
                     if (MODE == 3) {
                         // cells of this strip holding its maximum: the real columns of the row of its latest rise, plus later rows
-                        const int nA = __popc(hitA & realA) + (smA ? 1 : 0), nB = __popc(hitB & realB) + (smB ? 1 : 0);
+                        const int nA = mask_popc(hitA & realA) + (smA ? 1 : 0), nB = mask_popc(hitB & realB) + (smB ? 1 : 0);
                         if (sA > 0 && (upA && !eqA)) multA = nA > 1;   // a higher maximum: this strip's cells are all there are so far
                         else if (eqA && nA > 0) multA = true;          // the same value in two strips: two cells
                         if (sB > 0 && (upB && !eqB)) multB = nB > 1;
@@ -388,21 +404,21 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
             // below the strip's columns: b(c) of either read, joined by the cells of the strip's last row (H holds them)
             {
                 const uint32_t below = bot < R ? 0xffffffffu : 0u, exits = (bot < R && bot > top) ? 0xffffffffu : 0u;
-                const SeedStripEvents eA = seed_strip_events(k * C, C, yA.m, yA.c0, yA.stride, a.sp.K, yA.magic, yA.fb);
-                const SeedStripEvents eB = seed_strip_events(k * C, C, yB.m, yB.c0, yB.stride, a.sp.K, yB.magic, yB.fb);
-                const uint32_t any = eA.start | eA.end | eB.start | eB.end;
+                const SeedStripEventsT<M> eA = seed_strip_events_t<M>(k * C, C, yA.m, yA.c0, yA.stride, a.sp.K, yA.magic, yA.fb);
+                const SeedStripEventsT<M> eB = seed_strip_events_t<M>(k * C, C, yB.m, yB.c0, yB.stride, a.sp.K, yB.magic, yB.fb);
+                const M any = eA.start | eA.end | eB.start | eB.end;
                 BandPk lo;
                 lo.ch = (uint32_t)st[BF_LO_CH * BLOCK];
                 lo.fr = (uint32_t)st[BF_LO_FR * BLOCK];
                 uint32_t ob2 = (uint32_t)st[BF_OB * BLOCK], b2 = 0;
                 auto sweep = [&](auto full_tag) {
                     constexpr bool FULL = decltype(full_tag)::value;
-                    const uint32_t realA = nrA >= 32 ? 0xffffffffu : ((1u << nrA) - 1u), realB = nrB >= 32 ? 0xffffffffu : ((1u << nrB) - 1u);
+                    const M realA = mask_first<M>(nrA), realB = mask_first<M>(nrB);
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         lo.ch += maxw2;
                         lo.fr += maxw2;
-                        if (__ballot((any >> c) & 1u) != 0) pk_events(&lo, half_mask(eA.start, eB.start, c), half_mask(eA.end, eB.end, c), lam2);
+                        if (__ballot((uint32_t)(any >> c) & 1u) != 0) pk_events(&lo, half_mask(eA.start, eB.start, c), half_mask(eA.end, eB.end, c), lam2);
                         uint32_t he = pk_addu(pk_untag<TAG>(pk_subu(H[c], Dr)), PKB2) & exits;
                         uint32_t rm = 0xffffffffu;
                         if (!FULL) {
@@ -499,17 +515,18 @@ bool seed_band_applicable(const SeedParams& p, uint32_t max_len, uint32_t rebase
 }
 
 hipError_t launch_seed_band(const SeedBandArgs& a, int mode, bool narrow_strips, hipStream_t stream) {
-    // H, E and the selectors are 3 * C registers (4 * C with the MODE 2 snapshot of the H row)
+    // H, E and the selectors are 3 * C registers (4 * C with the MODE 2 snapshot of the H row); measured: the 48-column ends kernels at
+    // one wavefront per SIMD (AGPRs as spill space) beat two with scratch by 16 %, the score-only kernel at two beats one by 4 %
     if (narrow_strips) {
         if (mode == 0) hipLaunchKernelGGL((seed_band_kernel<BC_NARROW, 4, 0>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
         else if (mode == 1) hipLaunchKernelGGL((seed_band_kernel<BC_NARROW, 4, 1>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
         else if (mode == 2) hipLaunchKernelGGL((seed_band_kernel<BC_NARROW, 3, 2>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
         else hipLaunchKernelGGL((seed_band_kernel<BC_NARROW, 3, 3>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
     } else {
-        if (mode == 0) hipLaunchKernelGGL((seed_band_kernel<BC_WIDE, 3, 0>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
-        else if (mode == 1) hipLaunchKernelGGL((seed_band_kernel<BC_WIDE, 3, 1>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
-        else if (mode == 2) hipLaunchKernelGGL((seed_band_kernel<BC_WIDE, 2, 2>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
-        else hipLaunchKernelGGL((seed_band_kernel<BC_WIDE, 2, 3>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+        if (mode == 0) hipLaunchKernelGGL((seed_band_kernel<BC_WIDE, 2, 0>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+        else if (mode == 1) hipLaunchKernelGGL((seed_band_kernel<BC_WIDE, 1, 1>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+        else if (mode == 2) hipLaunchKernelGGL((seed_band_kernel<BC_WIDE, 1, 2>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((seed_band_kernel<BC_WIDE, 1, 3>), dim3(a.grid), dim3(BLOCK), 0, stream, a);
     }
     return hipGetLastError();
 }

@@ -190,7 +190,7 @@ bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, ui
 
 hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max_len, const SeedIndex& ix, uint8_t* work, size_t work_bytes,
                                uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, const ScoreArgsV2* band_tabs, const uint2* gtab_band, int32_t* band_dbg,
-                               uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream, KernelTimer* window_timer) {
+                               uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream, KernelTimer* window_timer, bool narrow_only) {
     const uint32_t n = a2.b.n_items;
     if (n == 0) return hipSuccess;
     if (!work || !gtab || work_bytes < seed_workspace_bytes(n, max_len, band_grid_cap)) return hipErrorNotSupported;
@@ -301,14 +301,22 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
             b1.wu_per16 = SEED_NARROW_WU_PER16;
             b1.wd0 = SEED_NARROW_WD;
             b1.wd_per32 = SEED_NARROW_WD_PER32;
-            b1.retry = retry;
+            b1.retry = narrow_only ? nullptr : retry;  // no second tier: what fails joins the worklist at once
             b1.next_pair = queue1;
             e = launch_seed_band(b1, mode, true, stream);
             if (e != hipSuccess) return e;
+            if (narrow_only) {
+                if (window_timer) window_timer->end(stream);
+                return hipSuccess;
+            }
             e = hipcub::DeviceSelect::Flagged(temp, temp_bytes, (const uint32_t*)order, (const uint8_t*)retry, order2, n2, (int)n, stream);
             if (e != hipSuccess) return e;
             b.order = order2;
             b.n_dev = n2;
+            b.wu0 = SEED_SECOND_WU;
+            b.wu_per16 = SEED_SECOND_WU_PER16;
+            b.wd0 = SEED_SECOND_WD;
+            b.wd_per32 = SEED_SECOND_WD_PER32;
         }
         e = launch_seed_band(b, mode, false, stream);
         if (window_timer) window_timer->end(stream);

@@ -15,9 +15,13 @@ constexpr int SEED_DM = 4;     // banded pass: diagonals right of the anchor tha
 constexpr int SEED_WD = 9;     // banded pass: diagonals kept below the anchor, SEED_WD + len * SEED_WD_PER16 / 16 (18 for 150 bases;
 constexpr int SEED_WD_PER16 = 1;  // coming back from beyond them takes insertions: the gap and the inserted columns' potential)
 // A narrow first band for short reads (two tiers): most reads lose little to their own errors and prove their score inside
-// 12 + len/16 diagonals above and 6 + len/32 below the anchor; the reads that cannot are walked again in the full band
-// (SEED_M1 + len/8, SEED_WD + len/16), and only what fails there is scored over all its cells.
+// 8 diagonals above and 6 below the anchor, walked in 16-column strips; the reads that cannot are walked again in 48-column strips
+// — a third as many strip boundaries, each of which costs a diverged read's proof some slack (zsw_score_band.hip) — and a band of
+// 16 + len/16 above and 8 + len/32 below (a strip is a rectangle: 48 columns widen the band by themselves), and only what fails
+// there is scored over all its cells. A batch that takes one tier only (few reads, or reads of more than SEED_NARROW_MAX_LEN bases) walks the
+// full band (SEED_M1 + len/8, SEED_WD + len/16).
 constexpr int SEED_NARROW_WU = 8, SEED_NARROW_WU_PER16 = 0, SEED_NARROW_WD = 6, SEED_NARROW_WD_PER32 = 0;
+constexpr int SEED_SECOND_WU = 16, SEED_SECOND_WU_PER16 = 1, SEED_SECOND_WD = 8, SEED_SECOND_WD_PER32 = 1;
 constexpr uint32_t SEED_NARROW_MAX_LEN = 640;  // beyond: a read's own indels drift further than the narrow band is wide
 constexpr uint32_t SEED_NARROW_MIN_READS = 200000;  // below: two more launches cost more than the narrower band saves (length classes of a ragged batch)
 constexpr int SEED_BAND_SLACK = 32;           // banded pass: two reads share a lane if their anchors are at most this far apart
@@ -118,7 +122,7 @@ hipError_t seed_build_gtab(const ScoreArgsV2& a2, uint2* gtab, hipStream_t strea
 // per-row table is gtab_band (seed_build_gtab with those tables); band_dbg: zsw_debug_band_records.
 hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max_len, const SeedIndex& ix, uint8_t* work, size_t work_bytes,
                                uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, const ScoreArgsV2* band_tabs, const uint2* gtab_band, int32_t* band_dbg,
-                               uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream, KernelTimer* window_timer);
+                               uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream, KernelTimer* window_timer, bool narrow_only = false);
 // (Re)builds the index for a reference given as residue indices on the host.
 hipError_t seed_index_update(SeedIndex* ix, const ScoringDev& sc, const uint8_t* h_ref, size_t ref_len);
 void seed_index_release(SeedIndex* ix);

@@ -353,28 +353,36 @@ ZSW_SEED_HD void seed_col_join(SeedColDP* s, int v, bool free_track) {
     if (free_track) s->vfr = v > s->vfr ? v : s->vfr;
     else s->vch = v > s->vch ? v : s->vch;
 }
-// the events of a strip's columns [kC, kC + C), C <= 32: bit i = a k-mer of `mask` starts / ends in column kC + i
-struct SeedStripEvents {
-    uint32_t start, end;
-    uint32_t inside;  // bit i: column kC + i lies in a k-mer of the mask, but is not its last column
+// the events of a strip's columns [kC, kC + C): bit i = a k-mer of `mask` starts / ends in column kC + i. T = uint32_t for strips of
+// up to 32 columns, uint64_t for up to 64
+template <class T>
+struct SeedStripEventsT {
+    T start, end;
+    T inside;  // bit i: column kC + i lies in a k-mer of the mask, but is not its last column
 };
-ZSW_SEED_HD SeedStripEvents seed_strip_events(int kC, int C, int m, int c0, int stride, int K, uint32_t magic, uint32_t mask) {
-    SeedStripEvents e;
+template <class T>
+ZSW_SEED_HD SeedStripEventsT<T> seed_strip_events_t(int kC, int C, int m, int c0, int stride, int K, uint32_t magic, uint32_t mask) {
+    constexpr int BITS = (int)sizeof(T) * 8;
+    SeedStripEventsT<T> e;
     e.start = e.end = e.inside = 0;
     for (int j = seed_started(kC - 1, m, c0, magic); j < m; ++j) {
         const int cj = c0 + j * stride;
         if (cj >= kC + C) break;
-        if ((mask >> j) & 1u) e.start |= 1u << (cj - kC);
+        if ((mask >> j) & 1u) e.start |= (T)1 << (cj - kC);
     }
     for (int j = seed_started(kC - K, m, c0, magic); j < m; ++j) {  // the first k-mer whose last column is not left of the strip
         const int cj = c0 + j * stride, ej = cj + K - 1;
         if (cj >= kC + C) break;
         if (!((mask >> j) & 1u)) continue;
-        if (ej < kC + C) e.end |= 1u << (ej - kC);
+        if (ej < kC + C) e.end |= (T)1 << (ej - kC);
         const int lo = cj > kC ? cj - kC : 0, hi = ej < kC + C ? ej - kC : C;  // columns [lo, hi) of the strip
-        if (hi > lo) e.inside |= (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+        if (hi > lo) e.inside |= (hi >= BITS ? ~(T)0 : (((T)1 << hi) - 1u)) & ~(((T)1 << lo) - 1u);
     }
     return e;
+}
+using SeedStripEvents = SeedStripEventsT<uint32_t>;
+ZSW_SEED_HD SeedStripEvents seed_strip_events(int kC, int C, int m, int c0, int stride, int K, uint32_t magic, uint32_t mask) {
+    return seed_strip_events_t<uint32_t>(kC, C, m, c0, stride, K, magic, mask);
 }
 // A value leaves the band above it after column x, possibly as an open insertion run: it does not pay for a k-mer of the mask
 // whose territory (the `spacer` columns before it and all but its last column) holds column x.
