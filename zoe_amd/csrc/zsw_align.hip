@@ -462,16 +462,23 @@ __global__ void count_block_kernel(const zsw_alignment* aln, const uint8_t* stat
 }
 
 __global__ void scan_sums_kernel(uint64_t* block_sums, uint32_t nblocks, uint64_t* total) {
-    // single thread: nblocks <= ~2M/1024; tiny
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint64_t run = 0;
-        for (uint32_t k = 0; k < nblocks; ++k) {
-            const uint64_t t = block_sums[k];
-            block_sums[k] = run;
-            run += t;
+    // one wavefront: 64 entries per step, an inclusive scan across the lanes, the running total carried on (10 M reads: 9,766 entries)
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    uint64_t run = 0;
+    for (uint32_t k0 = 0; k0 < nblocks; k0 += 64) {
+        const uint32_t k = k0 + (uint32_t)lane;
+        const uint64_t t = k < nblocks ? block_sums[k] : 0;
+        uint64_t inc = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t up = (uint64_t)__shfl_up((unsigned long long)inc, d, 64);
+            if (lane >= d) inc += up;
         }
-        *total = run;
+        if (k < nblocks) block_sums[k] = run + inc - t;
+        run += (uint64_t)__shfl((unsigned long long)inc, 63, 64);
     }
+    if (lane == 0) *total = run;
 }
 
 __global__ void write_ciglets_kernel(zsw_alignment* aln, const uint8_t* status, uint32_t n, const uint64_t* block_sums,

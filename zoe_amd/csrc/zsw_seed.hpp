@@ -215,12 +215,14 @@ ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetCell cell, Looku
     // one sweep over the columns, k-mer by k-mer (the loops over the k-mers have a fixed trip count: their arrays stay in registers)
     int pot_lo[SEED_MAX_KMERS], pot_hi[SEED_MAX_KMERS], dlo[SEED_MAX_KMERS], dhi[SEED_MAX_KMERS], last[SEED_MAX_KMERS];
     bool usable[SEED_MAX_KMERS], has[SEED_MAX_KMERS];
+    uint32_t codes[SEED_MAX_KMERS];
     int pot = 0, c = 0;
     const int lam = seed_lambda(p, stride);
 #pragma unroll
     for (int j = 0; j < SEED_MAX_KMERS; ++j) {
         pot_lo[j] = pot_hi[j] = dlo[j] = dhi[j] = last[j] = 0;
         usable[j] = has[j] = false;
+        codes[j] = 0;
         if (j >= m) continue;
         const int cj = c0 + j * stride;
         // An insertion run that opened inside the previous k-mer (which charged it lambda for the opening) reaches this k-mer by
@@ -244,18 +246,27 @@ ZSW_SEED_HD SeedRead seed_read(const SeedParams& p, int len, GetCell cell, Looku
             if (k == p.K - 2) pot_hi[j] = pot;
         }
         usable[j] = ok;
-        if (ok) {
-            uint32_t f1 = 0, l1 = 0;
-            look(code, &f1, &l1);
-            if (f1 != 0) {
-                has[j] = true;
-                dlo[j] = (int)(f1 - 1) - cj;
-                dhi[j] = (int)(l1 - 1) - cj;
-                last[j] = (int)(l1 - 1);
-            }
-        }
+        codes[j] = ok ? code : 0u;
     }
     for (; c < len; ++c) pot += (int)(cell(c) & 0xffu);
+    // the index entries of all sampled k-mers: sixteen independent loads in flight together (on the GPU each is a trip to L2;
+    // entry 0 stands in for the k-mers that are not looked up, and is not used)
+    uint32_t f1s[SEED_MAX_KMERS], l1s[SEED_MAX_KMERS];
+#pragma unroll
+    for (int j = 0; j < SEED_MAX_KMERS; ++j) {
+        f1s[j] = l1s[j] = 0;
+        look(codes[j], &f1s[j], &l1s[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < SEED_MAX_KMERS; ++j) {
+        if (j < m && usable[j] && f1s[j] != 0) {
+            const int cj = c0 + j * stride;
+            has[j] = true;
+            dlo[j] = (int)(f1s[j] - 1) - cj;
+            dhi[j] = (int)(l1s[j] - 1) - cj;
+            last[j] = (int)(l1s[j] - 1);
+        }
+    }
     out.t_all = pot;
     if (m == 0) return out;
     int dt = 0;
