@@ -75,7 +75,7 @@ struct ThreePassArgs {
     // is what sw_simd_align returns at every <T, N>; every other read is left to the literal striped kernel (cert_done[i] = 0).
     const uint8_t* cert_ok = nullptr;
     uint8_t* cert_done = nullptr;
-    int cert_maxw = 0, cert_go = 0;
+    int cert_maxw = 0, cert_go = 0, cert_ge = 0;  // (the one-gap certificate, tests/models/align_onegap_cert.cpp, needs gap_extend too)
 };
 
 hipError_t launch_threepass(const ThreePassArgs& a, uint32_t grid, hipStream_t stream);

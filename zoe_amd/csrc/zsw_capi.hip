@@ -755,6 +755,7 @@ zsw_error run_align(zsw_context* ctx, const zsw_batch* reads, const ResultRule& 
         a.cert_done = ws[WS_CERT_DONE].as<uint8_t>();
         a.cert_maxw = maxw;
         a.cert_go = ctx->h_sc.gap_open;
+        a.cert_ge = ctx->h_sc.gap_extend;
         e = launch_threepass(a, std::min<uint32_t>((n + 63) / 64, 65536u), stream);
         if (e != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "align: certificate pass", e);
         hipLaunchKernelGGL(cert_status_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, so.status, ws[WS_CERT_DONE].as<uint8_t>(), ws[WS_CERT_STATUS].as<uint8_t>());

@@ -129,9 +129,14 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
         if (!a.list) {
             // classify pass: the no-gaps shortcut (three_pass.rs:37-58) is resolved here, the rest is queued for the DP pass
             // (certificate mode: only reads with one optimal alignment, which must be this diagonal; the rest is not touched)
-            const bool may = !a.cert_ok || (a.cert_ok[id] && re > rs && (long long)score > (long long)a.cert_maxw * ((long long)rlen - 1) - 2ll * a.cert_go);
+            // Certificate mode (run_align): a.cert_ok[id] = both maxima of the read sit in one cell each, so every alignment that
+            // scores `score` runs from (rs, qs) to (re - 1, qe - 1). Equal ranges: it must be the diagonal, and no path with an
+            // insertion and a deletion may reach it (tests/models/align_gapless_cert.cpp). Ranges that differ by g: exactly one
+            // placement of ONE gap run of g must reach it, and no path with two runs may (tests/models/align_onegap_cert.cpp).
+            const bool cert = a.cert_ok != nullptr;
+            const bool uniq = !cert || (a.cert_ok[id] && re > rs && qe > qs);
             if (a.cert_done) a.cert_done[id] = 0;
-            if (may && qlen == rlen) {
+            if (uniq && qlen == rlen && (!cert || (long long)score > (long long)a.cert_maxw * ((long long)rlen - 1) - 2ll * a.cert_go)) {
                 int64_t sum = 0;
                 uint32_t k = 0;
                 for (; k + 4 <= qlen; k += 4) {  // four residues per (unaligned) load
@@ -152,6 +157,45 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                     out.query_start = qs;
                     out.query_end = qe;
                     done = true;
+                }
+            } else if (cert && uniq && qlen != rlen) {
+                const bool del = rlen > qlen;  // the run consumes reference rows
+                const uint32_t g = del ? rlen - qlen : qlen - rlen, m = del ? qlen : rlen;
+                const long long two_runs = (long long)a.cert_maxw * m - 2ll * a.cert_go - (long long)(g > 2 ? g - 2 : 0) * a.cert_ge;
+                if (m >= 2 && (long long)score > two_runs) {
+                    // second diagonal: the pairs behind the run
+                    const uint8_t* r1 = reference + rs + (del ? g : 0);
+                    const uint8_t* q1 = query + qs + (del ? 0 : g);
+                    int64_t t1 = 0;
+                    for (uint32_t k = 0; k < m; ++k) t1 += wt(r1[k], q1[k]);
+                    const int64_t gap = (int64_t)a.cert_go + (int64_t)(g - 1) * a.cert_ge;
+                    int64_t p0 = 0, p1 = 0, best = INT64_MIN;
+                    uint32_t best_p = 0, n_best = 0;
+                    for (uint32_t p = 1; p < m; ++p) {
+                        p0 += wt(reference[rs + p - 1], query[qs + p - 1]);
+                        p1 += wt(r1[p - 1], q1[p - 1]);
+                        const int64_t sc = p0 + (t1 - p1) - gap;
+                        if (sc > best) {
+                            best = sc;
+                            best_p = p;
+                            n_best = 1;
+                        } else if (sc == best) {
+                            ++n_best;
+                        }
+                    }
+                    if (n_best == 1 && best == (int64_t)score) {
+                        w.push(query_len - qe, 'S');
+                        w.push(m - best_p, 'M');
+                        w.push(g, del ? 'D' : 'I');
+                        w.push(best_p, 'M');
+                        w.push(qs, 'S');
+                        w.flush();
+                        out.ref_start = rs;
+                        out.ref_end = re;
+                        out.query_start = qs;
+                        out.query_end = qe;
+                        done = true;
+                    }
                 }
             }
             if (!done && a.cert_ok) continue;
