@@ -131,8 +131,8 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
             // (certificate mode: only reads with one optimal alignment, which must be this diagonal; the rest is not touched)
             // Certificate mode (run_align): a.cert_ok[id] = both maxima of the read sit in one cell each, so every alignment that
             // scores `score` runs from (rs, qs) to (re - 1, qe - 1). Equal ranges: it must be the diagonal, and no path with an
-            // insertion and a deletion may reach it (tests/models/align_gapless_cert.cpp). Ranges that differ by g: exactly one
-            // placement of ONE gap run of g must reach it, and no path with two runs may (tests/models/align_onegap_cert.cpp).
+            // insertion and a deletion may reach it (tests/models/align_gapless_cert.cpp). Ranges that differ by g: one placement
+            // of ONE gap run of g (or a run of adjacent placements) must reach it, and no path with two runs may (tests/models/align_onegap_cert.cpp).
             const bool cert = a.cert_ok != nullptr;
             const bool uniq = !cert || (a.cert_ok[id] && re > rs && qe > qs);
             if (a.cert_done) a.cert_done[id] = 0;
@@ -170,20 +170,22 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                     for (uint32_t k = 0; k < m; ++k) t1 += wt(r1[k], q1[k]);
                     const int64_t gap = (int64_t)a.cert_go + (int64_t)(g - 1) * a.cert_ge;
                     int64_t p0 = 0, p1 = 0, best = INT64_MIN;
-                    uint32_t best_p = 0, n_best = 0;
+                    uint32_t best_p = 0, first_p = 0, n_best = 0;
                     for (uint32_t p = 1; p < m; ++p) {
                         p0 += wt(reference[rs + p - 1], query[qs + p - 1]);
                         p1 += wt(r1[p - 1], q1[p - 1]);
                         const int64_t sc = p0 + (t1 - p1) - gap;
                         if (sc > best) {
                             best = sc;
-                            best_p = p;
+                            best_p = first_p = p;
                             n_best = 1;
                         } else if (sc == best) {
                             ++n_best;
+                            best_p = p;
                         }
                     }
-                    if (n_best == 1 && best == (int64_t)score) {
+                    // one placement, or adjacent ones (a gap inside a homopolymer run): the walk from the end takes the last
+                    if (best_p - first_p == n_best - 1 && best == (int64_t)score) {
                         w.push(query_len - qe, 'S');
                         w.push(m - best_p, 'M');
                         w.push(g, del ? 'D' : 'I');
