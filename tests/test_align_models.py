@@ -122,12 +122,12 @@ def test_gapless_alignment_certificate_model(tmp_path, seed):
 @pytest.mark.parametrize("seed", [20261005, 6])
 def test_one_gap_alignment_certificate_model(tmp_path, seed):
     """The second certificate of run_align (zsw_threepass.hip, classify pass in certificate mode): both maxima in one cell each,
-    ranges that differ by g, exactly one placement of ONE gap run of g between the corners reaches the score (one sweep over the
-    prefix sums of the two diagonals), and the score lies beyond maxw * min(rlen, qlen) - 2 * gap_open - max(g - 2, 0) * gap_extend,
+    ranges that differ by g, one placement of ONE gap run of g between the corners — or a run of adjacent placements, of which the
+    walk from the end takes the last — reaches the score (one sweep over the prefix sums of the two diagonals), and the score lies beyond maxw * min(rlen, qlen) - 2 * gap_open - max(g - 2, 0) * gap_extend,
     which no alignment with two gap runs reaches. The oracle's literal sw_simd_align must then return [p M][g D|I][m - p M] at
-    N = 2 .. 64 in 16-bit lanes and N = 16, 32 in 8-bit lanes; ten schemes, gaps of 1-5 inside repeats and homopolymer runs (ties:
-    never certified), reads with a second gap. (Without the uniqueness of p, or without the two-run bound, a counter-example turns up
-    within 3,000 iterations.)"""
+    N = 2 .. 64 in 16-bit lanes and N = 16, 32 in 8-bit lanes; ten schemes, gaps of 1-5 inside repeats and homopolymer runs (tied
+    placements), reads with a second gap. (Taking any tied placement but the last, or dropping the two-run bound, produces a
+    counter-example within 3,000 iterations.)"""
     out = subprocess.run([_build(tmp_path, "align_onegap_cert"), "500", str(seed)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "align_onegap_cert OK" in out.stdout

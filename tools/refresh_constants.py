@@ -40,7 +40,7 @@ band0 = lambda k: "seed_band_kernel<" in k and k.split("seed_band_kernel<")[1].s
 band_valu = total(f"{src}/band/pmc_a", "SQ_INSTS_VALU", band0) / CALLS_BAND / N_BAND
 band_fetch = total(f"{src}/band/pmc_fetch", "FETCH_SIZE", band0) * KIB / CALLS_BAND / N_BAND
 band_write = total(f"{src}/band/pmc_write", "WRITE_SIZE", band0) * KIB / CALLS_BAND / N_BAND
-names = sorted(k.split("::")[-1].split("(")[0] for k in counters(f"{src}/band/pmc_a", "SQ_INSTS_VALU") if band0(k))
+names = sorted("seed_band_kernel<" + k.split("seed_band_kernel<")[1].split(">")[0].replace(" ", "") + ">" for k in counters(f"{src}/band/pmc_a", "SQ_INSTS_VALU") if band0(k))
 subprocess.check_call([sys.executable, "tools/summarize_seed_prof.py", f"{src}/band", f"{tag}_band_summary", str(int(N_BAND))])
 for f in glob.glob(f"{src}/band/stats/*/*kernel_stats.csv"):  # the rocprofv3 --kernel-trace --stats table itself, kernels above 0.1 %
     rows = list(csv.DictReader(open(f)))
