@@ -52,7 +52,7 @@ def load_constants():
 
 PC = load_constants()
 PMC_PROFILE = PC["band"]["source"]
-WINDOW_HBM_BYTES_PER_READ = PC["band"]["hbm_bytes_per_read"]   # FETCH_SIZE + WRITE_SIZE per read of the batch, both launches of the banded kernel (tier 1 seed_band_kernel<16,4,0>, tier 2 <32,3,0>)
+WINDOW_HBM_BYTES_PER_READ = PC["band"]["hbm_bytes_per_read"]   # FETCH_SIZE + WRITE_SIZE per read of the batch, both launches of the banded kernel (tier 1 seed_band_kernel<16,4,0>, tier 2 <48,2,0>)
 WINDOW_VALU_PER_READ = PC["band"]["valu_per_read"]            # SQ_INSTS_VALU per read of the batch, both launches
 VALU_PEAK_SOURCE = "profiles/r01_valu_issue_rates_ubench.txt"  # this repo's micro-benchmark (tools/ubench.hip), not a figure of the guide
 TOTAL_READS_MULTI_GPU = 500_000_000  # BASELINE.json configs[3]
@@ -609,7 +609,7 @@ def main():
         pass_s = kern_s / max(launches, 1)             # the whole first pass: seed + sort + window + full pass over the handed-back reads
         seeded = win_launches > 0
         kern = win_s / win_launches if seeded else pass_s  # the dominant kernel alone
-        kernel_name = "zsw::seed_band_kernel<16,4,0> over every read (16-column strips, band 8/6) + <32,3,0> over the reads that fail in it (32-column strips, band 42/18): two launches per step" if seeded else "zsw::score_kernel_v2<4,38,0>"
+        kernel_name = "zsw::seed_band_kernel<16,4,0> over every read (16-column strips, band 8/6) + <48,2,0> over the reads that fail in it (48-column strips, band 25/12): two launches per step" if seeded else "zsw::score_kernel_v2<4,38,0>"
         achieved = ALGO_BYTES_PER_READ * n_local / kern / 1e9 if kern > 0 else 0.0
         traffic = WINDOW_HBM_BYTES_PER_READ * n_local if (seeded and WINDOW_HBM_BYTES_PER_READ) else None
         out = {
