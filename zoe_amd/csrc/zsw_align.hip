@@ -181,6 +181,169 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs a) {
     }
 }
 
+// The one-profile-many-sequences role when every score of the launch fits 16 bits (the i8 / i16 instantiations) and the rows of the
+// shared sequence's profile fit LDS with three wavefronts per CU: H and E of a vector in ONE dword per lane (two 16-bit halves), the
+// profile's residue codes once per block ([nv][N] bytes: every read of the launch meets the same profile), the row's flag bytes; the
+// next vector's dword and code are fetched before the current vector's are stored. Same recurrence, same lazy-F loop, same flags
+// as align_kernel<N, ., true> — which kept these rows in L2 (80 KB per wavefront at nv = 125 left LDS with two wavefronts per CU)
+// and ran at 29 cycles per instruction behind its own stores.
+// a lane's flag bytes of one row: nv rounded up to whole dwords, an odd number of them (lanes one stride apart never share a bank)
+__host__ __device__ inline uint32_t align_shared_row_stride(uint32_t nv) { return (((nv + 3) / 4) | 1u) * 4; }
+__host__ __device__ inline size_t align_shared_lds_bytes(uint32_t nv, int N) {
+    return (size_t)nv * 64 * 4 + (size_t)64 * align_shared_row_stride(nv) + (((size_t)nv * N + 15) & ~(size_t)15);
+}
+constexpr size_t ALIGN_SHARED_LDS_LIMIT = 52 * 1024;  // three blocks per CU
+
+template <int N>
+__global__ __launch_bounds__(64) void align_shared_kernel_h(AlignArgs a) {
+    extern __shared__ __align__(16) uint8_t smem_lds[];
+    __shared__ uint8_t lut[256];
+    __shared__ int32_t wpad[MAX_S * (MAX_S + 1)];  // weights with one more column: the padding residue S scores 0
+    constexpr int RPW = 64 / N;
+    const int lane = threadIdx.x;
+    const int li = lane % N, grp = lane / N;
+    const uint32_t nv = a.nv;
+    const uint32_t nvp = align_shared_row_stride(nv);  // a lane's flag bytes of one row: nv, padded so that 64 lanes fall into 32 banks twice
+    const int S = a.sc->S;
+    const int go = a.sc->gap_open, ge = a.sc->gap_extend;
+    uint32_t* HE = reinterpret_cast<uint32_t*>(smem_lds);     // [nv][64]: H in the low half, E in the high half
+    uint8_t* fl = smem_lds + (size_t)nv * 64 * 4;             // [64][nvp]: the row's flags, a lane's vectors side by side
+    uint8_t* kq = fl + (size_t)64 * nvp;                      // [nv][N]: residue code of position v + lane * nv (S = padding)
+    for (int i = lane; i < 256; i += 64) lut[i] = a.sc->index_map[i];
+    for (int i = lane; i < S * (S + 1); i += 64) wpad[i] = (i % (S + 1)) < S ? a.sc->w[(i / (S + 1)) * S + i % (S + 1)] : 0;
+    __syncthreads();
+    const uint32_t plen = a.prof_len;
+    for (uint32_t i = lane; i < nv * N; i += 64) {  // StripedProfile::new_unchecked (profile.rs:270-306), once per block
+        const uint32_t v = i / N, l = i % N, q = v + l * nv;
+        kq[i] = q < plen ? lut[a.prof_seq[q]] : (uint8_t)S;
+    }
+    for (uint32_t i = lane; i < 64 * nvp / 4; i += 64) reinterpret_cast<uint32_t*>(fl)[i] = 0;  // (the padding bytes travel to the ring)
+    __syncthreads();
+    const unsigned long long gmask = (N == 64) ? ~0ull : (((1ull << N) - 1ull) << (grp * N));
+    // the ring: per read W rows of [N lanes][nvp] flag bytes — a lane's share of a row goes out as whole dwords
+    const size_t row_bytes = (size_t)N * nvp;
+    uint8_t* ring = a.ring + ((size_t)blockIdx.x * RPW + grp) * (size_t)a.W * row_bytes;
+    uint8_t* const myfl = fl + (size_t)lane * nvp;
+
+    for (;;) {
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(a.next_item, (uint32_t)RPW);
+        first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+        if (first >= a.b.n_items) break;
+        const uint32_t item = first + grp;
+        const bool valid = item < a.b.n_items;
+        const uint32_t id = valid ? (a.b.items ? a.b.items[item] : item) : 0;
+        uint64_t off = 0;
+        const uint32_t rlen = valid ? read_len(a.b, id, &off) : 0;
+        const bool active = valid && a.status[id] == ZSW_STATUS_SOME && plen > 0 && rlen > 0;
+        const int rend = active ? (int)a.ref_end[id] - 1 : -1;
+        const int32_t best = active ? (int32_t)a.score[id] : 0;
+        for (uint32_t v = 0; v < nv; ++v) HE[v * 64 + lane] = 0;
+        int rmax = rend;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) rmax = max(rmax, __shfl_xor(rmax, d, 64));
+        uint8_t base_next = (active && rend >= 0) ? a.b.bases[off] : (uint8_t)0;
+
+        for (int r = 0; r <= rmax; ++r) {  // every row's flags are kept (W >= the longest read): the rows start at the read's first base
+            const bool act = r <= rend;
+            const int ri = lut[act ? base_next : (uint8_t)0];
+            if (r + 1 <= rend) base_next = a.b.bases[off + (uint32_t)r + 1];  // (in flight under this row)
+            const int32_t* wrow = wpad + ri * (S + 1);
+            // main pass (striped.rs:481-526). The loads of a vector step are issued one step ahead: the dword of H and E and the
+            // weight of vector v + 1 (whose residue code came in a step earlier still), the code of vector v + 2.
+            int32_t F = 0;
+            int32_t H = __shfl_up((int32_t)(HE[(nv - 1) * 64 + lane] & 0xffffu), 1, N);
+            if (li == 0) H = 0;
+            uint32_t he_cur = HE[lane];
+            int32_t w_cur = wrow[kq[li]];
+            uint32_t k_next = nv > 1 ? kq[N + li] : 0u;
+            for (uint32_t v = 0; v < nv; ++v) {
+                const uint32_t he = he_cur;
+                const int32_t w = w_cur;
+                if (v + 1 < nv) {
+                    he_cur = HE[(v + 1) * 64 + lane];
+                    w_cur = wrow[k_next];
+                    if (v + 2 < nv) k_next = kq[(v + 2) * N + li];
+                }
+                int32_t E = (int32_t)(he >> 16);
+                const int32_t hold = (int32_t)(he & 0xffffu);
+                H = max(H + w, 0);
+                H = max(H, max(E, F));
+                uint32_t flags = (E == H ? BT_UP : 0) | (F == H ? BT_LEFT : 0);
+                const bool stopped = H == 0;
+                const int32_t Hn = H;
+                H = max(H - go, 0);
+                E = max(max(E - ge, 0), H);
+                F = max(max(F - ge, 0), H);
+                flags |= (E > H ? BT_UP_EXT : 0) | (F > H ? BT_LEFT_EXT : 0);
+                if (stopped) flags = BT_STOP;
+                if (act) {
+                    HE[v * 64 + lane] = (uint32_t)Hn | ((uint32_t)E << 16);
+                    myfl[v] = (uint8_t)flags;
+                }
+                H = hold;
+            }
+            // lazy-F pass (striped.rs:528-553): per read, up to N rounds, stops at the first vector where no lane of THAT read has
+            // F > H - gap_open
+            bool done = !act;
+            for (int it = 0; it < N; ++it) {
+                F = __shfl_up(F, 1, N);
+                if (li == 0) F = 0;
+                bool all_done = false;
+                for (uint32_t v = 0; v < nv; ++v) {
+                    const uint32_t he = HE[v * 64 + lane];
+                    H = (int32_t)(he & 0xffffu);
+                    const bool cond = !done && F > max(H - go, 0);
+                    const unsigned long long bal = __ballot(cond);
+                    if ((bal & gmask) == 0) done = true;
+                    if (bal == 0) {  // every read of the wave has left its lazy-F loop
+                        all_done = true;
+                        break;
+                    }
+                    if (!done) {
+                        H = max(H, F);
+                        uint32_t flags = myfl[v];
+                        const bool stopped = H == 0;
+                        if (F == H) flags = (flags & BT_UP_EXT) | BT_LEFT;  // simd_correct_and_set_left
+                        HE[v * 64 + lane] = (he & 0xffff0000u) | (uint32_t)H;
+                        H = max(H - go, 0);
+                        F = max(F - ge, 0);
+                        if (F > H) flags |= BT_LEFT_EXT;
+                        if (stopped) flags = BT_STOP;
+                        myfl[v] = (uint8_t)flags;
+                    }
+                }
+                if (all_done) break;
+            }
+            if (act) {  // the row's flags: this lane's nvp bytes as dwords
+                uint32_t* dst = reinterpret_cast<uint32_t*>(ring + (size_t)(r % (int)a.W) * row_bytes + (size_t)li * nvp);
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(myfl);
+                for (uint32_t q = 0; q < nvp / 4; ++q) dst[q] = src[q];
+            }
+        }
+
+        // c_end: first position of the profile sequence in row r_end whose H equals the best score (striped.rs:571-583)
+        int cend = 0x7fffffff;
+        if (active) {
+            for (int v = (int)nv - 1; v >= 0; --v) {
+                const uint32_t ci = (uint32_t)v + (uint32_t)li * nv;
+                if (ci < plen && (int32_t)(HE[v * 64 + lane] & 0xffffu) == best) cend = (int)ci;
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < N; d <<= 1) cend = min(cend, __shfl_xor(cend, d, N));
+        __threadfence_block();  // this wave's ring stores are visible to its own traceback loads
+
+        if (active && li == 0) {
+            auto cell = [&](int rr, int cc) -> uint32_t {
+                return __hip_atomic_load(ring + (size_t)(rr % (int)a.W) * row_bytes + (size_t)(cc / (int)nv) * nvp + (size_t)(cc % (int)nv),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            traceback_emit(a, id, item, plen, rend, cend, best, cell, (int)a.W, rlen);
+        }
+    }
+}
+
 // shift_elements_right::<1>(T::MIN) inside groups of N lanes as one DPP move: row_shr:1 shifts within rows of 16 lanes and
 // wave_shr:1 across the whole wavefront; lanes without a source keep `old` = 0, group-leading lanes are zeroed.
 template <int N>
@@ -667,15 +830,21 @@ size_t align_ring_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid) {
 // its registers allow (100,000 reads vs 2 kb: 590 -> see DESIGN.md 4.5).
 constexpr size_t SHARED_ROWS_LDS_LIMIT = 16 * 1024;
 static bool shared_rows_global(uint32_t nv, int S) { return align_lds_bytes(nv, S) > SHARED_ROWS_LDS_LIMIT; }
+// (rows of N * align_shared_row_stride(nv) bytes: what align_shared_kernel_h writes; the generic kernel's N * nv fit inside)
+static size_t shared_ring_only_bytes(int N, uint32_t nv, uint32_t W, uint32_t grid) {
+    return ((size_t)grid * (64 / N) * (size_t)W * ((size_t)N * align_shared_row_stride(nv)) + 255) / 256 * 256;
+}
 size_t align_shared_ring_bytes(int N, uint32_t plen, uint32_t W, uint32_t grid, int S) {
     const uint32_t nv = (plen + (uint32_t)N - 1) / (uint32_t)N;
-    size_t bytes = ((size_t)grid * (64 / N) * (size_t)W * ((size_t)N * nv) + 255) / 256 * 256;
+    size_t bytes = shared_ring_only_bytes(N, nv, W, grid);
     if (shared_rows_global(nv, S)) bytes += (size_t)grid * align_rows_bytes(nv);
     return bytes;
 }
 
 template <int N>
-static hipError_t launch_align_shared_n(const AlignArgs& a, int S, uint32_t grid, hipStream_t stream) {
+static hipError_t launch_align_shared_n(const AlignArgs& a, int S, uint32_t grid, hipStream_t stream, bool half_ok) {
+    if (half_ok && align_shared_lds_bytes(a.nv, N) <= ALIGN_SHARED_LDS_LIMIT)
+        return launch_with_lds(&align_shared_kernel_h<N>, a, grid, align_shared_lds_bytes(a.nv, N), stream);
     if (shared_rows_global(a.nv, S)) {
         hipLaunchKernelGGL((align_kernel<N, true, true>), dim3(grid), dim3(64), 0, stream, a);
         return hipGetLastError();
@@ -687,7 +856,7 @@ hipError_t align_pass2_shared(int N, const uint8_t* d_pseq, uint32_t plen, const
                               const uint32_t* d_score, const uint32_t* d_ref_end, const uint8_t* d_status, uint32_t W, uint32_t maxc,
                               uint8_t* d_ring, uint32_t grid, uint32_t* d_cig, uint64_t pool_base, int by_item, uint64_t* d_cig_start,
                               uint32_t* d_cig_raw, zsw_alignment* d_aln, uint32_t* d_fb_list, uint32_t* d_fb_count, int invert,
-                              hipStream_t stream) {
+                              hipStream_t stream, bool half_ok) {
     const uint32_t nv = (plen + (uint32_t)N - 1) / (uint32_t)N;
     AlignArgs a;
     a.b = b;
@@ -713,17 +882,17 @@ hipError_t align_pass2_shared(int N, const uint8_t* d_pseq, uint32_t plen, const
     a.safe_row = nullptr;
     a.prof_seq = d_pseq;
     a.prof_len = plen;
-    a.rows = shared_rows_global(nv, S) ? d_ring + ((size_t)grid * (64 / N) * (size_t)W * ((size_t)N * nv) + 255) / 256 * 256 : nullptr;
+    a.rows = shared_rows_global(nv, S) ? d_ring + shared_ring_only_bytes(N, nv, W, grid) : nullptr;
     a.next_item = d_fb_count + 1;
     hipError_t ce = hipMemsetAsync(a.next_item, 0, 4, stream);
     if (ce != hipSuccess) return ce;
     switch (N) {
-        case 2: return launch_align_shared_n<2>(a, S, grid, stream);
-        case 4: return launch_align_shared_n<4>(a, S, grid, stream);
-        case 8: return launch_align_shared_n<8>(a, S, grid, stream);
-        case 16: return launch_align_shared_n<16>(a, S, grid, stream);
-        case 32: return launch_align_shared_n<32>(a, S, grid, stream);
-        case 64: return launch_align_shared_n<64>(a, S, grid, stream);
+        case 2: return launch_align_shared_n<2>(a, S, grid, stream, half_ok);
+        case 4: return launch_align_shared_n<4>(a, S, grid, stream, half_ok);
+        case 8: return launch_align_shared_n<8>(a, S, grid, stream, half_ok);
+        case 16: return launch_align_shared_n<16>(a, S, grid, stream, half_ok);
+        case 32: return launch_align_shared_n<32>(a, S, grid, stream, half_ok);
+        case 64: return launch_align_shared_n<64>(a, S, grid, stream, half_ok);
     }
     return hipErrorInvalidValue;
 }

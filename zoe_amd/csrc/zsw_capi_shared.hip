@@ -496,7 +496,8 @@ zsw_error run_align_shared(zsw_context* ctx, const zsw_batch* reads, const Resul
         hipError_t he = align_pass2_shared(N, ctx->d_pseq.as<uint8_t>(), plen, b, ctx->d_sc.as<ScoringDev>(), S, so.score, so.ref_end, so.status, W, maxc,
                                            ringbuf.as<uint8_t>(), grid, cigbuf.as<uint32_t>(), 0, by_item, ws[WS_CIGSTART].as<uint64_t>(),
                                            ws[WS_CIGRAW].as<uint32_t>(), ws[WS_ALN].as<zsw_alignment>(), ws[WS_FBLIST].as<uint32_t>(),
-                                           ws[WS_FBCOUNT].as<uint32_t>(), invert, stream);
+                                           ws[WS_FBCOUNT].as<uint32_t>(), invert, stream,
+                                           rule.n_tiers == 1 ? rule.tier_code[0] != 32 : N != lanes_w32);
         if (he != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "shared align pass 2", he);
         return ZSW_OK;
     };

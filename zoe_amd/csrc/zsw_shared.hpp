@@ -21,6 +21,6 @@ hipError_t align_pass2_shared(int N, const uint8_t* d_pseq, uint32_t plen, const
                               const uint32_t* d_score, const uint32_t* d_ref_end, const uint8_t* d_status, uint32_t W, uint32_t maxc,
                               uint8_t* d_ring, uint32_t grid, uint32_t* d_cig, uint64_t pool_base, int by_item, uint64_t* d_cig_start,
                               uint32_t* d_cig_raw, zsw_alignment* d_aln, uint32_t* d_fb_list, uint32_t* d_fb_count, int invert,
-                              hipStream_t stream);
+                              hipStream_t stream, bool half_ok /* every score of these reads fits 16 bits: the 8- and 16-bit instantiations */);
 
 }  // namespace zsw
