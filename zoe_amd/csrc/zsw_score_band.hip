@@ -148,6 +148,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
     const int R = (int)a.ref_len;
     const uint32_t n_items = a.n_dev ? min(*a.n_dev, a.n) : a.n;
     const uint32_t n_pairs = (n_items + 1) / 2;
+    const bool bail = a.bail_check && a.accepted && (uint64_t)(*a.accepted) * SEED_BAIL_RATIO < (uint64_t)n_items;
+    uint32_t n_accepted = 0;  // (first tier)
     const uint32_t ge2 = a.ge2, gd2 = a.gd2;  // doubled gap penalties (the tables hold doubled scores)
     const uint32_t ge1 = ge2 & 0xffffu;
     const uint32_t maxw2 = (uint32_t)a.sp.maxw * 0x00010001u, go2p = (uint32_t)a.sp.go * 0x00010001u;  // plain (not doubled) scores of the bound programmes
@@ -178,6 +180,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
         int dtB = validB ? (int)keyB - (int)a.key_bias : dtA;
         const uint32_t idA = a.b.items ? a.b.items[ridA] : ridA;
         uint32_t idB = validB ? (a.b.items ? a.b.items[ridB] : ridB) : idA;
+        if (bail) {  // (launch-uniform)
+            a.fail_list[atomicAdd(a.fail_count, 1u)] = idA;
+            if (validB) a.fail_list[atomicAdd(a.fail_count, 1u)] = idB;
+            continue;
+        }
         if (validB && dtB - dtA > SEED_BAND_SLACK) {  // anchors too far apart to share a band: B waits for the next tier / takes the full pass
             if (a.retry) a.retry[itemB] = 1;
             else a.fail_list[atomicAdd(a.fail_count, 1u)] = idB;
@@ -473,6 +480,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
                 if (a.retry) a.retry[h ? itemB : itemA] = 1;
                 else a.fail_list[atomicAdd(a.fail_count, 1u)] = id;
             } else {
+                ++n_accepted;
                 uint32_t score;
                 uint8_t status, tier;
                 apply_rule(a.rule, (uint64_t)S, &score, &status, &tier);
@@ -488,6 +496,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
             }
         }
         }  // active
+    }
+    if (a.retry && a.accepted) {  // first tier: one atomic per wavefront
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) n_accepted += (uint32_t)__shfl_xor((int)n_accepted, d, 64);
+        if ((tid & 63) == 0 && n_accepted) atomicAdd(a.accepted, n_accepted);
     }
 }
 

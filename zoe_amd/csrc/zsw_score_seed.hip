@@ -284,8 +284,9 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
         uint32_t* queue2 = reinterpret_cast<uint32_t*>(work + (size_t)n * 4);
         e = hipMemsetAsync(queue1, 0, 4, stream);
         if (e != hipSuccess) return e;
-        e = hipMemsetAsync(queue2, 0, 4, stream);
+        e = hipMemsetAsync(queue2, 0, 8, stream);  // (and the first tier's count of accepted reads behind it)
         if (e != hipSuccess) return e;
+        uint32_t* accepted = queue2 + 1;
         b.next_pair = queue2;
         if (window_timer) window_timer->begin(stream);
         if (max_len <= SEED_NARROW_MAX_LEN && n >= narrow_min_reads) {
@@ -302,6 +303,7 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
             b1.wd0 = SEED_NARROW_WD;
             b1.wd_per32 = SEED_NARROW_WD_PER32;
             b1.retry = narrow_only ? nullptr : retry;  // no second tier: what fails joins the worklist at once
+            b1.accepted = narrow_only ? nullptr : accepted;
             b1.next_pair = queue1;
             e = launch_seed_band(b1, mode, true, stream);
             if (e != hipSuccess) return e;
@@ -317,6 +319,10 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
             b.wu_per16 = SEED_SECOND_WU_PER16;
             b.wd0 = SEED_SECOND_WD;
             b.wd_per32 = SEED_SECOND_WD_PER32;
+            // measured (tools/bench_divergence.py): at 8 % divergence the first tier accepts 12 % of the anchored reads and the second
+            // a third of the rest (worth it); at 10 % 3 % and an eighth (break-even); at 12 % 0.4 % and 3 % (4 ms spent to save 1)
+            b.accepted = accepted;
+            b.bail_check = true;
         }
         e = launch_seed_band(b, mode, false, stream);
         if (window_timer) window_timer->end(stream);

@@ -21,6 +21,7 @@ constexpr int SEED_WD_PER16 = 1;  // coming back from beyond them takes insertio
 // there is scored over all its cells. A batch that takes one tier only (few reads, or reads of more than SEED_NARROW_MAX_LEN bases) walks the
 // full band (SEED_M1 + len/8, SEED_WD + len/16).
 constexpr int SEED_NARROW_WU = 8, SEED_NARROW_WU_PER16 = 0, SEED_NARROW_WD = 6, SEED_NARROW_WD_PER32 = 0;
+constexpr uint32_t SEED_BAIL_RATIO = 40;
 constexpr int SEED_SECOND_WU = 16, SEED_SECOND_WU_PER16 = 1, SEED_SECOND_WD = 8, SEED_SECOND_WD_PER32 = 1;
 constexpr uint32_t SEED_NARROW_MAX_LEN = 640;  // beyond: a read's own indels drift further than the narrow band is wide
 constexpr uint32_t SEED_NARROW_MIN_READS = 200000;  // below: two more launches cost more than the narrower band saves (length classes of a ragged batch)
@@ -87,6 +88,11 @@ struct SeedBandArgs {
     const uint32_t* n_dev;             // non-null: the number of items in `order` (a device-side count, at most n)
     uint32_t* next_pair;               // work queue: the next pair to hand out (zeroed before the launch)
     uint8_t* retry;                    // non-null (first tier): a read whose bounds fail sets retry[its position in `order`] instead of joining the list
+    // first tier: counts the reads it accepts; second tier: if the first accepted fewer than one read per SEED_BAIL_RATIO that arrive
+    // here (a batch ten per cent or more away from the reference: the wider strips would prove a few per cent of them for more than
+    // the full pass of those few costs), the launch hands its items back without walking them
+    uint32_t* accepted = nullptr;
+    bool bail_check = false;
     int* dbg;                          // non-null (tests): 8 ints per read — the walk's own values (maximum, oa, ob) and its geometry
     uint32_t key_bias, fail_key;
     uint32_t* fail_list;
