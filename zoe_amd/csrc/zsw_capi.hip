@@ -494,22 +494,15 @@ zsw_error ranges_device(zsw_context* ctx, const Staged& st, const ResultRule& ru
             ZSW_HIP(ctx, seed_index_update(&ctx->seed_rev, ctx->h_sc, rev.data(), R));
         }
         if (ctx->seed_rev.usable) {
-            uint64_t bytes = (uint64_t)n * st.b.fixed_len;
-            if (st.b.offsets) {
-                ZSW_HIP(ctx, hipMemcpyAsync(&bytes, st.b.offsets + n, 8, hipMemcpyDeviceToHost, stream));
-                ZSW_HIP(ctx, hipStreamSynchronize(stream));
-            }
-            ZSW_HIP(ctx, ws[RW_RBASES].ensure(bytes + 16));
             ZSW_HIP(ctx, ws[RW_UNIQ_R].ensure((size_t)n + 4));
             ZSW_HIP(ctx, ws[RW_ULIST].ensure((size_t)n * 4 + 4));
             ZSW_HIP(ctx, ws[RW_UCOUNT].ensure(4));
             ZSW_HIP(ctx, hipMemsetAsync(ws[RW_UNIQ_R].p, 0, n, stream));
-            ZSW_HIP(ctx, launch_reverse_reads(st.b, bytes, ws[RW_RBASES].as<uint8_t>(), stream));
-            BatchDev brev = st.b;
-            brev.bases = ws[RW_RBASES].as<uint8_t>();
+            BatchDev brev = st.b;  // the same bases: the seeded pass reads them back to front (ScoreOut::reads_reversed)
             ScoreOut o3 = ro;  // rows: positions of the reversed reference; columns: positions of the reversed read
             o3.unique = ws[RW_UNIQ_R].as<uint8_t>();
             o3.skip_handed_back = true;
+            o3.reads_reversed = true;
             // the exact reverse kernel walks a read's prefixes for what the second tier costs per read, and always answers; only the
             // certificate of run_align, whose unsettled reads take the literal second pass, is worth the second tier
             o3.narrow_only = cert == nullptr;

@@ -51,22 +51,6 @@ __global__ void select_not_unique_kernel(uint32_t n, const uint8_t* unique, uint
 }
 
 // every read of the batch reversed (same offsets): the other sequence of the reverse pass
-__global__ void reverse_reads_kernel(BatchDev b, uint64_t total_bases, uint8_t* out) {
-    if (!b.offsets) {
-        const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (i < total_bases) {
-            const uint64_t id = i / b.fixed_len, j = i % b.fixed_len;
-            out[id * b.fixed_len + (b.fixed_len - 1 - j)] = b.bases[i];
-        }
-    } else {
-        const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-        if (id < b.n_reads) {
-            const uint64_t o = b.offsets[id], e = b.offsets[id + 1];
-            for (uint64_t j = o; j < e; ++j) out[e - 1 - (j - o)] = b.bases[j];
-        }
-    }
-}
-
 // Second pass of sw_simd_score_ranges in the shared role, settled by the seeded pass over the REVERSED sequences: read i is done
 // if its forward maximum sits in one cell (uf), the reversed problem's maximum sits in one cell (ur) and the two scores agree —
 // then the starts are that cell's coordinates turned round (rs: position in rev(read) + 1 -> inclusive start in the read, qs
@@ -110,11 +94,6 @@ __global__ void settle_reverse_kernel(BatchDev b, uint32_t n, uint32_t plen, con
 namespace zsw {
 namespace capi {
 // (also used by the read-as-profile role's ranges, zsw_capi.hip: its reverse pass as a second seeded pass)
-hipError_t launch_reverse_reads(const BatchDev& b, uint64_t total_bases, uint8_t* out, hipStream_t stream) {
-    if (b.offsets) hipLaunchKernelGGL(reverse_reads_kernel, dim3((b.n_reads + 255) / 256), dim3(256), 0, stream, b, total_bases, out);
-    else if (total_bases) hipLaunchKernelGGL(reverse_reads_kernel, dim3((unsigned)((total_bases + 255) / 256)), dim3(256), 0, stream, b, total_bases, out);
-    return hipGetLastError();
-}
 // read_side / other_side: the reversed pass's ends in the reversed read / in the reversed other sequence (of other_len residues); on
 // return the inclusive starts in the sequences themselves for the settled reads
 hipError_t launch_settle_reverse(const BatchDev& b, uint32_t n, uint32_t other_len, const uint8_t* uf, const uint8_t* ur, const uint32_t* fscore,
@@ -346,21 +325,9 @@ zsw_error ranges_shared_device(zsw_context* ctx, const Staged& st, const ResultR
             ZSW_HIP(ctx, seed_index_update(&ctx->seed_shared_rev, h_t, rev.data(), plen));
         }
         if (ctx->seed_shared_rev.usable) {
-            const uint64_t total = st.b.offsets ? 0 : (uint64_t)n * st.b.fixed_len;
-            uint64_t bytes = total;
-            if (st.b.offsets) {
-                uint64_t last = 0;
-                ZSW_HIP(ctx, hipMemcpyAsync(&last, st.b.offsets + n, 8, hipMemcpyDeviceToHost, stream));
-                ZSW_HIP(ctx, hipStreamSynchronize(stream));
-                bytes = last;
-            }
-            ZSW_HIP(ctx, ws[SH_RBASES].ensure(bytes + 16));
             ZSW_HIP(ctx, ws[SH_UNIQUE_R].ensure((size_t)n + 4));
             ZSW_HIP(ctx, hipMemsetAsync(ws[SH_UNIQUE_R].p, 0, n, stream));
-            if (st.b.offsets) hipLaunchKernelGGL(reverse_reads_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, st.b, bytes, ws[SH_RBASES].as<uint8_t>());
-            else if (bytes) hipLaunchKernelGGL(reverse_reads_kernel, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, stream, st.b, bytes, ws[SH_RBASES].as<uint8_t>());
-            BatchDev brev = st.b;
-            brev.bases = ws[SH_RBASES].as<uint8_t>();
+            BatchDev brev = st.b;  // the same bases: the seeded pass reads them back to front (ScoreOut::reads_reversed)
             ScoreOut o3 = ro;
             o3.ref_end = ro.query_end;   // rows of the swapped problem: positions of the reversed profile sequence
             o3.query_end = ro.ref_end;   // columns: positions of the reversed read
@@ -368,6 +335,7 @@ zsw_error ranges_shared_device(zsw_context* ctx, const Staged& st, const ResultR
             o3.fb_count = ctx->d_fb_count.as<uint32_t>();
             o3.unique = ws[SH_UNIQUE_R].as<uint8_t>();
             o3.skip_handed_back = true;
+            o3.reads_reversed = true;
             ScoreWorkspace w = score_ws(ctx);
             w.seed = &ctx->seed_shared_rev;
             hipError_t e3 = launch_score(ctx->d_sc_t.as<ScoringDev>(), h_t, brev, st.max_len, ctx->d_pseq_rev.as<uint8_t>(), (uint32_t)plen, rule, o3, w,

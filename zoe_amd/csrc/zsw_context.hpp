@@ -203,9 +203,8 @@ struct RangesDev {  // device arrays of sw_simd_score_ranges for every read (lib
 zsw_error threepass_third_pass(zsw_context* ctx, const Staged& st, const RangesDev& rd, const uint8_t* pseq, uint32_t pseq_len, bool host, int invert,
                                zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap,
                                uint64_t* out_n_ciglets, hipStream_t stream);
-// zsw_capi_shared.hip: every read reversed in place of a copy of the batch; and the settlement of a reversed seeded pass (a read is
+// zsw_capi_shared.hip: the settlement of a reversed seeded pass (a read is
 // done if both maxima sit in one cell each and the scores agree; the others are listed for the exact reverse kernel)
-hipError_t launch_reverse_reads(const BatchDev& b, uint64_t total_bases, uint8_t* out, hipStream_t stream);
 hipError_t launch_settle_reverse(const BatchDev& b, uint32_t n, uint32_t other_len, const uint8_t* uf, const uint8_t* ur, const uint32_t* fscore,
                                  const uint8_t* fstatus, const uint32_t* rscore, const uint8_t* rstatus, uint32_t* read_side, uint32_t* other_side,
                                  uint32_t* list, uint32_t* count, hipStream_t stream, uint8_t* settled = nullptr);  // settled[i] = 1: read i is done

@@ -76,6 +76,9 @@ struct ScoreOut {
     // the banded seeded pass stops after its first (narrow) tier: what fails there is handed back at once — for a caller whose own
     // way of computing those reads costs no more than the second tier would (the exact reverse kernel of sw_simd_score_ranges)
     bool narrow_only = false;
+    // the seeded pass reads every read back to front (the reverse seeded pass of sw_simd_score_ranges: no reversed copy of the batch);
+    // only with skip_handed_back — no other kernel knows
+    bool reads_reversed = false;
 };
 
 struct KernelTimer;

@@ -602,7 +602,7 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
         pe = launch_score_seeded(ap, g, c, longest, *ws.seed, ws.seed_work + work_off, seed_workspace_bytes(bb.n_items, longest, band_grid_cap), ws.seed_gtab,
                                  ws.prune_fail_list + list_off, counter, mode, band_ok ? &ab : nullptr, gtab_band, ws.band_dbg,
                                  (ws.debug & ZSW_DEBUG_SEED_WIDE_BAND) ? 0xffffffffu : (ws.debug & ZSW_DEBUG_SCORE_PRUNE_ANY_SIZE) ? 0u : SEED_NARROW_MIN_READS, band_grid_cap, stream,
-                                 ws.window_timer, out.narrow_only);
+                                 ws.window_timer, out.narrow_only, out.reads_reversed && out.skip_handed_back);
         if (pe != hipSuccess) return pe;
         ap.b.items = ws.prune_fail_list + list_off;
         ap.n_items_dev = counter;

@@ -38,6 +38,7 @@ struct SeedArgs {
     uint32_t ref_len;
     uint32_t* fail_list;
     uint32_t* fail_count;
+    bool reversed;  // column c of a read is its base len - 1 - c
 };
 
 // One thread per read. STAGED (contiguous fixed-length reads of at most SEED_STAGE_LEN bases): the block's reads arrive in LDS
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a) {
     sr.bl_mask = 0;
     if (valid && len >= SEED_MIN_LEN && len < SEED_KEY_BIAS) {
         const uint8_t* bases = STAGED ? sbytes + off : a.b.bases + off;
+        const bool rev = a.reversed;
         const uint2* table = a.table;
         // seed_read asks for every column exactly once, in order: the cell functor also packs the residue codes for the banded pass
         uint32_t* code_out = a.codes ? a.codes + (size_t)k * a.cs : nullptr;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a) {
         sr = seed_read(
             a.sp, (int)len,
             [&](int c) {
-                const uint32_t v = cell_lut[bases[c]];
+                const uint32_t v = cell_lut[bases[rev ? (int)len - 1 - c : c]];
                 if (code_out) {
                     acc |= (v >> 12) << (4 * (c & 7));
                     if ((c & 7) == 7) {
@@ -128,7 +130,8 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a) {
                 if (swept && (len & 7u)) {
                     const uint8_t* bases = STAGED ? sbytes + off : a.b.bases + off;
                     tail = 0;
-                    for (uint32_t c = full * 8; c < full * 8 + 8; ++c) tail |= (c < len ? (uint32_t)(cell_lut[bases[c]] >> 12) : 15u) << (4 * (c & 7));
+                    for (uint32_t c = full * 8; c < full * 8 + 8; ++c)
+                        tail |= (c < len ? (uint32_t)(cell_lut[bases[a.reversed ? len - 1 - c : c]] >> 12) : 15u) << (4 * (c & 7));
                 }
                 code_row[full] = tail;
                 for (uint32_t d = full + 1; d < a.cs; ++d) code_row[d] = 0xffffffffu;
@@ -190,7 +193,7 @@ bool seed_applicable(const SeedIndex& ix, uint32_t max_len, uint32_t ref_len, ui
 
 hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max_len, const SeedIndex& ix, uint8_t* work, size_t work_bytes,
                                uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, const ScoreArgsV2* band_tabs, const uint2* gtab_band, int32_t* band_dbg,
-                               uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream, KernelTimer* window_timer, bool narrow_only) {
+                               uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream, KernelTimer* window_timer, bool narrow_only, bool reads_reversed) {
     const uint32_t n = a2.b.n_items;
     if (n == 0) return hipSuccess;
     if (!work || !gtab || work_bytes < seed_workspace_bytes(n, max_len, band_grid_cap)) return hipErrorNotSupported;
@@ -238,6 +241,7 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
     s.ref_len = a2.ref_len;
     s.fail_list = fail_list;
     s.fail_count = fail_count;
+    s.reversed = reads_reversed;
     if (!s.b.offsets && !s.b.items && s.b.fixed_len <= SEED_STAGE_LEN)
         hipLaunchKernelGGL(seed_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, stream, s);
     else
@@ -355,6 +359,7 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
     w.fail_key = fail_key;
     w.fail_list = fail_list;
     w.fail_count = fail_count;
+    w.reversed = reads_reversed;
     if (window_timer) window_timer->begin(stream);
     e = mode == 0 ? launch_seed_window_m0(w, G, C, stream) : mode == 1 ? launch_seed_window_m1(w, G, C, stream) : launch_seed_window_m2(w, G, C, stream);
     if (window_timer) window_timer->end(stream);

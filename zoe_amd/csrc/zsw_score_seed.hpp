@@ -62,6 +62,7 @@ struct SeedWindowArgs {
     uint32_t key_bias, fail_key;
     uint32_t* fail_list;      // global read ids
     uint32_t* fail_count;
+    bool reversed = false;    // column c of a read is its base len - 1 - c
 };
 
 // banded pass (zsw_score_band.hip): one read pair per lane, strips of query columns
@@ -128,7 +129,7 @@ hipError_t seed_build_gtab(const ScoreArgsV2& a2, uint2* gtab, hipStream_t strea
 // per-row table is gtab_band (seed_build_gtab with those tables); band_dbg: zsw_debug_band_records.
 hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max_len, const SeedIndex& ix, uint8_t* work, size_t work_bytes,
                                uint2* gtab, uint32_t* fail_list, uint32_t* fail_count, int mode, const ScoreArgsV2* band_tabs, const uint2* gtab_band, int32_t* band_dbg,
-                               uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream, KernelTimer* window_timer, bool narrow_only = false);
+                               uint32_t narrow_min_reads, uint32_t band_grid_cap, hipStream_t stream, KernelTimer* window_timer, bool narrow_only = false, bool reads_reversed = false);
 // (Re)builds the index for a reference given as residue indices on the host.
 hipError_t seed_index_update(SeedIndex* ix, const ScoringDev& sc, const uint8_t* h_ref, size_t ref_len);
 void seed_index_release(SeedIndex* ix);

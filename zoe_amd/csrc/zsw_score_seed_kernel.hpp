@@ -74,8 +74,8 @@ __global__ __launch_bounds__(BLOCK, seed_min_waves(C, MODE)) void seed_window_ke
     for (int c = 0; c < C; ++c) {
         const uint32_t q = (uint32_t)(g * C + c);
         uint32_t kA = PAD_K, kB = PAD_K;
-        if (q < lenA) kA = lut[a.b.bases[offA + q]];
-        if (q < lenB) kB = lut[a.b.bases[offB + q]];
+        if (q < lenA) kA = lut[a.b.bases[offA + (a.reversed ? lenA - 1 - q : q)]];
+        if (q < lenB) kB = lut[a.b.bases[offB + (a.reversed ? lenB - 1 - q : q)]];
         const uint32_t sA = kA < 4 ? (2 * kA + 1) | ((8 + kA) << 8) : (kA == PAD_K ? 0x0c00u : (2 * (kA - 3)) | 0x0c00u);
         const uint32_t sB = kB < 4 ? (2 * kB + 1) | ((8 + kB) << 8) : (kB == PAD_K ? 0x0c00u : (2 * (kB - 3)) | 0x0c00u);
         sel[c] = sA | (sB << 16);
