@@ -628,7 +628,18 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
                 hipLaunchKernelGGL(chunk_finalize_kernel, dim3(zgrid), dim3(256), 0, stream, ap.b, counter, ws.chunk_keys, ap.limit, rule, out, std::min(mode, 2));
                 pe = hipGetLastError();
             } else {
-                pe = launch_table_cfg_v2(ap, g, c, mode, stream);
+                // A short list is latency-bound in the class's configuration (10,000 reads hand back a few hundred: one wavefront per
+                // 32 reads walking all R rows is 1.3 ms whatever the count): with a guess of the count — a thirty-second of the
+                // batch — it takes the small-batch configuration, more lanes per read (the count itself stays on the device).
+                int g2 = g, c2 = c;
+                ScoreArgsV2 ah = a2;
+                if (score_config_for_batch(longest, bb.n_items / 32 + 1024, &g2, &c2) && g2 != g && build_tables_v2(h_sc, g2, &ah)) {
+                    ah.b = ap.b;
+                    ah.n_items_dev = counter;
+                    pe = launch_table_cfg_v2(ah, g2, c2, mode, stream);
+                } else {
+                    pe = launch_table_cfg_v2(ap, g, c, mode, stream);
+                }
             }
         }
         if (pe != hipSuccess) return pe;
