@@ -148,7 +148,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void seed_band_kernel(SeedBandArgs a) 
     const int R = (int)a.ref_len;
     const uint32_t n_items = a.n_dev ? min(*a.n_dev, a.n) : a.n;
     const uint32_t n_pairs = (n_items + 1) / 2;
-    const bool bail = a.bail_check && a.accepted && (uint64_t)(*a.accepted) * SEED_BAIL_RATIO < (uint64_t)n_items;
+    const bool bail = a.bail_check && a.accepted && ((uint64_t)(*a.accepted) * SEED_BAIL_RATIO < (uint64_t)n_items || n_items < a.bail_below);
     uint32_t n_accepted = 0;  // (first tier)
     const uint32_t ge2 = a.ge2, gd2 = a.gd2;  // doubled gap penalties (the tables hold doubled scores)
     const uint32_t ge1 = ge2 & 0xffffu;

@@ -327,6 +327,7 @@ hipError_t launch_score_seeded(const ScoreArgsV2& a2, int G, int C, uint32_t max
             // a third of the rest (worth it); at 10 % 3 % and an eighth (break-even); at 12 % 0.4 % and 3 % (4 ms spent to save 1)
             b.accepted = accepted;
             b.bail_check = true;
+            b.bail_below = band_dbg ? 0u : SEED_BAIL_BELOW;  // (the bounds test wants the second tier's records)
         }
         e = launch_seed_band(b, mode, false, stream);
         if (window_timer) window_timer->end(stream);

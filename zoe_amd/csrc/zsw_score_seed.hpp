@@ -22,6 +22,7 @@ constexpr int SEED_WD_PER16 = 1;  // coming back from beyond them takes insertio
 // full band (SEED_M1 + len/8, SEED_WD + len/16).
 constexpr int SEED_NARROW_WU = 8, SEED_NARROW_WU_PER16 = 0, SEED_NARROW_WD = 6, SEED_NARROW_WD_PER32 = 0;
 constexpr uint32_t SEED_BAIL_RATIO = 40;
+constexpr uint32_t SEED_BAIL_BELOW = 16384;  // 0.4 ms of second-tier latency = the full pass of 13,000 reads
 constexpr int SEED_SECOND_WU = 16, SEED_SECOND_WU_PER16 = 1, SEED_SECOND_WD = 8, SEED_SECOND_WD_PER32 = 1;
 constexpr uint32_t SEED_NARROW_MAX_LEN = 640;  // beyond: a read's own indels drift further than the narrow band is wide
 constexpr uint32_t SEED_NARROW_MIN_READS = 200000;  // below: two more launches cost more than the narrower band saves (length classes of a ragged batch)
@@ -94,6 +95,8 @@ struct SeedBandArgs {
     // the full pass of those few costs), the launch hands its items back without walking them
     uint32_t* accepted = nullptr;
     bool bail_check = false;
+    uint32_t bail_below = 0;  // ... or with fewer items than this: a handful of reads costs the second tier one wavefront's whole walk (0.4 ms)
+                              // and the full pass 30 ns each
     int* dbg;                          // non-null (tests): 8 ints per read — the walk's own values (maximum, oa, ob) and its geometry
     uint32_t key_bias, fail_key;
     uint32_t* fail_list;
