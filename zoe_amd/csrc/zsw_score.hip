@@ -629,16 +629,30 @@ hipError_t launch_score(const ScoringDev* d_sc, const ScoringDev& h_sc, const Ba
                 pe = hipGetLastError();
             } else {
                 // A short list is latency-bound in the class's configuration (10,000 reads hand back a few hundred: one wavefront per
-                // 32 reads walking all R rows is 1.3 ms whatever the count): with a guess of the count — a thirty-second of the
-                // batch — it takes the small-batch configuration, more lanes per read (the count itself stays on the device).
-                int g2 = g, c2 = c;
-                ScoreArgsV2 ah = a2;
-                if (score_config_for_batch(longest, bb.n_items / 32 + 1024, &g2, &c2) && g2 != g && build_tables_v2(h_sc, g2, &ah)) {
-                    ah.b = ap.b;
-                    ah.n_items_dev = counter;
-                    pe = launch_table_cfg_v2(ah, g2, c2, mode, stream);
-                } else {
-                    pe = launch_table_cfg_v2(ap, g, c, mode, stream);
+                // 32 reads walking all R rows is 1.3 ms whatever the count), a long one throughput-bound in any other. The count
+                // stays on the device, so the list is launched in up to three configurations — the ones the cost model picks for
+                // 16 k, 128 k and many reads — and each launch returns at once unless the count lies in its range (measured, 1 M
+                // reads: 21 k handed back 1.27 ms at 8 lanes per pair, 1.1 ms at 16; 110 k: 4.3 ms at 4 lanes, 4.0 ms at 8).
+                const uint32_t cuts[2] = {49152u, 327680u}, probe[2] = {16384u, 131072u};
+                uint32_t lo = 0;
+                for (int k = 0; k < 3 && pe == hipSuccess; ++k) {
+                    const uint32_t hi = k < 2 ? cuts[k] : 0xffffffffu;
+                    int g2 = g, c2 = c;
+                    ScoreArgsV2 ah = ap;
+                    const bool other = k < 2 && lo < bb.n_items && score_config_for_batch(longest, probe[k], &g2, &c2) && g2 != g;
+                    if (other) {
+                        ah = a2;
+                        if (!build_tables_v2(h_sc, g2, &ah)) continue;  // (the class's configuration serves this range too: lo stays)
+                        ah.b = ap.b;
+                        ah.b.n_items = std::min(bb.n_items, hi);  // (the grid: a longer list is not this launch's)
+                        ah.n_items_dev = counter;
+                    } else if (k < 2) {
+                        continue;
+                    }
+                    ah.gate_lo = lo;
+                    ah.gate_hi = hi;
+                    if (lo < bb.n_items) pe = launch_table_cfg_v2(ah, other ? g2 : g, other ? c2 : c, mode, stream);
+                    lo = hi;
                 }
             }
         }

@@ -89,6 +89,9 @@ struct ScoreArgsV2 {
     // non-null: the number of items is read from the device (a worklist filled by an earlier kernel of the stream); the grid
     // is sized for b.n_items, blocks past the list return at once
     const uint32_t* n_items_dev = nullptr;
+    // ... and the launch does nothing unless that number lies in [gate_lo, gate_hi): the same worklist is launched in several strip
+    // configurations (many lanes per read for a short list, few for a long one), and the count picks the one that runs
+    uint32_t gate_lo = 0, gate_hi = 0xffffffffu;
     // Row-chunked launch (reads handed back by the seeded pass against a long reference: a few thousand reads walking 30,000 rows
     // each fill a fraction of the chip): chunk_rows > 0 = blockIdx.y is a chunk of reference rows, rows [y * chunk_rows -
     // chunk_overlap, (y + 1) * chunk_rows) from a zero state; a path that spans more than chunk_overlap rows cannot be positive
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(BLOCK, min_waves(C, MODE)) void score_kernel_v2(Sco
     const uint32_t group = blockIdx.x * (BLOCK / G) + tid / G;
     const uint32_t itemA = 2 * group, itemB = 2 * group + 1;
     const uint32_t n_items = a.n_items_dev ? min(*a.n_items_dev, a.b.n_items) : a.b.n_items;
-    if (2 * blockIdx.x * (BLOCK / G) >= n_items) return;
+    if (2 * blockIdx.x * (BLOCK / G) >= n_items || n_items < a.gate_lo || n_items >= a.gate_hi) return;
     const bool validA = itemA < n_items, validB = itemB < n_items;
     const uint32_t idA = validA ? (a.b.items ? a.b.items[itemA] : itemA) : 0;
     const uint32_t idB = validB ? (a.b.items ? a.b.items[itemB] : itemB) : 0;
