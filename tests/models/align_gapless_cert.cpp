@@ -71,6 +71,24 @@ bool returns_diagonal(const std::vector<uint8_t>& ref, const std::vector<uint8_t
            (int)a.value.query_end == qe && a.value.states == want;
 }
 
+
+// The same pair with the roles swapped, as the shared-profile role sees it (zsw_capi_shared.hip): the profile is striped over the
+// reference-side sequence, the read supplies the rows; the only optimal alignment is the same diagonal, the clipped ends those of
+// the long sequence.
+template <typename T, int N>
+bool returns_diagonal_swapped(const std::vector<uint8_t>& ref, const std::vector<uint8_t>& q, const ProfileWeights& pw, const ByteIndexMap& map, int go, int ge,
+                              int S, int rs, int re, int qs, int qe) {
+    auto prof = StripedProfile<T, N>::make(ref.data(), ref.size(), pw, map, -go, -ge);
+    const Maybe<Alignment> a = sw_simd_align<T, N>(q.data(), q.size(), prof);
+    if (a.status != SOME) return a.status == OVERFLOWED;
+    AlignmentStates want;
+    want.soft_clip((size_t)rs);
+    want.add_ciglet({(size_t)(re - rs), 'M'});
+    want.soft_clip(ref.size() - (size_t)re);
+    return (int)a.value.score == S && (int)a.value.ref_start == qs && (int)a.value.ref_end == qe && (int)a.value.query_start == rs &&
+           (int)a.value.query_end == re && a.value.states == want;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -143,7 +161,11 @@ int main(int argc, char** argv) {
                             returns_diagonal<int16_t, 32>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe) &&
                             returns_diagonal<int16_t, 64>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe) &&
                             returns_diagonal<int8_t, 16>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe) &&
-                            returns_diagonal<int8_t, 32>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe);
+                            returns_diagonal<int8_t, 32>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe) &&
+                            returns_diagonal_swapped<int16_t, 4>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe) &&
+                            returns_diagonal_swapped<int16_t, 16>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe) &&
+                            returns_diagonal_swapped<int16_t, 64>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe) &&
+                            returns_diagonal_swapped<int8_t, 32>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe);
             if (!ok) {
                 printf("certified read whose striped alignment is not the diagonal: S %d ref [%d,%d) query [%d,%d) scheme %d/%d/%d/%d\n  ref  ", S, rs, re, qs, qe, sc.match,
                        sc.mismatch, sc.go, sc.ge);

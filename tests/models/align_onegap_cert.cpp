@@ -81,6 +81,28 @@ bool returns_onegap(const std::vector<uint8_t>& ref, const std::vector<uint8_t>&
            (int)a.value.query_end == qe && a.value.states == want;
 }
 
+
+// The same pair with the roles swapped, as the shared-profile role sees it (zsw_capi_shared.hip): the profile is striped over the
+// reference-side sequence, the read supplies the rows. The matrix is the transpose; its only optimal alignment is the transpose of
+// the certified one (insertions and deletions trade places, the clipped ends are those of the long sequence), and among adjacent
+// tied placements the walk from the end meets the same one first.
+template <typename T, int N>
+bool returns_onegap_swapped(const std::vector<uint8_t>& ref, const std::vector<uint8_t>& q, const ProfileWeights& pw, const ByteIndexMap& map, int go, int ge, int S,
+                            int rs, int re, int qs, int qe, int p, int g, char op) {
+    auto prof = StripedProfile<T, N>::make(ref.data(), ref.size(), pw, map, -go, -ge);
+    const Maybe<Alignment> a = sw_simd_align<T, N>(q.data(), q.size(), prof);
+    if (a.status != SOME) return a.status == OVERFLOWED;
+    const int m = std::min(re - rs, qe - qs);
+    AlignmentStates want;
+    want.soft_clip((size_t)rs);
+    want.add_ciglet({(size_t)p, 'M'});
+    want.add_ciglet({(size_t)g, (uint8_t)(op == 'D' ? 'I' : 'D')});
+    want.add_ciglet({(size_t)(m - p), 'M'});
+    want.soft_clip(ref.size() - (size_t)re);
+    return (int)a.value.score == S && (int)a.value.ref_start == qs && (int)a.value.ref_end == qe && (int)a.value.query_start == rs &&
+           (int)a.value.query_end == re && a.value.states == want;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -175,7 +197,11 @@ int main(int argc, char** argv) {
                             returns_onegap<int16_t, 32>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe, best_p, g, op) &&
                             returns_onegap<int16_t, 64>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe, best_p, g, op) &&
                             returns_onegap<int8_t, 16>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe, best_p, g, op) &&
-                            returns_onegap<int8_t, 32>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe, best_p, g, op);
+                            returns_onegap<int8_t, 32>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe, best_p, g, op) &&
+                            returns_onegap_swapped<int16_t, 4>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe, best_p, g, op) &&
+                            returns_onegap_swapped<int16_t, 16>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe, best_p, g, op) &&
+                            returns_onegap_swapped<int16_t, 64>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe, best_p, g, op) &&
+                            returns_onegap_swapped<int8_t, 32>(ref, q, pw, map, sc.go, sc.ge, S, rs, re, qs, qe, best_p, g, op);
             if (!ok) {
                 printf("certified read whose striped alignment is not the one-gap alignment: S %d ref [%d,%d) query [%d,%d) p %d g %d %c scheme %d/%d/%d/%d\n  ref  ", S, rs, re,
                        qs, qe, best_p, g, op, sc.match, sc.mismatch, sc.go, sc.ge);

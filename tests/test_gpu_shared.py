@@ -381,3 +381,60 @@ def test_three_pass_with_the_shared_profile_on_tie_rich_and_diverged_reads(za, o
         assert aq.key(i) == okey(oracle.align_3pass(T, N, sc, seq, reads[i], other_is_query=True)[0]), i
         if i % 3 == 0:
             assert ar.key(i) == okey(oracle.align_3pass(T, N, sc, seq, reads[i], other_is_query=False)[0]), i
+
+
+@pytest.mark.parametrize("T,N", [("i16", 16), ("i8", 32)])
+def test_exact_alignment_with_the_shared_profile_skips_the_literal_pass_where_one_alignment_is_optimal(za, oracle, T, N):
+    """run_align_shared in certificate mode (zsw_capi_shared.hip; tests/models/align_gapless_cert.cpp and align_onegap_cert.cpp check
+    the swapped roles against the literal oracle): the two seeded passes of the shared ranges tell which reads have both maxima in one
+    cell each; those whose only optimal alignment is gapless or has one gap run get it from the classify pass, the others from the
+    literal striped recurrence over the shared sequence's profile. 12,000 reads — synthetic (indels in homopolymer runs: tied
+    placements), tie-rich, 3-8 % diverged: every record and ciglet must equal the all-literal path (ZSW_DEBUG_ALIGN_NO_CERTIFICATE), both
+    SeqSrc directions, and the oracle's literal sw_simd_align on a sample; most reads must have skipped the literal pass."""
+    import time
+
+    import torch
+
+    from test_gpu_bounds import diverged_reads
+    from zoe_amd import _lib, synth
+
+    ctx = za.SwContext.get(0)
+    rng = np.random.default_rng(stable_seed("shared-cert", T, N))
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seq = bytearray(synth.reference_host(1800))
+    seq[300:340] = bytes(rng.choice(alpha[:2], 40))
+    for i in range(700 + 3, 760):
+        seq[i] = seq[i - 3]
+    seq[1200:1260] = seq[100:160]
+    seq = bytes(seq)
+    L = 120
+    reads = np.concatenate([synth.reads_host(seq, 5, 8000, L), _tie_rich_reads(rng, seq, 2000, L), diverged_reads(seq, 1000, L, 30, 3),
+                            diverged_reads(seq, 1000, L, 80, 4)])
+    dna = za.WeightMatrix.new_dna_matrix(2, -5, b"N")
+    sc = osc(oracle, dna, -10, -1)
+    prof = za.SharedStripedProfile(seq, dna, -10, -1, T, N)
+    rb = za.ReadBatch.from_fixed(torch.from_numpy(np.ascontiguousarray(reads).reshape(-1)).cuda(), L)
+
+    def timed(src):
+        prof.sw_align(src)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        a = prof.sw_align(src)
+        torch.cuda.synchronize()
+        return a, time.perf_counter() - t0
+
+    aq, t_cert = timed(za.SeqBatchSrc.Query(rb))
+    ar, _ = timed(za.SeqBatchSrc.Reference(rb))
+    ctx.debug_set(_lib.DEBUG_ALIGN_NO_CERTIFICATE)
+    try:
+        lq, t_lit = timed(za.SeqBatchSrc.Query(rb))
+        lr, _ = timed(za.SeqBatchSrc.Reference(rb))
+    finally:
+        ctx.debug_set(0)
+    for got, want in ((aq, lq), (ar, lr)):
+        assert np.array_equal(got.status, want.status)
+        assert np.array_equal(got.records, want.records)
+        assert np.array_equal(got.inc, want.inc) and np.array_equal(got.op, want.op)
+    assert t_cert < 0.6 * t_lit, (t_cert, t_lit)
+    for i in range(0, len(reads), 37):
+        assert aq.key(i) == okey(oracle.align(T, N, sc, seq, reads[i], other_is_query=True)), i

@@ -594,6 +594,11 @@ __global__ void cert_status_kernel(uint32_t n, const uint8_t* status, const uint
     if (i < n) out[i] = done[i] ? (uint8_t)ZSW_STATUS_UNMAPPED : status[i];
 }
 
+hipError_t launch_cert_status(uint32_t n, const uint8_t* status, const uint8_t* done, uint8_t* out, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(cert_status_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, status, done, out);
+    return hipGetLastError();
+}
+
 // (grid-stride, one atomic per wavefront at the end: 10 M statuses used to be 156,000 atomics on one word, 1.8 ms)
 __global__ void count_some_kernel(const uint8_t* status, uint32_t n, uint32_t* out) {
     uint32_t mine = 0;

@@ -241,7 +241,7 @@ zsw_error run_ends_shared(zsw_context* ctx, const zsw_batch* reads, const Result
 
 // sw_simd_score_ranges of the shared role for every read, on the device (rs / re: positions in the read, qs / qe: in the profile
 // sequence); opens ctx->timer's interval and leaves it open.
-zsw_error ranges_shared_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, hipStream_t stream, RangesDev* out);
+zsw_error ranges_shared_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, hipStream_t stream, RangesDev* out, uint8_t* settled = nullptr);
 
 zsw_error run_ranges_shared(zsw_context* ctx, const zsw_batch* reads, const ResultRule& rule, uint32_t* out_score, uint32_t* out_rs,
                             uint32_t* out_re, uint32_t* out_qs, uint32_t* out_qe, uint8_t* out_status, uint8_t* out_tier, void* stream_) {
@@ -274,7 +274,8 @@ zsw_error run_ranges_shared(zsw_context* ctx, const zsw_batch* reads, const Resu
     return ZSW_OK;
 }
 
-zsw_error ranges_shared_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, hipStream_t stream, RangesDev* out) {
+// settled (optional, n bytes): 1 where both maxima of the read sit in one cell each (the two seeded passes agree), else 0
+zsw_error ranges_shared_device(zsw_context* ctx, const Staged& st, const ResultRule& rule, hipStream_t stream, RangesDev* out, uint8_t* settled) {
     zsw_error ze = ZSW_OK;
     const uint32_t n = st.b.n_reads;
     DevBuf* ws = ctx->sh_ws;
@@ -308,6 +309,7 @@ zsw_error ranges_shared_device(zsw_context* ctx, const Staged& st, const ResultR
     ro.fb_count = nullptr;
     BatchDev rest = st.b;
     const uint32_t* rest_count = nullptr;
+    if (settled) ZSW_HIP(ctx, hipMemsetAsync(settled, 0, n, stream));
     if (seeded) {
         // The reverse pass as a seeded pass of its own: reversed reads against the reversed profile sequence, whole sequences. If
         // the forward maximum sits in one cell, every alignment that scores it ends there, i.e. lies inside the prefixes the
@@ -344,7 +346,7 @@ zsw_error ranges_shared_device(zsw_context* ctx, const Staged& st, const ResultR
             ZSW_HIP(ctx, hipMemsetAsync(ws[SH_UCOUNT].p, 0, 4, stream));
             hipLaunchKernelGGL(settle_reverse_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, stream, st.b, n, (uint32_t)plen, ws[SH_UNIQUE].as<uint8_t>(),
                                ws[SH_UNIQUE_R].as<uint8_t>(), fo.score, fo.status, ro.score, ro.status, ro.ref_end, ro.query_end,
-                               ws[SH_ULIST].as<uint32_t>(), ws[SH_UCOUNT].as<uint32_t>(), (uint8_t*)nullptr);
+                               ws[SH_ULIST].as<uint32_t>(), ws[SH_UCOUNT].as<uint32_t>(), settled);
             rest.items = ws[SH_ULIST].as<uint32_t>();
             rest_count = ws[SH_UCOUNT].as<uint32_t>();
         }
@@ -428,8 +430,79 @@ zsw_error run_align_shared(zsw_context* ctx, const zsw_batch* reads, const Resul
     so.query_end = nullptr;
     so.fb_list = nullptr;
     so.fb_count = nullptr;
-    ze = shared_ends_device(ctx, st, rule, so, stream);
-    if (ze != ZSW_OK) return ze;
+    // Certificate mode, as in the read-as-profile role (zsw_capi.hip run_align; tests/models/align_gapless_cert.cpp and
+    // align_onegap_cert.cpp check the swapped roles too): the first pass is the whole of sw_simd_score_ranges in this role, whose two
+    // seeded passes tell which reads have both maxima in one cell each; a read whose only optimal alignment is gapless or has one gap
+    // run gets it from the classify pass of zsw_threepass.hip and never sees the literal recurrence, which in this role walks all the
+    // vectors of the shared sequence's profile for every base of the read.
+    const uint8_t* pass2_status = nullptr;
+    const bool certify = !(ctx->flags() & ZSW_DEBUG_ALIGN_NO_CERTIFICATE) && ctx->h_sc.gap_open > 0;
+    if (certify) {
+        const uint32_t MAXC0 = 32;
+        ZSW_HIP(ctx, ws[WS_CERT_OK].ensure((size_t)n + 4));
+        ZSW_HIP(ctx, ws[WS_CERT_DONE].ensure((size_t)n + 4));
+        ZSW_HIP(ctx, ws[WS_CERT_STATUS].ensure((size_t)n + 4));
+        ZSW_HIP(ctx, ws[WS_ALN].ensure((size_t)n * sizeof(zsw_alignment)));
+        ZSW_HIP(ctx, ws[WS_CIGSTART].ensure((size_t)n * 8));
+        ZSW_HIP(ctx, ws[WS_CIGRAW].ensure((size_t)n * 4));
+        ZSW_HIP(ctx, ws[WS_CIG].ensure((size_t)n * MAXC0 * 4));
+        ZSW_HIP(ctx, ws[WS_FBLIST].ensure((size_t)n * 4 + 4));
+        ZSW_HIP(ctx, ws[WS_FBCOUNT].ensure(16));
+        RangesDev rd;
+        ze = ranges_shared_device(ctx, st, rule, stream, &rd, ws[WS_CERT_OK].as<uint8_t>());
+        ctx->timer.end(stream);
+        if (ze != ZSW_OK) return ze;
+        so.score = rd.score;
+        so.status = rd.status;
+        so.tier = rd.tier;
+        so.ref_end = rd.re;
+        int maxw = 0;
+        for (int i = 0; i < ctx->h_sc.S * ctx->h_sc.S; ++i) maxw = std::max(maxw, (int)ctx->h_sc.w[i]);
+        ThreePassArgs a;
+        a.b = st.b;
+        a.ref = nullptr;
+        a.ref_len = 0;
+        a.pseq = ctx->d_pseq.as<uint8_t>();  // three_pass.rs:21-26 with the roles of this call: `reference` = read i
+        a.pseq_len = (uint32_t)ctx->pseq_len;
+        a.sc = ctx->d_sc.as<ScoringDev>();
+        a.score = rd.score;
+        a.rs = rd.rs;
+        a.re = rd.re;
+        a.qs = rd.qs;
+        a.qe = rd.qe;
+        a.status = rd.status;
+        a.list = nullptr;
+        a.list_count = nullptr;
+        a.dp_list = nullptr;
+        a.dp_count = nullptr;
+        a.dp_need_max = nullptr;
+        a.scratch = nullptr;
+        a.slots = 0;
+        a.slot_bytes = 0;
+        a.cig = ws[WS_CIG].as<uint32_t>();
+        a.maxc = MAXC0;
+        a.pool_base = 0;
+        a.by_item = 0;
+        a.cig_start = ws[WS_CIGSTART].as<uint64_t>();
+        a.cig_raw = ws[WS_CIGRAW].as<uint32_t>();
+        a.aln = ws[WS_ALN].as<zsw_alignment>();
+        a.fb_list = ws[WS_FBLIST].as<uint32_t>();
+        a.fb_count = ws[WS_FBCOUNT].as<uint32_t>();
+        a.invert = invert;
+        a.cert_ok = ws[WS_CERT_OK].as<uint8_t>();
+        a.cert_done = ws[WS_CERT_DONE].as<uint8_t>();
+        a.cert_maxw = maxw;
+        a.cert_go = ctx->h_sc.gap_open;
+        a.cert_ge = ctx->h_sc.gap_extend;
+        hipError_t ce = launch_threepass(a, std::min<uint32_t>((n + 63) / 64, 65536u), stream);
+        if (ce != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "shared align: certificate pass", ce);
+        ZSW_HIP(ctx, launch_cert_status(n, rd.status, ws[WS_CERT_DONE].as<uint8_t>(), ws[WS_CERT_STATUS].as<uint8_t>(), stream));
+        pass2_status = ws[WS_CERT_STATUS].as<uint8_t>();
+    } else {
+        ze = shared_ends_device(ctx, st, rule, so, stream);
+        if (ze != ZSW_OK) return ze;
+        pass2_status = so.status;
+    }
     // pass 2 per tier (each tier of the cascade has its own lane count, hence its own striping of the shared sequence)
     const int S = ctx->h_sc.S;
     const uint32_t plen = (uint32_t)ctx->pseq_len;
@@ -461,7 +534,7 @@ zsw_error run_align_shared(zsw_context* ctx, const zsw_batch* reads, const Resul
         BatchDev b = st.b;
         b.items = d_items;
         b.n_items = count;
-        hipError_t he = align_pass2_shared(N, ctx->d_pseq.as<uint8_t>(), plen, b, ctx->d_sc.as<ScoringDev>(), S, so.score, so.ref_end, so.status, W, maxc,
+        hipError_t he = align_pass2_shared(N, ctx->d_pseq.as<uint8_t>(), plen, b, ctx->d_sc.as<ScoringDev>(), S, so.score, so.ref_end, pass2_status, W, maxc,
                                            ringbuf.as<uint8_t>(), grid, cigbuf.as<uint32_t>(), 0, by_item, ws[WS_CIGSTART].as<uint64_t>(),
                                            ws[WS_CIGRAW].as<uint32_t>(), ws[WS_ALN].as<zsw_alignment>(), ws[WS_FBLIST].as<uint32_t>(),
                                            ws[WS_FBCOUNT].as<uint32_t>(), invert, stream,
@@ -479,7 +552,7 @@ zsw_error run_align_shared(zsw_context* ctx, const zsw_batch* reads, const Resul
         uint32_t* d_list = ws[WS_ITEMS].as<uint32_t>();
         uint32_t* d_count = ctx->sh_ws[SH_LIST].as<uint32_t>();
         ZSW_HIP(ctx, hipMemsetAsync(d_count, 0, 4, stream));
-        hipLaunchKernelGGL(iota_some_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, so.status, so.tier, t.code, d_list, d_count);
+        hipLaunchKernelGGL(iota_some_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, pass2_status, so.tier, t.code, d_list, d_count);
         uint32_t count = 0;
         ZSW_HIP(ctx, hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, stream));
         ZSW_HIP(ctx, hipStreamSynchronize(stream));

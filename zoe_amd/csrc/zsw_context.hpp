@@ -203,6 +203,8 @@ struct RangesDev {  // device arrays of sw_simd_score_ranges for every read (lib
 zsw_error threepass_third_pass(zsw_context* ctx, const Staged& st, const RangesDev& rd, const uint8_t* pseq, uint32_t pseq_len, bool host, int invert,
                                zsw_alignment* out_aln, uint8_t* out_status, uint8_t* out_tier, uint32_t* out_inc, uint8_t* out_op, uint64_t ciglet_cap,
                                uint64_t* out_n_ciglets, hipStream_t stream);
+// statuses as a literal second pass sees them: reads whose alignment a certificate pass wrote (done[i]) do not take part
+hipError_t launch_cert_status(uint32_t n, const uint8_t* status, const uint8_t* done, uint8_t* out, hipStream_t stream);
 // zsw_capi_shared.hip: the settlement of a reversed seeded pass (a read is
 // done if both maxima sit in one cell each and the scores agree; the others are listed for the exact reverse kernel)
 hipError_t launch_settle_reverse(const BatchDev& b, uint32_t n, uint32_t other_len, const uint8_t* uf, const uint8_t* ur, const uint32_t* fscore,
