@@ -71,7 +71,7 @@ struct ThreePassArgs {
     // Certificate mode of the classify pass (sw_simd_align's second pass skipped, zsw_capi.hip run_align; host model
     // tests/models/align_gapless_cert.cpp): cert_ok[i] = both maxima of read i sit in one cell each (forward and reversed seeded
     // pass, mode 3). A read whose ranges have equal lengths n, whose diagonal adds up to its score S and whose S exceeds
-    // cert_maxw * (n - 1) - 2 * cert_go has exactly one optimal alignment, the diagonal: it is written here (cert_done[i] = 1) and
+    // cert_maxw * (n - 1) - 3 * cert_go, and whose two-run alternatives stay below it (classify pass), has exactly one optimal alignment, the diagonal: it is written here (cert_done[i] = 1) and
     // is what sw_simd_align returns at every <T, N>; every other read is left to the literal striped kernel (cert_done[i] = 0).
     const uint8_t* cert_ok = nullptr;
     uint8_t* cert_done = nullptr;

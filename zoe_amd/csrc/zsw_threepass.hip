@@ -136,7 +136,9 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
             const bool cert = a.cert_ok != nullptr;
             const bool uniq = !cert || (a.cert_ok[id] && re > rs && qe > qs);
             if (a.cert_done) a.cert_done[id] = 0;
-            if (uniq && qlen == rlen && (!cert || (long long)score > (long long)a.cert_maxw * ((long long)rlen - 1) - 2ll * a.cert_go)) {
+            // (gapless certificate: three or more gap runs are ruled out by the potential — at most n - 1 pairs, 3 * gap_open —, two runs,
+            // an insertion and a deletion of the same length k in either order, by the potential too or by the sweep below)
+            if (uniq && qlen == rlen && (!cert || (long long)score > (long long)a.cert_maxw * ((long long)rlen - 1) - 3ll * a.cert_go)) {
                 int64_t sum = 0;
                 uint32_t k = 0;
                 for (; k + 4 <= qlen; k += 4) {  // four residues per (unaligned) load
@@ -147,7 +149,33 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                     for (int j = 0; j < 4; ++j) sum += wt((uint8_t)(rw >> (8 * j)), (uint8_t)(qw >> (8 * j)));
                 }
                 for (; k < qlen; ++k) sum += wt(reference[rs + k], query[qs + k]);
-                if ((sum < 0 ? 0u : (uint32_t)sum) == score) {
+                bool only = (sum < 0 ? 0u : (uint32_t)sum) == score;
+                if (only && cert) {
+                    // paths with two runs of k: pairs 0 .. i-1 on the diagonal, run, pairs i .. j-1 on the diagonal k rows (dir 0) or
+                    // k columns (dir 1) away, run, pairs j+k .. n-1 on the diagonal again: score - 2go - 2ge(k-1) + A(j) - B(i) with
+                    // A(j) = Q(j) - P0(j+k), B(i) = Q(i) - P0(i), 1 <= i <= j <= n-k-1 (tests/models/align_gapless_cert.cpp)
+                    const long long n_ = (long long)rlen, S_ = (long long)score;
+                    for (uint32_t k = 1; k < rlen && only; ++k) {
+                        if ((long long)a.cert_maxw * (n_ - k) - 2ll * a.cert_go - 2ll * a.cert_ge * ((long long)k - 1) < S_) break;
+                        for (int dir = 0; dir < 2 && only; ++dir) {
+                            const uint8_t* r1 = reference + rs + (dir == 0 ? k : 0);
+                            const uint8_t* q1 = query + qs + (dir == 0 ? 0 : k);
+                            int64_t qv = 0, p0j = 0, p0jk = 0, low = INT64_MAX, best_alt = INT64_MIN;
+                            for (uint32_t t = 0; t < k; ++t) p0jk += wt(reference[rs + t], query[qs + t]);
+                            for (uint32_t j = 1; j + k + 1 <= rlen; ++j) {
+                                qv += wt(r1[j - 1], q1[j - 1]);
+                                p0j += wt(reference[rs + j - 1], query[qs + j - 1]);
+                                p0jk += wt(reference[rs + j + k - 1], query[qs + j + k - 1]);
+                                const int64_t bj = qv - p0j;
+                                low = bj < low ? bj : low;
+                                const int64_t v = qv - p0jk - low;
+                                best_alt = v > best_alt ? v : best_alt;
+                            }
+                            if (best_alt != INT64_MIN && best_alt - 2ll * a.cert_go - 2ll * a.cert_ge * ((long long)k - 1) >= 0) only = false;
+                        }
+                    }
+                }
+                if (only) {
                     w.push(query_len - qe, 'S');
                     w.push(qe - qs, 'M');
                     w.push(qs, 'S');
