@@ -13,9 +13,13 @@
 //       ends an optimal path — E == H or F == H is tested before the diagonal — i.e. the LAST placement; the values along an
 //       optimal path are exact at every striping (E opens from an H that a diagonal step produced; the lazy-F loop does not
 //       stop while the lane that carries the run still has F > H - gap_open), so that choice does not depend on <T, N>.
-//   (4) An alignment between these corners with two or more gap runs has at most m pairs and pays at least 2 * gap_open +
-//       (g - 2) * gap_extend (both runs of the kind that makes up g; any other combination has fewer pairs and longer runs):
-//       S > maxw * m - 2 * gap_open - max(g - 2, 0) * gap_extend rules them out.
+//   (4) An alignment between these corners with three or more gap runs has at most m pairs and pays at least 3 * gap_open +
+//       max(g - 3, 0) * gap_extend: S must lie beyond maxw * m minus that. One with TWO runs — signed lengths a and rlen - qlen - a,
+//       i pairs on the first diagonal, the first run, j - i pairs on the diagonal a away, the second run, the rest on the last
+//       diagonal — scores P0(i) + Pa(j) - Pa(i) + Pz(M) - Pz(j) - cost(a): for every a that the potential does not rule out,
+//       the best (i, j) is one sweep over the prefix sums of the three diagonals, and it must stay below S. (Until the middle
+//       of round 4: the potential bound alone, S > maxw * m - 2 * gap_open - max(g - 2, 0) * gap_extend — one substitution
+//       beside the gap at 2 / -5, -10 / -1; now two, or one and a few N.)
 // Then that alignment is the ONLY one scoring S and every exact algorithm returns it: the oracle's literal sw_simd_align
 // (oracle/zoe_oracle.hpp, the restated striped.rs:449-598) must return [qs S][p M][g D|I][m - p M][len - qe S] at every lane count.
 // Checked for N = 2 .. 64 in 16-bit lanes and N = 16, 32 in 8-bit lanes under ten schemes, on pairs with one indel and few other
@@ -116,7 +120,7 @@ int main(int argc, char** argv) {
         int match, mismatch, go, ge;
     };
     const Sch schemes[] = {{2, -5, 10, 1}, {1, -1, 2, 1}, {3, -2, 5, 1}, {1, -3, 5, 2}, {5, -4, 8, 1}, {2, -2, 3, 3}, {4, -6, 12, 2}, {2, -10, 10, 1}, {1, -1, 1, 1}, {3, -1, 1, 0}};
-    long pairs = 0, certified = 0, unique_both = 0, tied = 0;
+    long pairs = 0, certified = 0, unique_both = 0, tied = 0, swept = 0;
     for (int it = 0; it < iters; ++it) {
         const Sch& sc = schemes[it % (sizeof(schemes) / sizeof(schemes[0]))];
         const WeightMatrixI8 wm = WeightMatrixI8::make(map, (int8_t)sc.match, (int8_t)sc.mismatch, 'N');
@@ -141,7 +145,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < L; ++i) {
                 const int e = rnd(0, 99);
                 uint8_t b = ref[std::min(p, R - 1)];
-                if (e < 2) b = keys[rnd(0, 3)];            // a substitution
+                if (e < 4) b = keys[rnd(0, 3)];            // a substitution
                 else if (e < 5) b = 'N';
                 else if (i == indel_at && indel_len < 0) { p += -indel_len; }                                  // the deletion ...
                 else if (i == indel_at && indel_len > 0) { for (int x = 0; x < indel_len; ++x) q.push_back(keys[rnd(0, 3)]); }  // ... or the insertion
@@ -186,7 +190,38 @@ int main(int argc, char** argv) {
                 }
             }
             if (best != S || best_p - first_p != n_best - 1) continue;  // one placement, or a run of adjacent ones
-            if (!((long)S > (long)sc.match * m - 2l * sc.go - (long)std::max(g - 2, 0) * sc.ge)) continue;
+            // (4) nothing with more runs reaches S. Three or more runs: at most m pairs, 3 * gap_open and, if all of them make up g,
+            // (g - 3) extensions. Two runs: signed lengths a and b = gs - a (gs = rlen - qlen: a deletion counts +, an insertion -),
+            // i pairs on the first diagonal, the run a, j - i pairs on the diagonal a away, the run b, the rest on the last diagonal;
+            // for every a that the potential does not rule out, the best (i, j) is one sweep over the prefix sums of three diagonals.
+            if (!((long)S > (long)sc.match * m - 3l * sc.go - (long)std::max(g - 3, 0) * sc.ge)) continue;
+            bool two_runs_below = true;
+            int swept_here = 0;
+            const int gs = rlen - qlen;
+            for (int a = -(m + g); a <= m + g && two_runs_below; ++a) {
+                const int b = gs - a;
+                if (a == 0 || b == 0) continue;
+                const int ap = std::max(a, 0), an = std::max(-a, 0), bp = std::max(b, 0), bn = std::max(-b, 0);
+                const int M = rlen - ap - bp;  // pairs (= qlen - an - bn)
+                if (M < 2) continue;
+                const long cost = 2l * sc.go + (long)sc.ge * (std::abs(a) + std::abs(b) - 2);
+                if ((long)sc.match * M - cost < (long)S) continue;  // the potential rules this pair of runs out
+                ++swept_here;
+                // score(i, j) = P0(i) + Pa(j) - Pa(i) + Pz(M) - Pz(j) - cost,  1 <= i <= j <= M - 1
+                long p0 = 0, pa = 0, pz = 0, pzM = 0;
+                for (int t = 0; t < M; ++t) pzM += wt(rs + t + ap + bp, qs + t + an + bn);
+                long low = 1l << 40, best_alt = -(1l << 40);
+                for (int j = 1; j <= M - 1; ++j) {
+                    p0 += wt(rs + j - 1, qs + j - 1);
+                    pa += wt(rs + j - 1 + ap, qs + j - 1 + an);
+                    pz += wt(rs + j - 1 + ap + bp, qs + j - 1 + an + bn);
+                    low = std::min(low, pa - p0);                       // i = j: no pairs between the runs
+                    best_alt = std::max(best_alt, pa - pz - low);
+                }
+                if (pzM - cost + best_alt >= (long)S) two_runs_below = false;
+            }
+            if (!two_runs_below) continue;
+            if (swept_here) ++swept;
             ++certified;
             if (n_best > 1) ++tied;
             const char op = del ? 'D' : 'I';
@@ -213,7 +248,7 @@ int main(int argc, char** argv) {
             }
         }
     }
-    printf("pairs %ld, both maxima in one cell %ld, certified %ld, of which with tied placements %ld\n", pairs, unique_both, certified, tied);
+    printf("pairs %ld, both maxima in one cell %ld, certified %ld, of which with tied placements %ld, with two-run sweeps %ld\n", pairs, unique_both, certified, tied, swept);
     if (certified * 12 < pairs) {
         printf("the certificate is vacuous: fewer than a twelfth of the pairs get one\n");
         return 1;

@@ -189,8 +189,9 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
             } else if (cert && uniq && qlen != rlen) {
                 const bool del = rlen > qlen;  // the run consumes reference rows
                 const uint32_t g = del ? rlen - qlen : qlen - rlen, m = del ? qlen : rlen;
-                const long long two_runs = (long long)a.cert_maxw * m - 2ll * a.cert_go - (long long)(g > 2 ? g - 2 : 0) * a.cert_ge;
-                if (m >= 2 && (long long)score > two_runs) {
+                // three or more runs: ruled out by the potential; two runs: by the potential or by the sweeps below
+                const long long three_runs = (long long)a.cert_maxw * m - 3ll * a.cert_go - (long long)(g > 3 ? g - 3 : 0) * a.cert_ge;
+                if (m >= 2 && a.cert_ge > 0 && (long long)score > three_runs) {
                     // second diagonal: the pairs behind the run
                     const uint8_t* r1 = reference + rs + (del ? g : 0);
                     const uint8_t* q1 = query + qs + (del ? 0 : g);
@@ -213,7 +214,43 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                         }
                     }
                     // one placement, or adjacent ones (a gap inside a homopolymer run): the walk from the end takes the last
-                    if (best_p - first_p == n_best - 1 && best == (int64_t)score) {
+                    bool only = best_p - first_p == n_best - 1 && best == (int64_t)score;
+                    if (only) {
+                        // two runs of signed lengths ra and rb = gs - ra (a deletion counts +, an insertion -): i pairs on the first
+                        // diagonal, run ra, j - i pairs on the diagonal ra away, run rb, the rest on the last diagonal:
+                        // P0(i) + Pa(j) - Pa(i) + Pz(M) - Pz(j) - cost, 1 <= i <= j <= M - 1 (tests/models/align_onegap_cert.cpp)
+                        const long long gs = (long long)rlen - (long long)qlen, S_ = (long long)score;
+                        // |ra| + |rb| <= X or the potential rules the pair out; |ra| + |gs - ra| >= 2 |ra| - g
+                        const long long X = ((long long)a.cert_maxw * m - 2ll * a.cert_go - S_) / a.cert_ge + 2;
+                        const long long amax = X >= 0 ? (X + g) / 2 + 1 : 0;
+                        for (long long ra = -amax; ra <= amax && only; ++ra) {
+                            const long long rb = gs - ra;
+                            if (ra == 0 || rb == 0) continue;
+                            const long long ap = ra > 0 ? ra : 0, an = ra < 0 ? -ra : 0, bp = rb > 0 ? rb : 0, bn = rb < 0 ? -rb : 0;
+                            const long long M = (long long)rlen - ap - bp;
+                            if (M < 2) continue;
+                            const long long cost = 2ll * a.cert_go + (long long)a.cert_ge * (ap + an + bp + bn - 2);
+                            if ((long long)a.cert_maxw * M - cost < S_) continue;
+                            const uint8_t* ra_r = reference + rs + ap;
+                            const uint8_t* ra_q = query + qs + an;
+                            const uint8_t* rz_r = reference + rs + ap + bp;
+                            const uint8_t* rz_q = query + qs + an + bn;
+                            int64_t pzM = 0;
+                            for (long long t = 0; t < M; ++t) pzM += wt(rz_r[t], rz_q[t]);
+                            int64_t s0 = 0, sa = 0, sz = 0, low = INT64_MAX, best_alt = INT64_MIN;
+                            for (long long j = 1; j <= M - 1; ++j) {
+                                s0 += wt(reference[rs + j - 1], query[qs + j - 1]);
+                                sa += wt(ra_r[j - 1], ra_q[j - 1]);
+                                sz += wt(rz_r[j - 1], rz_q[j - 1]);
+                                const int64_t bj = sa - s0;
+                                low = bj < low ? bj : low;
+                                const int64_t v = sa - sz - low;
+                                best_alt = v > best_alt ? v : best_alt;
+                            }
+                            if (pzM - cost + best_alt >= S_) only = false;
+                        }
+                    }
+                    if (only) {
                         w.push(query_len - qe, 'S');
                         w.push(m - best_p, 'M');
                         w.push(g, del ? 'D' : 'I');
