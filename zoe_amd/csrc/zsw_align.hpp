@@ -76,6 +76,13 @@ struct ThreePassArgs {
     const uint8_t* cert_ok = nullptr;
     uint8_t* cert_done = nullptr;
     int cert_maxw = 0, cert_go = 0, cert_ge = 0;  // (the one-gap certificate, tests/models/align_onegap_cert.cpp, needs gap_extend too)
+    // The sweeps over the two-run alternatives cost a read several times the rest of the certificate, and one read in seven needs
+    // them: with one thread per read the other lanes of its wavefront would wait. The classify launch therefore lists those reads
+    // (sweep_list / sweep_count) and a second launch — list = that list, sweep_pass = true: classify code, sweeps included — takes
+    // them, every lane busy.
+    uint32_t* sweep_list = nullptr;
+    uint32_t* sweep_count = nullptr;
+    bool sweep_pass = false;
 };
 
 hipError_t launch_threepass(const ThreePassArgs& a, uint32_t grid, hipStream_t stream);

@@ -494,8 +494,18 @@ zsw_error run_align_shared(zsw_context* ctx, const zsw_batch* reads, const Resul
         a.cert_maxw = maxw;
         a.cert_go = ctx->h_sc.gap_open;
         a.cert_ge = ctx->h_sc.gap_extend;
+        // reads that need the sweeps over their two-run alternatives are listed and take a second, dense launch (ThreePassArgs::sweep_list)
+        ZSW_HIP(ctx, ws[WS_ITEMS].ensure((size_t)n * 4 + 4));
+        ZSW_HIP(ctx, hipMemsetAsync(ws[WS_FBCOUNT].as<uint32_t>() + 2, 0, 4, stream));
+        a.sweep_list = ws[WS_ITEMS].as<uint32_t>();
+        a.sweep_count = ws[WS_FBCOUNT].as<uint32_t>() + 2;
         hipError_t ce = launch_threepass(a, std::min<uint32_t>((n + 63) / 64, 65536u), stream);
         if (ce != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "shared align: certificate pass", ce);
+        a.list = a.sweep_list;
+        a.list_count = a.sweep_count;
+        a.sweep_pass = true;
+        ce = launch_threepass(a, std::min<uint32_t>((n / 4 + 63) / 64 + 1, 16384u), stream);
+        if (ce != hipSuccess) return fail(ctx, ZSW_ERR_HIP, "shared align: certificate pass (sweeps)", ce);
         ZSW_HIP(ctx, launch_cert_status(n, rd.status, ws[WS_CERT_DONE].as<uint8_t>(), ws[WS_CERT_STATUS].as<uint8_t>(), stream));
         pass2_status = ws[WS_CERT_STATUS].as<uint8_t>();
     } else {

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
         out.query_len = query_len;
         out.ciglet_offset = 0;
         bool done = false;
-        if (!a.list) {
+        if (!a.list || a.sweep_pass) {
             // classify pass: the no-gaps shortcut (three_pass.rs:37-58) is resolved here, the rest is queued for the DP pass
             // (certificate mode: only reads with one optimal alignment, which must be this diagonal; the rest is not touched)
             // Certificate mode (run_align): a.cert_ok[id] = both maxima of the read sit in one cell each, so every alignment that
@@ -134,6 +134,8 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
             // insertion and a deletion may reach it (tests/models/align_gapless_cert.cpp). Ranges that differ by g: one placement
             // of ONE gap run of g (or a run of adjacent placements) must reach it, and no path with two runs may (tests/models/align_onegap_cert.cpp).
             const bool cert = a.cert_ok != nullptr;
+            const bool defer = a.sweep_list != nullptr && !a.sweep_pass;  // reads that need the sweeps wait for the second launch
+            bool deferred = false;
             const bool uniq = !cert || (a.cert_ok[id] && re > rs && qe > qs);
             if (a.cert_done) a.cert_done[id] = 0;
             // (gapless certificate: three or more gap runs are ruled out by the potential — at most n - 1 pairs, 3 * gap_open —, two runs,
@@ -150,6 +152,10 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                 }
                 for (; k < qlen; ++k) sum += wt(reference[rs + k], query[qs + k]);
                 bool only = (sum < 0 ? 0u : (uint32_t)sum) == score;
+                if (only && cert && defer && (long long)a.cert_maxw * ((long long)rlen - 1) - 2ll * a.cert_go >= (long long)score) {
+                    only = false;  // (k = 1 is not ruled out by the potential: sweeps needed)
+                    deferred = true;
+                }
                 if (only && cert) {
                     // paths with two runs of k: pairs 0 .. i-1 on the diagonal, run, pairs i .. j-1 on the diagonal k rows (dir 0) or
                     // k columns (dir 1) away, run, pairs j+k .. n-1 on the diagonal again: score - 2go - 2ge(k-1) + A(j) - B(i) with
@@ -231,6 +237,11 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                             if (M < 2) continue;
                             const long long cost = 2ll * a.cert_go + (long long)a.cert_ge * (ap + an + bp + bn - 2);
                             if ((long long)a.cert_maxw * M - cost < S_) continue;
+                            if (defer) {
+                                only = false;
+                                deferred = true;
+                                break;
+                            }
                             const uint8_t* ra_r = reference + rs + ap;
                             const uint8_t* ra_q = query + qs + an;
                             const uint8_t* rz_r = reference + rs + ap + bp;
@@ -265,6 +276,7 @@ __global__ __launch_bounds__(64) void threepass_kernel(ThreePassArgs a) {
                     }
                 }
             }
+            if (deferred) a.sweep_list[atomicAdd(a.sweep_count, 1u)] = id;
             if (!done && a.cert_ok) continue;
             if (!done) {
                 const uint32_t k = atomicAdd(a.dp_count, 1u);
